@@ -1,0 +1,189 @@
+/*
+ * include/lcpc_hip.h -- C ABI of the MI355X-native lcpc-2d commit / prove path.
+ *
+ * Drop-in boundary for conroi/lcpc (reference @ /root/reference; file:line below cite that tree).
+ * The reference's plugin API for this path is the LcEncoding trait (lcpc-2d/src/lib.rs:74-104)
+ * plus LcCommit::{commit, prove, get_root} (lib.rs:270-312) and LcEvalProof::verify (lib.rs:518-527).
+ * Per-row `encode` cannot be the FFI seam (it is called once per row from inside a Rayon closure,
+ * lib.rs:648-653), so the seam is one level up: whole-matrix operations on a device-resident
+ * commitment, with a batched single-row `encode` kept for the verifier.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative lcpc_status; nothing throws across the ABI;
+ *  - field elements cross exactly as ff_derive stores them: L little-endian uint64_t limbs in
+ *    Montgomery form (R = 2^(64 L)), so a Rust `&[Ft255]` is passed as `*const u64` unchanged
+ *    (lcpc-test-fields/src/lib.rs:18-58); digests are 32 raw bytes;
+ *  - the caller owns every host buffer; the context owns all device memory (coeffs, comm, hashes
+ *    stay on the GPU after commit, as LcCommit retains them, lib.rs:172-184);
+ *  - a context is used by one host thread at a time; contexts are independent;
+ *  - `*_device` entry points take HIP device pointers + a hipStream_t (passed as void*), so a host
+ *    runtime (torch, or a Rust hip-sys binding) can keep inputs resident in HBM.
+ */
+#ifndef LCPC_HIP_H
+#define LCPC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCPC_ABI_VERSION 1
+
+/* fields of lcpc-test-fields/src/lib.rs:13-59 */
+enum { LCPC_FT63 = 0, LCPC_FT127 = 1, LCPC_FT191 = 2, LCPC_FT255 = 3 };
+/* encodings: lcpc-ligero-pc/src/lib.rs:31-37 (LigeroEncodingRho), lcpc-brakedown-pc/src/lib.rs:41-47 (SdigEncodingS) */
+enum { LCPC_ENC_LIGERO = 0, LCPC_ENC_SDIG = 1 };
+/* D: Digest -- every reference test/bench uses blake3::Hasher */
+enum { LCPC_HASH_BLAKE3 = 0 };
+
+typedef enum {
+  LCPC_OK = 0,
+  /* ProverError, lcpc-2d/src/lib.rs:111-131 */
+  LCPC_ERR_TOO_BIG = -1,
+  LCPC_ERR_ENCODE = -2,
+  LCPC_ERR_COMMIT = -3,
+  LCPC_ERR_COLUMN_NUMBER = -4,
+  LCPC_ERR_OUTER_TENSOR = -5,
+  /* the reference's assert!()s on caller-shaped input (lib.rs:630-632, ligero lib.rs:139) */
+  LCPC_ERR_DIMS = -6,
+  LCPC_ERR_ARG = -7,
+  LCPC_ERR_STATE = -8,      /* e.g. prove before commit */
+  /* device / runtime */
+  LCPC_ERR_HIP = -16,
+  LCPC_ERR_NOMEM = -17,
+  LCPC_ERR_NO_DEVICE = -18,
+  /* VerifierError, lib.rs:137-166 */
+  LCPC_VERR_NUM_COL_OPENS = -32,
+  LCPC_VERR_COLUMN_PATH = -33,
+  LCPC_VERR_COLUMN_EVAL = -34,
+  LCPC_VERR_COLUMN_DEGREE = -35,
+  LCPC_VERR_OUTER_TENSOR = -36,
+  LCPC_VERR_INNER_TENSOR = -37,
+  LCPC_VERR_ENCODING_DIMS = -38,
+  LCPC_VERR_ENCODE = -39,
+  LCPC_VERR_MALFORMED = -40 /* bincode payload does not parse (serde error in the reference) */
+} lcpc_status;
+
+typedef struct lcpc_ctx lcpc_ctx;
+typedef struct lcpc_transcript lcpc_transcript;
+
+typedef struct {
+  uint32_t field;        /* LCPC_FT* */
+  uint32_t encoding;     /* LCPC_ENC_* */
+  uint32_t hash;         /* LCPC_HASH_BLAKE3 */
+  uint32_t rho_num, rho_den;  /* Ligero rate Rn/Rd (default alias 1/2: ligero lib.rs:189) */
+  uint32_t sdig_code;    /* 1..6 = SdigCode1..6 (codespec.rs:169-232); default 3 (brakedown lib.rs:19) */
+  uint64_t seed;         /* Brakedown matgen seed (brakedown lib.rs:103) */
+  uint64_t n_coeffs;     /* `len`: dims come from the restated `new(len)` optimisers ... */
+  uint64_t n_per_row;    /* ... unless n_per_row and n_cols are both nonzero: `new_from_dims` */
+  uint64_t n_cols;
+  int32_t  device;       /* HIP device ordinal */
+  /* row sharding across GPUs (one ctx/process per GPU): this ctx holds shard `shard_rank` of
+   * `shard_count`; 0/0 or 0/1 = unsharded.  Shards are aligned to BLAKE3 chunk boundaries of the
+   * leaf message so that each GPU reduces its rows to chunk chaining values. */
+  uint32_t shard_rank, shard_count;
+} lcpc_params;
+
+/* ---- construction: LigeroEncoding::new / new_from_dims (ligero lib.rs:121-148),
+ *      SdigEncoding::new / new_from_dims (brakedown lib.rs:103-137).  Twiddles / expander matrices
+ *      are built and uploaded here, outside any timed commit (as in rough_bench, ligero tests.rs:86-90). */
+int  lcpc_ctx_create(const lcpc_params *params, lcpc_ctx **out);
+void lcpc_ctx_destroy(lcpc_ctx *ctx);
+const char *lcpc_strerror(int status);
+const char *lcpc_last_error(const lcpc_ctx *ctx);     /* detail string for LCPC_ERR_HIP etc. */
+int  lcpc_abi_version(void);
+
+/* ---- LcEncoding trait (lcpc-2d/src/lib.rs:74-104) ---- */
+/* get_dims(len) (ligero lib.rs:166-169, brakedown lib.rs:155-158) */
+int  lcpc_get_dims(const lcpc_ctx *ctx, uint64_t len, uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols);
+/* dims_ok (ligero lib.rs:171-177, brakedown lib.rs:160-167): returns 1 / 0 */
+int  lcpc_dims_ok(const lcpc_ctx *ctx, uint64_t n_per_row, uint64_t n_cols);
+uint64_t lcpc_get_n_col_opens(const lcpc_ctx *ctx);       /* ligero lib.rs:179-181 */
+uint64_t lcpc_get_n_degree_tests(const lcpc_ctx *ctx);    /* ligero lib.rs:183-185 */
+uint32_t lcpc_field_limbs(const lcpc_ctx *ctx);           /* L */
+/* static `_get_dims(len)` without a context (ligero lib.rs:70-112; brakedown lib.rs:69-110) */
+int  lcpc_static_get_dims(const lcpc_params *params, uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols);
+/* encode (ligero lib.rs:162-164, brakedown lib.rs:150-153), batched: `rows` holds n_rows rows of
+ * n_cols elements each, first n_per_row = message, rest zero on entry; encoded in place. */
+int  lcpc_encode_rows(lcpc_ctx *ctx, uint64_t *rows_host, uint64_t n_rows);
+
+/* ---- LcCommit (lcpc-2d/src/lib.rs:172-184, 270-312) ---- */
+/* commit(coeffs, enc) (lib.rs:299-301 -> 622-671): pad, encode every row, hash columns, Merkleize.
+ * comm / coeffs / hashes stay on the device.  `root` (32 bytes) may be NULL. */
+int  lcpc_commit(lcpc_ctx *ctx, const uint64_t *coeffs_host, uint64_t n_coeffs, uint8_t *root);
+/* same with the coefficients already resident in HBM (device pointer), work enqueued on `stream`;
+ * if `root` is non-NULL the call synchronises the stream and copies the root out. */
+int  lcpc_commit_device(lcpc_ctx *ctx, const uint64_t *coeffs_dev, uint64_t n_coeffs, void *stream, uint8_t *root);
+/* test hook for lcpc-2d/src/tests.rs:435-466 `random_comm` + `merkleize` (tests.rs:136-149): install a
+ * caller-supplied comm (n_rows x n_cols) and coeffs (n_rows x n_per_row, may be NULL), then Merkleize. */
+int  lcpc_commit_from_parts(lcpc_ctx *ctx, const uint64_t *comm_host, const uint64_t *coeffs_host,
+                            uint64_t n_rows, uint8_t *root);
+int  lcpc_get_root(lcpc_ctx *ctx, uint8_t root[32]);                /* get_root lib.rs:276-281 */
+int  lcpc_commit_dims(const lcpc_ctx *ctx, uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols,
+                      uint64_t *n_hashes);                           /* get_n_rows/.. lib.rs:283-296 */
+int  lcpc_get_hashes(lcpc_ctx *ctx, uint8_t *hashes);               /* LcCommit.hashes: (2*np2-1)*32 bytes */
+int  lcpc_get_comm(lcpc_ctx *ctx, uint64_t row0, uint64_t n_rows, uint64_t *out);    /* LcCommit.comm rows */
+int  lcpc_get_coeffs(lcpc_ctx *ctx, uint64_t row0, uint64_t n_rows, uint64_t *out);  /* LcCommit.coeffs rows */
+
+/* collapse_columns (lib.rs:1095-1123; test alias eval_outer lib.rs:1176-1202) for n_tensors tensors
+ * of n_rows elements each, fused into one pass over coeffs: polys[t][j] = sum_r coeffs[r][j]*tensors[t][r]. */
+int  lcpc_collapse(lcpc_ctx *ctx, const uint64_t *tensors_host, uint32_t n_tensors, uint64_t *polys_host);
+/* open_column (lib.rs:788-825) for n columns: col_vals[n][n_rows][L], paths[n][path_len][32],
+ * path_len = ceil(log2 n_cols).  LCPC_ERR_COLUMN_NUMBER if any column >= n_cols. */
+int  lcpc_open_columns(lcpc_ctx *ctx, const uint64_t *cols, uint32_t n, uint64_t *col_vals, uint8_t *paths);
+
+/* ---- merlin::Transcript (the `tr: &mut Transcript` argument of prove/verify, lib.rs:304-311, 518-527) ---- */
+lcpc_transcript *lcpc_transcript_new(const uint8_t *label, size_t len);
+lcpc_transcript *lcpc_transcript_clone(const lcpc_transcript *);
+void lcpc_transcript_append_message(lcpc_transcript *, const uint8_t *label, size_t llen, const uint8_t *msg, size_t mlen);
+void lcpc_transcript_challenge_bytes(lcpc_transcript *, const uint8_t *label, size_t llen, uint8_t *out, size_t n);
+void lcpc_transcript_free(lcpc_transcript *);
+
+/* ---- prove / verify ---- */
+/* LcCommit::prove (lib.rs:304-311 -> 1004-1093).  The proof is returned in the reference's bincode 1.3
+ * wire layout (lib.rs:550-609): the only way to hand an LcEvalProof to the reference (its fields are
+ * private).  `*proof` is malloc'ed; free with lcpc_free.  cols_opened (n_col_opens entries) may be NULL. */
+int  lcpc_prove(lcpc_ctx *ctx, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
+                uint8_t **proof, uint64_t *proof_len, uint64_t *cols_opened);
+/* LcEvalProof::verify (lib.rs:518-527 -> 832-952) on a bincode proof; `ctx` plays the role of `enc`
+ * (it need not hold a commitment).  eval_out: L limbs. */
+int  lcpc_verify(lcpc_ctx *ctx, const uint8_t root[32], const uint64_t *outer_tensor, uint64_t n_outer,
+                 const uint64_t *inner_tensor, uint64_t n_inner, const uint8_t *proof, uint64_t proof_len,
+                 lcpc_transcript *tr, uint64_t *eval_out);
+/* bincode of LcRoot (lib.rs:373-384): 8-byte length + 32 bytes -> out[40] */
+void lcpc_root_bincode(const uint8_t root[32], uint8_t out[40]);
+void lcpc_free(void *p);
+
+/* ---- row-sharded commit across GPUs (one ctx per GPU; the exchange is done by the caller, e.g.
+ *      torch.distributed all_gather over RCCL/xGMI) ---- */
+/* rows [row_begin,row_end) and leaf-message chunks [chunk_begin,chunk_end) owned by this shard for a
+ * commitment of n_rows_total rows; n_chunks_total = BLAKE3 chunks per leaf message. */
+int  lcpc_shard_layout(const lcpc_ctx *ctx, uint64_t n_rows_total, uint64_t *row_begin, uint64_t *row_end,
+                       uint64_t *chunk_begin, uint64_t *chunk_end, uint64_t *n_chunks_total);
+/* phase 1: encode the local rows (coeffs_dev = local rows only, row-major) and reduce them to one
+ * BLAKE3 chaining value per (local chunk, column): cvs_dev[(chunk - chunk_begin) * n_cols + col][32 B]. */
+int  lcpc_commit_shard_device(lcpc_ctx *ctx, const uint64_t *coeffs_local_dev, uint64_t n_rows_total,
+                              void *stream, uint8_t *cvs_dev);
+/* phase 2 (after the all-gather): all_cvs_dev[chunk * n_cols + col][32 B] for every chunk -> leaf
+ * digests, Merkle tree, root. */
+int  lcpc_commit_finish_device(lcpc_ctx *ctx, const uint8_t *all_cvs_dev, uint64_t n_rows_total,
+                               void *stream, uint8_t *root);
+/* collapse on the local rows only (tensor entries for the local rows); partial results are summed
+ * mod p by lcpc_field_sum_device after an all-gather. */
+int  lcpc_collapse_device(lcpc_ctx *ctx, const uint64_t *tensors_dev, uint32_t n_tensors, void *stream,
+                          uint64_t *polys_dev);
+int  lcpc_field_sum_device(lcpc_ctx *ctx, const uint64_t *parts_dev, uint32_t n_parts, uint64_t n_elems,
+                           void *stream, uint64_t *out_dev);
+
+/* ---- measurement hooks (bench.py): HIP-event time of each kernel group of the last commit, ms ---- */
+typedef struct {
+  float encode_ms, hash_ms, merkle_ms, total_ms;
+  uint32_t encode_launches, hash_launches, merkle_launches;
+} lcpc_timings;
+int  lcpc_set_timing(lcpc_ctx *ctx, int enable);
+int  lcpc_get_timings(lcpc_ctx *ctx, lcpc_timings *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCPC_HIP_H */

@@ -1,0 +1,325 @@
+"""lcpc_amd -- host-side mirror of conroi/lcpc's LcEncoding / LcCommit / prove / verify API over the
+MI355X-native C ABI (include/lcpc_hip.h).  The reference's toolchain (Rust) is absent from this image, so
+the host side above the C ABI is Python + ctypes with the reference's names, argument meaning and error
+behaviour; INTEGRATION.md shows the Rust `extern "C"` binding a maintainer would add instead.
+
+Field elements are numpy uint64 arrays of shape (n, L): ff_derive's Montgomery limbs, exactly what a Rust
+`&[FtN]` is in memory.  (/root/reference citations: see include/lcpc_hip.h.)"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LcpcParams, LcpcTimings
+
+FT63, FT127, FT191, FT255 = 0, 1, 2, 3
+FIELD_LIMBS = {FT63: 1, FT127: 2, FT191: 3, FT255: 4}
+ENC_LIGERO, ENC_SDIG = 0, 1
+
+
+class LcpcError(RuntimeError):
+    """a negative lcpc_status; .code mirrors ProverError / VerifierError (lcpc-2d/src/lib.rs:111-166)."""
+
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = _lib.lib().lcpc_strerror(code).decode()
+        super().__init__("%s (%d)%s" % (msg, code, (": " + detail) if detail else ""))
+
+
+ERR_TOO_BIG, ERR_ENCODE, ERR_COMMIT, ERR_COLUMN_NUMBER, ERR_OUTER_TENSOR, ERR_DIMS, ERR_ARG, ERR_STATE = -1, -2, -3, -4, -5, -6, -7, -8
+VERR_NUM_COL_OPENS, VERR_COLUMN_PATH, VERR_COLUMN_EVAL, VERR_COLUMN_DEGREE = -32, -33, -34, -35
+VERR_OUTER_TENSOR, VERR_INNER_TENSOR, VERR_ENCODING_DIMS, VERR_ENCODE, VERR_MALFORMED = -36, -37, -38, -39, -40
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _elems(a, L):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.size % L:
+        raise ValueError("element array size is not a multiple of L")
+    return a
+
+
+class Transcript:
+    """merlin::Transcript (the `tr: &mut Transcript` of prove/verify)."""
+
+    def __init__(self, label=b"", _h=None):
+        self._h = _h if _h is not None else _lib.lib().lcpc_transcript_new(label, len(label))
+
+    def append_message(self, label, message):
+        _lib.lib().lcpc_transcript_append_message(self._h, label, len(label), bytes(message), len(message))
+
+    def challenge_bytes(self, label, n):
+        out = C.create_string_buffer(n)
+        _lib.lib().lcpc_transcript_challenge_bytes(self._h, label, len(label), out, n)
+        return out.raw
+
+    def clone(self):
+        return Transcript(_h=_lib.lib().lcpc_transcript_clone(self._h))
+
+    def __del__(self):
+        try:
+            _lib.lib().lcpc_transcript_free(self._h)
+        except Exception:
+            pass
+
+
+class _Encoding:
+    """common part of the two LcEncoding implementors; owns one lcpc_ctx (encoder tables on the GPU)."""
+
+    def __init__(self, params):
+        self.params = params
+        h = C.c_void_p()
+        rc = _lib.lib().lcpc_ctx_create(C.byref(params), C.byref(h))
+        if rc:
+            raise LcpcError(rc)
+        self._h = h
+        self.field = params.field
+        self.L = FIELD_LIMBS[params.field]
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.lib().lcpc_get_dims(self._h, 1, C.byref(a), C.byref(b), C.byref(c))
+        self.n_per_row, self.n_cols = b.value, c.value
+
+    def _check(self, rc):
+        if rc:
+            raise LcpcError(rc, _lib.lib().lcpc_last_error(self._h).decode())
+
+    # LcEncoding trait, lcpc-2d/src/lib.rs:74-104
+    def get_dims(self, length):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(_lib.lib().lcpc_get_dims(self._h, length, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def dims_ok(self, n_per_row, n_cols):
+        return bool(_lib.lib().lcpc_dims_ok(self._h, n_per_row, n_cols))
+
+    def get_n_col_opens(self):
+        return _lib.lib().lcpc_get_n_col_opens(self._h)
+
+    def get_n_degree_tests(self):
+        return _lib.lib().lcpc_get_n_degree_tests(self._h)
+
+    def encode(self, rows):
+        """in place on a copy: rows of n_cols elements, message in the first n_per_row, rest zero."""
+        rows = _elems(rows, self.L).copy()
+        n = rows.size // (self.L * self.n_cols)
+        if n * self.L * self.n_cols != rows.size:
+            raise LcpcError(ERR_ENCODE, "row length != n_cols")
+        self._check(_lib.lib().lcpc_encode_rows(self._h, _ptr(rows), n))
+        return rows
+
+    def set_timing(self, on=True):
+        self._check(_lib.lib().lcpc_set_timing(self._h, 1 if on else 0))
+
+    def timings(self):
+        t = LcpcTimings()
+        self._check(_lib.lib().lcpc_get_timings(self._h, C.byref(t)))
+        return t
+
+    def __del__(self):
+        try:
+            _lib.lib().lcpc_ctx_destroy(self._h)
+        except Exception:
+            pass
+
+
+def _params(field, encoding, device, **kw):
+    p = LcpcParams()
+    p.field, p.encoding, p.hash, p.device = field, encoding, 0, device
+    p.rho_num, p.rho_den = kw.get("rho", (1, 2))
+    p.sdig_code, p.seed = kw.get("code", 3), kw.get("seed", 0)
+    p.n_coeffs, p.n_per_row, p.n_cols = kw.get("n_coeffs", 0), kw.get("n_per_row", 0), kw.get("n_cols", 0)
+    p.shard_rank, p.shard_count = kw.get("shard", (0, 1))
+    return p
+
+
+def static_get_dims(field, encoding, length, rho=(1, 2), code=3):
+    """LigeroEncodingRho::_get_dims (ligero lib.rs:70-112) / SdigEncodingS::new's shape (brakedown lib.rs:69-110)."""
+    p = _params(field, encoding, 0, n_coeffs=length, rho=rho, code=code)
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = _lib.lib().lcpc_static_get_dims(C.byref(p), C.byref(a), C.byref(b), C.byref(c))
+    if rc:
+        raise LcpcError(rc)
+    return a.value, b.value, c.value
+
+
+class LigeroEncoding(_Encoding):
+    """LigeroEncodingRho<Ft, Rn, Rd> (lcpc-ligero-pc/src/lib.rs:31-186); default rate 1/2 (lib.rs:189)."""
+
+    def __init__(self, field, length=None, rho=(1, 2), device=0, shard=(0, 1), _dims=None):
+        kw = dict(rho=rho, shard=shard)
+        if _dims is not None:
+            kw.update(n_per_row=_dims[0], n_cols=_dims[1])
+        else:
+            kw.update(n_coeffs=length)
+        super().__init__(_params(field, ENC_LIGERO, device, **kw))
+
+    @classmethod
+    def new(cls, field, length, rho=(1, 2), device=0, shard=(0, 1)):
+        return cls(field, length, rho, device, shard)
+
+    @classmethod
+    def new_from_dims(cls, field, n_per_row, n_cols, rho=(1, 2), device=0, shard=(0, 1)):
+        return cls(field, None, rho, device, shard, _dims=(n_per_row, n_cols))
+
+
+class SdigEncoding(_Encoding):
+    """SdigEncodingS<Ft, S> (lcpc-brakedown-pc/src/lib.rs:41-176); default code SdigCode3 (lib.rs:19)."""
+
+    def __init__(self, field, length=None, seed=0, code=3, device=0, shard=(0, 1), _dims=None):
+        kw = dict(seed=seed, code=code, shard=shard)
+        if _dims is not None:
+            kw.update(n_per_row=_dims[0], n_cols=_dims[1])
+        else:
+            kw.update(n_coeffs=length)
+        super().__init__(_params(field, ENC_SDIG, device, **kw))
+
+    @classmethod
+    def new(cls, field, length, seed, code=3, device=0):
+        return cls(field, length, seed, code, device)
+
+    @classmethod
+    def new_from_dims(cls, field, n_per_row, n_cols, seed, code=3, device=0):
+        return cls(field, None, seed, code, device, _dims=(n_per_row, n_cols))
+
+
+class LcCommit:
+    """LcCommit<D, E> (lcpc-2d/src/lib.rs:172-184, 270-312) with D = BLAKE3: comm / coeffs / hashes stay in HBM,
+    owned by the encoding's context (one live commitment per encoding object)."""
+
+    def __init__(self, enc):
+        self.enc = enc
+        a, b, c, d = (C.c_uint64() for _ in range(4))
+        enc._check(_lib.lib().lcpc_commit_dims(enc._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        self.n_rows, self.n_per_row, self.n_cols, self.n_hashes = a.value, b.value, c.value, d.value
+
+    @classmethod
+    def commit(cls, coeffs, enc):
+        """LcCommit::commit(&coeffs, &enc) (lib.rs:299-301) from host memory."""
+        coeffs = _elems(coeffs, enc.L)
+        enc._check(_lib.lib().lcpc_commit(enc._h, _ptr(coeffs), coeffs.size // enc.L, None))
+        return cls(enc)
+
+    @classmethod
+    def commit_device(cls, coeffs_ptr, n_coeffs, enc, stream=0, sync=True):
+        """same, coefficients already in HBM (`coeffs_ptr` = device address, e.g. torch tensor .data_ptr())."""
+        root = (C.c_uint8 * 32)() if sync else None
+        enc._check(_lib.lib().lcpc_commit_device(enc._h, C.c_void_p(coeffs_ptr), n_coeffs, C.c_void_p(stream), root))
+        return cls(enc)
+
+    @classmethod
+    def from_parts(cls, enc, comm, coeffs, n_rows):
+        """test hook = lcpc-2d/src/tests.rs:435-466 random_comm + merkleize."""
+        comm = _elems(comm, enc.L)
+        cp = _ptr(_elems(coeffs, enc.L)) if coeffs is not None else None
+        enc._check(_lib.lib().lcpc_commit_from_parts(enc._h, _ptr(comm), cp, n_rows, None))
+        return cls(enc)
+
+    def get_root(self):
+        out = (C.c_uint8 * 32)()
+        self.enc._check(_lib.lib().lcpc_get_root(self.enc._h, out))
+        return bytes(out)
+
+    def get_n_rows(self):
+        return self.n_rows
+
+    def get_n_cols(self):
+        return self.n_cols
+
+    def get_n_per_row(self):
+        return self.n_per_row
+
+    def hashes(self):
+        out = np.zeros((self.n_hashes, 32), np.uint8)
+        self.enc._check(_lib.lib().lcpc_get_hashes(self.enc._h, _ptr(out)))
+        return out
+
+    def comm(self, row0=0, n_rows=None):
+        n_rows = self.n_rows - row0 if n_rows is None else n_rows
+        out = np.zeros((n_rows * self.n_cols, self.enc.L), np.uint64)
+        self.enc._check(_lib.lib().lcpc_get_comm(self.enc._h, row0, n_rows, _ptr(out)))
+        return out
+
+    def coeffs(self, row0=0, n_rows=None):
+        n_rows = self.n_rows - row0 if n_rows is None else n_rows
+        out = np.zeros((n_rows * self.n_per_row, self.enc.L), np.uint64)
+        self.enc._check(_lib.lib().lcpc_get_coeffs(self.enc._h, row0, n_rows, _ptr(out)))
+        return out
+
+    def eval_outer(self, tensors):
+        """collapse_columns (lib.rs:1095-1123) for one (n_rows, L) or several (k, n_rows, L) tensors."""
+        t = _elems(tensors, self.enc.L)
+        k = t.size // (self.n_rows * self.enc.L)
+        if k * self.n_rows * self.enc.L != t.size or k == 0:
+            raise LcpcError(ERR_OUTER_TENSOR)
+        out = np.zeros((k, self.n_per_row, self.enc.L), np.uint64)
+        self.enc._check(_lib.lib().lcpc_collapse(self.enc._h, _ptr(t), k, _ptr(out)))
+        return out[0] if k == 1 and np.ndim(tensors) <= 2 else out
+
+    def open_columns(self, cols):
+        cols = np.ascontiguousarray(cols, np.uint64)
+        n = cols.size
+        path_len = max(0, (self.n_cols - 1).bit_length())
+        vals = np.zeros((n, self.n_rows, self.enc.L), np.uint64)
+        paths = np.zeros((n, max(path_len, 1), 32), np.uint8)
+        self.enc._check(_lib.lib().lcpc_open_columns(self.enc._h, _ptr(cols), n, _ptr(vals), _ptr(paths)))
+        return vals, paths[:, :path_len]
+
+    def open_column(self, col):
+        v, p = self.open_columns([col])
+        return v[0], p[0]
+
+    def prove(self, outer_tensor, enc, tr):
+        """LcCommit::prove (lib.rs:304-311): returns an LcEvalProof (bincode bytes + parsed header)."""
+        if enc is not self.enc:
+            raise LcpcError(ERR_COMMIT)
+        t = _elems(outer_tensor, enc.L)
+        pp, plen = C.c_void_p(), C.c_uint64()
+        cols = np.zeros(enc.get_n_col_opens(), np.uint64)
+        enc._check(_lib.lib().lcpc_prove(enc._h, _ptr(t), t.size // enc.L, tr._h, C.byref(pp), C.byref(plen), _ptr(cols)))
+        data = C.string_at(pp, plen.value)
+        _lib.lib().lcpc_free(pp)
+        return LcEvalProof(data, enc.L, cols)
+
+
+class LcEvalProof:
+    """LcEvalProof<D, E> (lib.rs:490-500) held in the reference's bincode wire layout (lib.rs:550-609)."""
+
+    def __init__(self, data, L, cols_opened=None):
+        self.data, self.L, self.cols_opened = bytes(data), L, cols_opened
+        self.n_cols, n_per_row = np.frombuffer(self.data[:16], np.uint64)
+        self._n_per_row = int(n_per_row)
+        self.n_cols = int(self.n_cols)
+
+    def get_n_cols(self):
+        return self.n_cols
+
+    def get_n_per_row(self):
+        return self._n_per_row
+
+    def to_bytes(self):           # bincode::serialize(&pf)
+        return self.data
+
+    @classmethod
+    def from_bytes(cls, data, L):  # bincode::deserialize
+        return cls(data, L)
+
+    def verify(self, root, outer_tensor, inner_tensor, enc, tr):
+        """LcEvalProof::verify (lib.rs:518-527); returns the evaluation (L limbs) or raises LcpcError(VERR_*)."""
+        o, i = _elems(outer_tensor, enc.L), _elems(inner_tensor, enc.L)
+        out = np.zeros(enc.L, np.uint64)
+        buf = np.frombuffer(self.data, np.uint8)
+        rootb = np.frombuffer(bytes(root), np.uint8)
+        rc = _lib.lib().lcpc_verify(enc._h, _ptr(rootb), _ptr(o), o.size // enc.L, _ptr(i), i.size // enc.L,
+                                    _ptr(buf), len(self.data), tr._h, _ptr(out))
+        if rc:
+            raise LcpcError(rc)
+        return out
+
+
+def root_bincode(root):
+    out = (C.c_uint8 * 40)()
+    _lib.lib().lcpc_root_bincode(bytes(root), out)
+    return bytes(out)

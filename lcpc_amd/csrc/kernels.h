@@ -1,0 +1,73 @@
+// lcpc_amd/csrc/kernels.h -- host-callable launchers for the gfx950 kernels (kernels.hip).
+// Element pointers are `const uint32_t*` views of the L x u64 Montgomery limbs (NL = 2L words).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lcpc {
+
+struct NttPassArgs {
+  const uint32_t* src;     // row-major, src_stride elements per row
+  uint32_t* dst;           // row-major, dst_stride elements per row (may alias src when strides match)
+  const uint32_t* roots;   // roots[i] = w^i (Montgomery), i < n/2
+  uint64_t src_stride, dst_stride;
+  uint64_t n_valid;        // elements >= n_valid of every src row read as zero (fused zero padding)
+  uint64_t n_rows;
+  uint32_t log_n, t0, s, log_tj;   // stages [t0, t0+s) on tiles of 2^s x 2^log_tj elements
+};
+hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream_t st);
+
+struct LeafArgs {
+  const uint32_t* comm;        // local rows, row-major
+  uint64_t row_stride;         // elements
+  uint64_t n_cols;
+  int64_t  row_base;           // global index of local row 0
+  uint64_t n_rows_total;
+  uint32_t chunk_begin, n_chunks_local, n_chunks_total;
+  uint32_t* out;               // n_chunks_total == 1: digests [n_cols][8]; else CVs [n_chunks_local][n_cols][8]
+};
+hipError_t launch_leaf_chunks(int nl, const LeafArgs& a, hipStream_t st);
+// cvs [n_chunks][n_cols][8] (clobbered: used as the BLAKE3 CV stack) -> digests [n_cols][8]
+hipError_t launch_leaf_finish(uint32_t* cvs, uint32_t n_chunks, uint64_t n_cols, uint32_t* digests, hipStream_t st);
+// one Merkle layer: out[i] = D(in[2i] || in[2i+1]), n_out parents
+hipError_t launch_merkle_layer(const uint32_t* in, uint32_t* out, uint64_t n_out, hipStream_t st);
+// whole tree above the leaf layer in as few launches as possible (hashes = LcCommit.hashes, np2 leaves)
+hipError_t launch_merkle_tree(uint32_t* hashes, uint64_t np2, hipStream_t st);
+
+struct CollapseArgs {
+  const uint32_t* coeffs;      // local rows x n_per_row
+  const uint32_t* tensors;     // [n_tensors][n_rows_local]
+  uint32_t* out;               // n_splits == 1: polys [n_tensors][n_per_row]; else partial [n_splits][n_tensors][n_per_row]
+  uint64_t n_rows, n_per_row;
+  uint32_t n_tensors, n_splits;
+};
+hipError_t launch_collapse(int nl, const CollapseArgs& a, hipStream_t st);
+// out[e] = sum_p parts[p][e] mod p
+hipError_t launch_field_sum(int nl, const uint32_t* parts, uint32_t n_parts, uint64_t n_elems, uint32_t* out, hipStream_t st);
+
+// open_column: vals[k][r] = comm[r][cols[k]]; paths[k][lvl] = sibling digest
+hipError_t launch_gather_columns(int nl, const uint32_t* comm, uint64_t n_rows, uint64_t n_cols, const uint64_t* cols,
+                                 uint32_t n, uint32_t* vals, hipStream_t st);
+hipError_t launch_gather_paths(const uint32_t* hashes, uint64_t np2, uint32_t path_len, const uint64_t* cols, uint32_t n,
+                               uint32_t* paths, hipStream_t st);
+
+// Brakedown: y[row][out_off + o] = sum_k vals[k] * x[row][in_off + colidx[k]], k in [rowptr[o], rowptr[o+1])
+struct SpmvArgs {
+  uint32_t* mat;                // comm (row-major, stride elements per row); in and out segments are disjoint
+  uint32_t* out_alt;            // if non-null: write to out_alt[row][o] (stride out_alt_stride) instead of mat
+  uint64_t stride, out_alt_stride;
+  uint64_t in_off, out_off;
+  const uint32_t* rowptr;       // [m+1]
+  const uint32_t* colidx;       // [nnz]
+  const uint32_t* vals;         // [nnz][NL]
+  uint64_t m, n_rows;
+};
+hipError_t launch_spmv(int nl, const SpmvArgs& a, hipStream_t st);
+// Reed-Solomon base case (encode.rs:97-110): out[row][out_off + k] = sum_j in[row][j] (k+1)^j
+hipError_t launch_sdig_rs(int nl, const uint32_t* in, uint64_t in_stride, uint32_t n_in, uint32_t* mat, uint64_t stride,
+                          uint64_t out_off, uint32_t n_out, uint64_t n_rows, const uint32_t* r2, hipStream_t st);
+// copy rows with zero padding: dst[row][0..n_valid) = src[row][..], rest zero (Brakedown row setup)
+hipError_t launch_pad_rows(int nl, const uint32_t* src, uint64_t src_stride, uint32_t* dst, uint64_t dst_stride,
+                           uint64_t n_valid, uint64_t n_rows, hipStream_t st);
+
+}  // namespace lcpc

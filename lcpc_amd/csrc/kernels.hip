@@ -1,0 +1,551 @@
+// lcpc_amd/csrc/kernels.hip -- gfx950 (MI355X) kernels of the lcpc-2d commit / prove path.
+//
+//   K1  ntt_pass_kernel      LcEncoding::encode for Ligero = fffft fft_io_pc   (ligero lib.rs:162-164)
+//   K2  spmv / sdig_rs       LcEncoding::encode for Brakedown                  (brakedown encode.rs:36-110)
+//   K3  leaf_chunk/finish    hash_columns                                       (lcpc-2d lib.rs:706-745)
+//   K4  merkle_*             merkle_tree / merkle_layer                         (lib.rs:747-785)
+//   K5  collapse / field_sum collapse_columns                                   (lib.rs:1095-1123)
+//   K6  gather_*             open_column                                        (lib.rs:788-825)
+//
+// All arithmetic is exact modular integer arithmetic, so any evaluation order gives bit-identical,
+// fully-reduced results; the kernels are free to re-associate (multi-pass NTT, split sums).
+#include "kernels.h"
+#include "field_dev.h"
+#include "blake3_dev.h"
+
+namespace lcpc {
+
+// =================================================================================================
+// K1: batched multi-pass radix-2 DIF NTT, LDS-staged.
+//
+// One pass executes stages [t0, t0+s) of the n = 2^k point transform of every row.  A stage-t
+// butterfly pairs x[e] and x[e + gap], gap = 2^(k-t-1), twiddle w^(2^t * (e mod gap)).  The elements
+// that interact inside a pass share every index bit except bits [lb, lb+s), lb = k-t0-s, so the
+// element index splits as  e = hi * 2^(lb+s) + i * 2^lb + lo.   A workgroup owns a tile of
+// 2^s values of i  x  Tj = 2^log_tj consecutive values of the combined outer index (hi,lo), stages
+// the tile through LDS in *memory order* (so global loads/stores are contiguous runs of
+// min(Tj, 2^lb) elements -- whole 128 B lines for the first pass, the full tile for the last), and
+// runs the s stages with one barrier each.  Output stays in the bit-reversed order the reference
+// produces (no reorder pass); zero padding of the message is fused into the first pass's loads.
+// =================================================================================================
+template <int NL> struct LdsLayout {
+  static constexpr int CW = (NL % 4 == 0) ? 4 : 2;      // words per LDS chunk: b128 / b64 accesses
+  static constexpr int NCH = NL / CW;
+};
+
+template <int NL, int LT>
+__device__ __forceinline__ Fe<NL> lds_get(const u32* lds, u32 e) {
+  constexpr int CW = LdsLayout<NL>::CW, NCH = LdsLayout<NL>::NCH;
+  Fe<NL> r;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    if constexpr (CW == 4) {
+      uint4 t = *reinterpret_cast<const uint4*>(lds + ((size_t)c * (1u << LT) + e) * 4);
+      r.v[4 * c] = t.x; r.v[4 * c + 1] = t.y; r.v[4 * c + 2] = t.z; r.v[4 * c + 3] = t.w;
+    } else {
+      uint2 t = *reinterpret_cast<const uint2*>(lds + ((size_t)c * (1u << LT) + e) * 2);
+      r.v[2 * c] = t.x; r.v[2 * c + 1] = t.y;
+    }
+  }
+  return r;
+}
+template <int NL, int LT>
+__device__ __forceinline__ void lds_put(u32* lds, u32 e, const Fe<NL>& a) {
+  constexpr int CW = LdsLayout<NL>::CW, NCH = LdsLayout<NL>::NCH;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    if constexpr (CW == 4)
+      *reinterpret_cast<uint4*>(lds + ((size_t)c * (1u << LT) + e) * 4) =
+          make_uint4(a.v[4 * c], a.v[4 * c + 1], a.v[4 * c + 2], a.v[4 * c + 3]);
+    else
+      *reinterpret_cast<uint2*>(lds + ((size_t)c * (1u << LT) + e) * 2) = make_uint2(a.v[2 * c], a.v[2 * c + 1]);
+  }
+}
+
+template <int NL, int LT>
+__global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  const u32 k = a.log_n, t0 = a.t0, s = a.s, ltj = a.log_tj;
+  const u32 lb = k - t0 - s;                    // bits below the pass's i-field
+  const u32 lbt = lb < ltj ? lb : ltj;          // lo-bits that live inside the tile
+  const u32 T = 1u << (s + ltj);                // tile elements (<= 2^LT)
+  const u64 tiles_per_row = (u64)1 << (k - s - ltj);
+  const u64 row = blockIdx.x / tiles_per_row;
+  const u64 tile = blockIdx.x % tiles_per_row;
+  const u64 o0 = tile << ltj;                   // first outer index of the tile
+  const u32 tid = threadIdx.x;
+  const u32 lp_mask = (1u << lbt) - 1, i_mask = (1u << s) - 1;
+  const u64 lo_mask = ((u64)1 << lb) - 1;
+
+  auto gindex = [&](u32 e) -> u64 {              // LDS slot -> element index within the row
+    const u32 lp = e & lp_mask, i = (e >> lbt) & i_mask, hp = e >> (lbt + s);
+    const u64 outer = o0 | ((u64)hp << lbt) | lp;
+    return ((outer >> lb) << (lb + s)) | ((u64)i << lb) | (outer & lo_mask);
+  };
+
+  const u32* src = a.src + row * a.src_stride * NL;
+  for (u32 e = tid; e < T; e += 256) {
+    const u64 g = gindex(e);
+    Fe<NL> v = (g < a.n_valid) ? fe_load<NL>(src + g * NL) : fe_zero<NL>();
+    lds_put<NL, LT>(lds, e, v);
+  }
+  __syncthreads();
+
+  for (u32 u = 0; u < s; u++) {
+    const u32 t = t0 + u;
+    const u32 hb = s - u - 1;                    // bit of i that distinguishes the butterfly pair
+    const u64 gap_mask = ((u64)1 << (k - t - 1)) - 1;
+    for (u32 q = tid; q < T / 2; q += 256) {
+      const u32 lp = q & lp_mask;
+      const u32 j = (q >> lbt) & (i_mask >> 1);
+      const u32 hp = q >> (lbt + s - 1);
+      const u32 i = ((j >> hb) << (hb + 1)) | (j & ((1u << hb) - 1));
+      const u32 e1 = ((((hp << s) | i)) << lbt) | lp;
+      const u32 e2 = e1 + (1u << (hb + lbt));
+      const u64 g1 = gindex(e1);
+      const u64 widx = (g1 & gap_mask) << t;     // exponent of w, < n/2
+      const Fe<NL> x = lds_get<NL, LT>(lds, e1);
+      const Fe<NL> y = lds_get<NL, LT>(lds, e2);
+      const Fe<NL> w = fe_load<NL>(a.roots + widx * NL);
+      lds_put<NL, LT>(lds, e1, fe_add<NL>(x, y));
+      lds_put<NL, LT>(lds, e2, fe_mul<NL>(fe_sub<NL>(x, y), w));
+    }
+    __syncthreads();
+  }
+
+  u32* dst = a.dst + row * a.dst_stride * NL;
+  for (u32 e = tid; e < T; e += 256) fe_store<NL>(dst + gindex(e) * NL, lds_get<NL, LT>(lds, e));
+}
+
+template <int NL, int LT>
+static hipError_t launch_ntt_pass_t(const NttPassArgs& a, hipStream_t st) {
+  const u64 tiles = ((u64)1 << (a.log_n - a.s - a.log_tj)) * a.n_rows;
+  const size_t lds_bytes = ((size_t)NL * 4) << LT;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<NL, LT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ntt_pass_kernel<NL, LT>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream_t st) {
+  if (a.s + a.log_tj > (uint32_t)log_tile) return hipErrorInvalidValue;
+#define NTT_CASE(NLV, LTV) if (nl == NLV && log_tile == LTV) return launch_ntt_pass_t<NLV, LTV>(a, st);
+  NTT_CASE(2, 10) NTT_CASE(4, 10) NTT_CASE(6, 10) NTT_CASE(8, 10)
+  NTT_CASE(2, 11) NTT_CASE(4, 11) NTT_CASE(6, 11) NTT_CASE(8, 11)
+  NTT_CASE(2, 12) NTT_CASE(4, 12)
+#undef NTT_CASE
+  return hipErrorInvalidValue;
+}
+
+// =================================================================================================
+// K3: column hashing.  leaf[c] = BLAKE3( 0^32 || to_repr(comm[0][c]) || ... || to_repr(comm[R-1][c]) ).
+// The leaf message (32 + 8L*R bytes) spans several 1 KiB BLAKE3 chunks; chunk chaining values are
+// independent, so the grid is (column, chunk): one lane per column (a wave reads 64 consecutive
+// elements of a row = one contiguous 64*8L byte run), blockIdx.y = chunk.  This is also exactly the
+// unit a row-sharded multi-GPU commit exchanges.  A second tiny kernel folds the CVs of a column with
+// BLAKE3's parent rule.  Element -> canonical little-endian bytes is one Montgomery reduction.
+// =================================================================================================
+template <int NL, int PH>
+__device__ __forceinline__ void leaf_fill_block(u32 m[16], const LeafArgs& a, u64 col, int64_t row0) {
+  constexpr int NEL = (PH + 16 + NL - 1) / NL;
+  Fe<NL> el[NEL];
+#pragma unroll
+  for (int x = 0; x < NEL; x++) {
+    const int64_t row = row0 + x;
+    if (row >= 0 && (u64)row < a.n_rows_total) {
+      const u32* p = a.comm + ((u64)(row - a.row_base) * a.row_stride + col) * NL;
+      el[x] = fe_canon<NL>(fe_load<NL>(p));
+    } else {
+      el[x] = fe_zero<NL>();
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 16; p++) m[p] = el[(PH + p) / NL].v[(PH + p) % NL];
+}
+
+template <int NL>
+__global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
+  const u64 col = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (col >= a.n_cols) return;
+  const u32 chunk = a.chunk_begin + blockIdx.y;
+  const u64 total_len = 32 + (u64)NL * 4 * a.n_rows_total;
+  const u64 chunk_off = (u64)chunk * 1024;
+  const u32 chunk_len = (u32)((total_len - chunk_off) < 1024 ? (total_len - chunk_off) : 1024);
+  const u32 nblocks = (chunk_len + 63) / 64;
+  u32 cv[8];
+  b3_set_iv(cv);
+  for (u32 b = 0; b < nblocks; b++) {
+    // element-word offset of this block's first word; the 32-byte zero prefix is words -8..-1
+    const int64_t s0 = ((int64_t)chunk * 16 + b) * 16 - 8;
+    int64_t row0 = s0 >= 0 ? s0 / NL : -((-s0 + NL - 1) / NL);
+    const int ph = (int)(s0 - row0 * NL);
+    u32 m[16];
+    if constexpr (NL == 6) {
+      if (ph == 0) leaf_fill_block<NL, 0>(m, a, col, row0);
+      else if (ph == 2) leaf_fill_block<NL, 2>(m, a, col, row0);
+      else leaf_fill_block<NL, 4>(m, a, col, row0);
+    } else {
+      leaf_fill_block<NL, 0>(m, a, col, row0);
+    }
+    const u32 rem = chunk_len - 64 * b;
+    const u32 blen = rem < 64 ? rem : 64;
+    u32 flags = (b == 0 ? B3_CHUNK_START : 0u);
+    if (b == nblocks - 1) flags |= B3_CHUNK_END | (a.n_chunks_total == 1 ? B3_ROOT : 0u);
+    b3_compress(cv, m, chunk, blen, flags);
+  }
+  u32* o = a.out + ((u64)blockIdx.y * a.n_cols + col) * 8;
+  *reinterpret_cast<uint4*>(o) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+  *reinterpret_cast<uint4*>(o + 4) = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+hipError_t launch_leaf_chunks(int nl, const LeafArgs& a, hipStream_t st) {
+  if (a.n_chunks_local == 0 || a.n_cols == 0) return hipSuccess;
+  dim3 grid((unsigned)((a.n_cols + 255) / 256), a.n_chunks_local);
+  switch (nl) {
+    case 2: hipLaunchKernelGGL(leaf_chunk_kernel<2>, grid, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(leaf_chunk_kernel<4>, grid, dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL(leaf_chunk_kernel<6>, grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(leaf_chunk_kernel<8>, grid, dim3(256), 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+__device__ __forceinline__ void ld8(u32 d[8], const u32* p) {
+  uint4 x = *reinterpret_cast<const uint4*>(p), y = *reinterpret_cast<const uint4*>(p + 4);
+  d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; d[4] = y.x; d[5] = y.y; d[6] = y.z; d[7] = y.w;
+}
+__device__ __forceinline__ void st8(u32* p, const u32 d[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(d[0], d[1], d[2], d[3]);
+  *reinterpret_cast<uint4*>(p + 4) = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+// BLAKE3 tree over the n chunk CVs of each column (left subtree = largest power of two < n): the
+// incremental stack algorithm, with the (wave-uniform) stack kept in the CV buffer itself.
+__global__ void __launch_bounds__(256) leaf_finish_kernel(u32* cvs, u32 n_chunks, u64 n_cols, u32* digests) {
+  const u64 col = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (col >= n_cols) return;
+  u32 cv[8], left[8];
+  u32 len = 0;
+  for (u32 c = 0; c < n_chunks; c++) {
+    ld8(cv, cvs + ((u64)c * n_cols + col) * 8);
+    if (c == n_chunks - 1) break;
+    u32 total = c + 1;
+    while ((total & 1) == 0) {
+      --len;
+      ld8(left, cvs + ((u64)len * n_cols + col) * 8);
+      u32 out[8];
+      b3_hash64(out, left, cv, B3_PARENT);
+#pragma unroll
+      for (int i = 0; i < 8; i++) cv[i] = out[i];
+      total >>= 1;
+    }
+    st8(cvs + ((u64)len * n_cols + col) * 8, cv);
+    ++len;
+  }
+  while (len > 0) {
+    --len;
+    ld8(left, cvs + ((u64)len * n_cols + col) * 8);
+    u32 out[8];
+    b3_hash64(out, left, cv, B3_PARENT | (len == 0 ? B3_ROOT : 0u));
+#pragma unroll
+    for (int i = 0; i < 8; i++) cv[i] = out[i];
+  }
+  st8(digests + col * 8, cv);
+}
+hipError_t launch_leaf_finish(u32* cvs, u32 n_chunks, u64 n_cols, u32* digests, hipStream_t st) {
+  hipLaunchKernelGGL(leaf_finish_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, cvs, n_chunks, n_cols,
+                     digests);
+  return hipGetLastError();
+}
+
+// =================================================================================================
+// K4: Merkle tree.  parent = D(left || right): a 64-byte message = one compression with
+// CHUNK_START|CHUNK_END|ROOT.  merkle_subtree_kernel folds 2*256 = 512 nodes -> 1 inside one
+// workgroup (9 layers through LDS) and writes every intermediate layer to its slot of the
+// reference's flat `hashes` array (lib.rs:656-666, 747-760).
+// =================================================================================================
+__global__ void __launch_bounds__(256) merkle_layer_kernel(const u32* in, u32* out, u64 n_out) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_out) return;
+  u32 l[8], r[8], o[8];
+  ld8(l, in + 2 * i * 8);
+  ld8(r, in + (2 * i + 1) * 8);
+  b3_hash64(o, l, r, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+  st8(out + i * 8, o);
+}
+hipError_t launch_merkle_layer(const u32* in, u32* out, u64 n_out, hipStream_t st) {
+  hipLaunchKernelGGL(merkle_layer_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, in, out, n_out);
+  return hipGetLastError();
+}
+
+// layers: `width` nodes at `hashes + in_off*8`; each WG reduces SUB = 2^lsub consecutive nodes down
+// `lsub` layers.  Layer j (1-based) of the subtree lands at hashes[layer_off_j + wg * (SUB >> j) + ...].
+__global__ void __launch_bounds__(256) merkle_subtree_kernel(u32* hashes, u64 in_off, u64 width, u32 lsub) {
+  __shared__ u32 buf[256 * 8];
+  const u32 tid = threadIdx.x;
+  const u64 sub = (u64)1 << lsub;               // nodes consumed per WG (<= 512)
+  const u64 base = (u64)blockIdx.x * sub;
+  u32 l[8], r[8], o[8];
+  u64 layer_in = in_off, w = width;
+  u64 layer_out = in_off + w;
+  u32 n_out = (u32)(sub / 2);
+  // first layer: read from global
+  if (tid < n_out) {
+    ld8(l, hashes + (layer_in + base + 2 * tid) * 8);
+    ld8(r, hashes + (layer_in + base + 2 * tid + 1) * 8);
+    b3_hash64(o, l, r, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+    st8(hashes + (layer_out + (base >> 1) + tid) * 8, o);
+    st8(buf + tid * 8, o);
+  }
+  for (u32 j = 2; j <= lsub; j++) {
+    __syncthreads();
+    layer_in = layer_out;
+    w >>= 1;
+    layer_out = layer_in + w;
+    n_out >>= 1;
+    const bool act = tid < n_out;
+    if (act) {
+      ld8(l, buf + (2 * tid) * 8);
+      ld8(r, buf + (2 * tid + 1) * 8);
+      b3_hash64(o, l, r, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+    }
+    __syncthreads();
+    if (act) {
+      st8(buf + tid * 8, o);
+      st8(hashes + (layer_out + (base >> j) + tid) * 8, o);
+    }
+  }
+}
+hipError_t launch_merkle_tree(u32* hashes, u64 np2, hipStream_t st) {
+  u64 in_off = 0, width = np2;
+  while (width > 1) {
+    u32 lw = 0;
+    while (((u64)1 << lw) < width) lw++;
+    const u32 lsub = lw < 9 ? lw : 9;
+    const u64 nwg = width >> lsub;
+    hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)nwg), dim3(256), 0, st, hashes, in_off, width, lsub);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    for (u32 j = 0; j < lsub; j++) { in_off += width; width >>= 1; }
+  }
+  return hipSuccess;
+}
+
+// =================================================================================================
+// K5: collapse_columns: poly_t[j] = sum_r coeffs[r][j] * tensor_t[r], for up to 4 tensors in one pass
+// over coeffs.  Lane = column j (coalesced row reads); the tensor entry is wave-uniform.  Products
+// are accumulated unreduced (2NL+1 limbs) in batches and Montgomery-reduced once per batch.
+// =================================================================================================
+template <int NL, int NT>
+__global__ void __launch_bounds__(256) collapse_kernel(CollapseArgs a) {
+  const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.n_per_row) return;
+  const u32 z = blockIdx.y;
+  const u64 rows_per = (a.n_rows + a.n_splits - 1) / a.n_splits;
+  const u64 r0 = (u64)z * rows_per;
+  const u64 r1 = (r0 + rows_per < a.n_rows) ? r0 + rows_per : a.n_rows;
+  constexpr int BATCH = 8;
+  Fe<NL> acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = fe_zero<NL>();
+  for (u64 rb = r0; rb < r1; rb += BATCH) {
+    Wide<NL> w[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) w[t] = wide_zero<NL>();
+    const u64 re = (rb + BATCH < r1) ? rb + BATCH : r1;
+    for (u64 r = rb; r < re; r++) {
+      const Fe<NL> c = fe_load<NL>(a.coeffs + (r * a.n_per_row + j) * NL);
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const Fe<NL> tv = fe_load<NL>(a.tensors + ((u64)t * a.n_rows + r) * NL);
+        wide_mac<NL>(w[t], c, tv);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = fe_add<NL>(acc[t], wide_reduce<NL>(w[t]));
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++) fe_store<NL>(a.out + (((u64)z * NT + t) * a.n_per_row + j) * NL, acc[t]);
+}
+template <int NL>
+static hipError_t launch_collapse_t(const CollapseArgs& a, hipStream_t st) {
+  dim3 grid((unsigned)((a.n_per_row + 255) / 256), a.n_splits);
+  switch (a.n_tensors) {
+    case 1: hipLaunchKernelGGL((collapse_kernel<NL, 1>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((collapse_kernel<NL, 2>), grid, dim3(256), 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_collapse(int nl, const CollapseArgs& a, hipStream_t st) {
+  switch (nl) {
+    case 2: return launch_collapse_t<2>(a, st);
+    case 4: return launch_collapse_t<4>(a, st);
+    case 6: return launch_collapse_t<6>(a, st);
+    case 8: return launch_collapse_t<8>(a, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <int NL>
+__global__ void __launch_bounds__(256) field_sum_kernel(const u32* parts, u32 n_parts, u64 n_elems, u32* out) {
+  const u64 e = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_elems) return;
+  Fe<NL> acc = fe_load<NL>(parts + e * NL);
+  for (u32 p = 1; p < n_parts; p++) acc = fe_add<NL>(acc, fe_load<NL>(parts + ((u64)p * n_elems + e) * NL));
+  fe_store<NL>(out + e * NL, acc);
+}
+hipError_t launch_field_sum(int nl, const u32* parts, u32 n_parts, u64 n_elems, u32* out, hipStream_t st) {
+  dim3 grid((unsigned)((n_elems + 255) / 256));
+  switch (nl) {
+    case 2: hipLaunchKernelGGL(field_sum_kernel<2>, grid, dim3(256), 0, st, parts, n_parts, n_elems, out); break;
+    case 4: hipLaunchKernelGGL(field_sum_kernel<4>, grid, dim3(256), 0, st, parts, n_parts, n_elems, out); break;
+    case 6: hipLaunchKernelGGL(field_sum_kernel<6>, grid, dim3(256), 0, st, parts, n_parts, n_elems, out); break;
+    case 8: hipLaunchKernelGGL(field_sum_kernel<8>, grid, dim3(256), 0, st, parts, n_parts, n_elems, out); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// =================================================================================================
+// K6: open_column gathers
+// =================================================================================================
+template <int NL>
+__global__ void __launch_bounds__(256) gather_columns_kernel(const u32* comm, u64 n_rows, u64 n_cols, const u64* cols,
+                                                            u32* vals) {
+  const u32 k = blockIdx.y;
+  const u64 c = cols[k];
+  for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (u64)gridDim.x * 256)
+    fe_store<NL>(vals + ((u64)k * n_rows + r) * NL, fe_load<NL>(comm + (r * n_cols + c) * NL));
+}
+hipError_t launch_gather_columns(int nl, const u32* comm, u64 n_rows, u64 n_cols, const u64* cols, u32 n, u32* vals,
+                                 hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  unsigned gx = (unsigned)((n_rows + 255) / 256);
+  if (gx > 64) gx = 64;
+  dim3 grid(gx, n);
+  switch (nl) {
+    case 2: hipLaunchKernelGGL(gather_columns_kernel<2>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals); break;
+    case 4: hipLaunchKernelGGL(gather_columns_kernel<4>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals); break;
+    case 6: hipLaunchKernelGGL(gather_columns_kernel<6>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals); break;
+    case 8: hipLaunchKernelGGL(gather_columns_kernel<8>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) gather_paths_kernel(const u32* hashes, u64 np2, u32 path_len, const u64* cols, u32 n,
+                                                          u32* paths) {
+  const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (u64)n * path_len) return;
+  const u32 k = (u32)(id / path_len), lvl = (u32)(id % path_len);
+  u64 base = 0, w = np2;
+  for (u32 i = 0; i < lvl; i++) { base += w; w >>= 1; }
+  const u64 node = (cols[k] >> lvl) ^ 1;
+  u32 d[8];
+  ld8(d, hashes + (base + node) * 8);
+  st8(paths + id * 8, d);
+}
+hipError_t launch_gather_paths(const u32* hashes, u64 np2, u32 path_len, const u64* cols, u32 n, u32* paths, hipStream_t st) {
+  const u64 tot = (u64)n * path_len;
+  if (tot == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_paths_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, hashes, np2, path_len, cols, n,
+                     paths);
+  return hipGetLastError();
+}
+
+// =================================================================================================
+// K2: Brakedown expander code.  The reference multiplies a CSC matrix by one row at a time
+// (sprs CsMat::dot, encode.rs:50-55); here the matrix is stored CSR-by-output and applied to all
+// rows of the commitment in one launch: lane = output index o (consecutive lanes write consecutive
+// codeword positions), blockIdx.y = matrix row of the commitment.  Products accumulate unreduced.
+// =================================================================================================
+template <int NL>
+__global__ void __launch_bounds__(256) spmv_kernel(SpmvArgs a) {
+  const u64 o = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (o >= a.m) return;
+  const u64 row = blockIdx.y;
+  const u32* x = a.mat + (row * a.stride + a.in_off) * NL;
+  const u32 k0 = a.rowptr[o], k1 = a.rowptr[o + 1];
+  constexpr u32 BATCH = 8;
+  Fe<NL> acc = fe_zero<NL>();
+  for (u32 kb = k0; kb < k1; kb += BATCH) {
+    Wide<NL> w = wide_zero<NL>();
+    const u32 ke = kb + BATCH < k1 ? kb + BATCH : k1;
+    for (u32 k = kb; k < ke; k++) {
+      const Fe<NL> v = fe_load<NL>(a.vals + (u64)k * NL);
+      const Fe<NL> xv = fe_load<NL>(x + (u64)a.colidx[k] * NL);
+      wide_mac<NL>(w, v, xv);
+    }
+    acc = fe_add<NL>(acc, wide_reduce<NL>(w));
+  }
+  u32* dst = a.out_alt ? a.out_alt + (row * a.out_alt_stride + o) * NL : a.mat + (row * a.stride + a.out_off + o) * NL;
+  fe_store<NL>(dst, acc);
+}
+hipError_t launch_spmv(int nl, const SpmvArgs& a, hipStream_t st) {
+  if (a.m == 0 || a.n_rows == 0) return hipSuccess;
+  dim3 grid((unsigned)((a.m + 255) / 256), (unsigned)a.n_rows);
+  switch (nl) {
+    case 2: hipLaunchKernelGGL(spmv_kernel<2>, grid, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(spmv_kernel<4>, grid, dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL(spmv_kernel<6>, grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(spmv_kernel<8>, grid, dim3(256), 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+template <int NL>
+__global__ void __launch_bounds__(64) sdig_rs_kernel(const u32* in, u64 in_stride, u32 n_in, u32* mat, u64 stride, u64 out_off,
+                                                    u32 n_out, const u32* r2) {
+  const u32 k = threadIdx.x + blockIdx.x * 64;
+  if (k >= n_out) return;
+  const u64 row = blockIdx.y;
+  // x = (k+1) in Montgomery form = (k+1) * R^2 * R^-1
+  Fe<NL> raw = fe_zero<NL>();
+  raw.v[0] = k + 1;
+  const Fe<NL> x = fe_mul<NL>(raw, fe_load<NL>(r2));
+  Fe<NL> r = fe_zero<NL>();
+  for (u32 j = n_in; j-- > 0;) r = fe_add<NL>(fe_mul<NL>(r, x), fe_load<NL>(in + (row * in_stride + j) * NL));
+  fe_store<NL>(mat + (row * stride + out_off + k) * NL, r);
+}
+hipError_t launch_sdig_rs(int nl, const u32* in, u64 in_stride, u32 n_in, u32* mat, u64 stride, u64 out_off, u32 n_out,
+                          u64 n_rows, const u32* r2, hipStream_t st) {
+  if (n_out == 0 || n_rows == 0) return hipSuccess;
+  dim3 grid((n_out + 63) / 64, (unsigned)n_rows);
+  switch (nl) {
+    case 2: hipLaunchKernelGGL(sdig_rs_kernel<2>, grid, dim3(64), 0, st, in, in_stride, n_in, mat, stride, out_off, n_out, r2); break;
+    case 4: hipLaunchKernelGGL(sdig_rs_kernel<4>, grid, dim3(64), 0, st, in, in_stride, n_in, mat, stride, out_off, n_out, r2); break;
+    case 6: hipLaunchKernelGGL(sdig_rs_kernel<6>, grid, dim3(64), 0, st, in, in_stride, n_in, mat, stride, out_off, n_out, r2); break;
+    case 8: hipLaunchKernelGGL(sdig_rs_kernel<8>, grid, dim3(64), 0, st, in, in_stride, n_in, mat, stride, out_off, n_out, r2); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+template <int NL>
+__global__ void __launch_bounds__(256) pad_rows_kernel(const u32* src, u64 src_stride, u32* dst, u64 dst_stride, u64 n_valid) {
+  const u64 row = blockIdx.y;
+  for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < n_valid; e += (u64)gridDim.x * 256)
+    fe_store<NL>(dst + (row * dst_stride + e) * NL, fe_load<NL>(src + (row * src_stride + e) * NL));
+}
+hipError_t launch_pad_rows(int nl, const u32* src, u64 src_stride, u32* dst, u64 dst_stride, u64 n_valid, u64 n_rows,
+                           hipStream_t st) {
+  if (n_rows == 0 || n_valid == 0) return hipSuccess;
+  unsigned gx = (unsigned)((n_valid + 255) / 256);
+  if (gx > 1024) gx = 1024;
+  dim3 grid(gx, (unsigned)n_rows);
+  switch (nl) {
+    case 2: hipLaunchKernelGGL(pad_rows_kernel<2>, grid, dim3(256), 0, st, src, src_stride, dst, dst_stride, n_valid); break;
+    case 4: hipLaunchKernelGGL(pad_rows_kernel<4>, grid, dim3(256), 0, st, src, src_stride, dst, dst_stride, n_valid); break;
+    case 6: hipLaunchKernelGGL(pad_rows_kernel<6>, grid, dim3(256), 0, st, src, src_stride, dst, dst_stride, n_valid); break;
+    case 8: hipLaunchKernelGGL(pad_rows_kernel<8>, grid, dim3(256), 0, st, src, src_stride, dst, dst_stride, n_valid); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace lcpc

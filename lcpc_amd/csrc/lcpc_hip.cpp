@@ -1,0 +1,1005 @@
+// lcpc_amd/csrc/lcpc_hip.cpp -- context + C ABI (include/lcpc_hip.h) of the MI355X lcpc-2d path.
+//
+// Host orchestration of: commit (lcpc-2d/src/lib.rs:622-671), merkleize (690-704), open_column
+// (788-825), prove (1004-1093), collapse_columns (1095-1123), verify (832-1000) and the bincode wire
+// layout (186-268, 352-609) of /root/reference.  Every heavy step is a HIP kernel (kernels.hip); there
+// is no CPU fallback: without a usable HIP device lcpc_ctx_create fails with LCPC_ERR_NO_DEVICE.
+#include "../../include/lcpc_hip.h"
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "encoding.h"
+#include "host_crypto.h"
+#include "host_field.h"
+#include "kernels.h"
+
+using namespace lcpc;
+
+namespace {
+
+struct DevCsr {
+  uint64_t n_in = 0, n_out = 0;
+  uint32_t *rowptr = nullptr, *colidx = nullptr, *vals = nullptr;
+};
+struct Pass { uint32_t t0, s, log_tj; int log_tile; };
+
+const uint8_t LBL_DT[] = "$l//DT", LBL_PR[] = "$l//PR", LBL_PE[] = "$l//PE", LBL_CO[] = "$l//CO";  // macros.rs:31-34
+
+}  // namespace
+
+struct lcpc_transcript {
+  Transcript t;
+  lcpc_transcript(const uint8_t* l, size_t n) : t(l, n) {}
+};
+
+struct lcpc_ctx {
+  lcpc_params prm{};
+  const FieldDesc* f = nullptr;
+  int L = 0, NL = 0;
+  uint64_t n_per_row = 0, n_cols = 0, np2 = 0;
+  uint32_t path_len = 0;
+  // Ligero
+  unsigned log_n = 0;
+  uint32_t* d_roots = nullptr;
+  std::vector<Pass> passes;
+  // Brakedown
+  SdigSpec spec{};
+  std::vector<LevelDims> pre_dims, post_dims;
+  std::vector<DevCsr> d_pre, d_post;
+  uint32_t* d_r2 = nullptr;
+  uint32_t* d_tmp = nullptr;       // last precode output, n_rows x m_last
+  uint64_t tmp_cap = 0;
+  // commitment (device resident)
+  bool committed = false;
+  uint64_t n_rows = 0;             // rows of the whole commitment
+  uint64_t row_begin = 0, n_rows_local = 0;
+  uint64_t chunk_begin = 0, chunk_end = 0, n_chunks = 0;
+  uint32_t *d_coeffs = nullptr, *d_comm = nullptr, *d_hashes = nullptr, *d_cvs = nullptr;
+  uint64_t cap_rows = 0, cap_cvs = 0;
+  // scratch for prove / collapse / open
+  uint32_t* d_scratch = nullptr;
+  uint64_t scratch_cap = 0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  lcpc_timings last{};
+  uint32_t launches[3] = {0, 0, 0};
+  std::string err;
+  std::mutex mu;
+};
+
+namespace {
+
+int fail_hip(lcpc_ctx* c, hipError_t e, const char* what) {
+  if (c) c->err = std::string(what) + ": " + hipGetErrorString(e);
+  return e == hipErrorOutOfMemory ? LCPC_ERR_NOMEM : LCPC_ERR_HIP;
+}
+#define HIPCHK(c, call)                                   \
+  do {                                                    \
+    hipError_t e__ = (call);                              \
+    if (e__ != hipSuccess) return fail_hip(c, e__, #call); \
+  } while (0)
+
+template <typename T> int dev_alloc(lcpc_ctx* c, T** p, size_t bytes) {
+  *p = nullptr;
+  if (bytes == 0) bytes = 16;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), bytes));
+  return 0;
+}
+void dev_free(void* p) { if (p) (void)hipFree(p); }
+
+size_t elem_bytes(const lcpc_ctx* c) { return (size_t)8 * c->L; }
+
+// ---- NTT pass plan (DESIGN.md "K1") ----------------------------------------------------------------
+void plan_passes(lcpc_ctx* c) {
+  const unsigned k = c->log_n;
+  const int NL = c->NL;
+  const int lt_small = NL >= 6 ? 10 : (NL == 4 ? 11 : 12);      // 32 KiB (24 KiB for NL=6) tiles
+  const int lt_big = NL >= 6 ? 11 : 12;
+  unsigned ltj_min = 0;                                          // >= 128 B contiguous runs in strided passes
+  while (((size_t)NL * 4 << ltj_min) < 128) ltj_min++;
+  c->passes.clear();
+  if ((int)k <= lt_small) {
+    c->passes.push_back({0, k, 0, lt_small});
+    return;
+  }
+  int LT = lt_small;
+  auto n_pass = [&](int lt) { unsigned per = lt - ltj_min, rest = k - lt; return 1 + (rest + per - 1) / per; };
+  if (n_pass(lt_small) > 2 && n_pass(lt_big) < n_pass(lt_small)) LT = lt_big;
+  const unsigned P = n_pass(LT);
+  const unsigned s_final = LT;
+  unsigned rem = k - s_final, t0 = 0;
+  for (unsigned i = 0; i + 1 < P; i++) {
+    const unsigned left = P - 1 - i;
+    const unsigned s = (rem + left - 1) / left;
+    c->passes.push_back({t0, s, (uint32_t)LT - s, LT});
+    t0 += s;
+    rem -= s;
+  }
+  c->passes.push_back({t0, s_final, 0u, LT});
+}
+
+int ensure_buffers(lcpc_ctx* c, uint64_t n_rows_local) {
+  if (n_rows_local > c->cap_rows || !c->d_comm) {
+    dev_free(c->d_coeffs); dev_free(c->d_comm);
+    c->d_coeffs = c->d_comm = nullptr;
+    c->cap_rows = 0;
+    const size_t eb = elem_bytes(c);
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_coeffs, (size_t)n_rows_local * c->n_per_row * eb))) return rc;
+    if ((rc = dev_alloc(c, &c->d_comm, (size_t)n_rows_local * c->n_cols * eb))) return rc;
+    c->cap_rows = n_rows_local;
+  }
+  if (!c->d_hashes) {
+    int rc = dev_alloc(c, &c->d_hashes, (size_t)(2 * c->np2 - 1) * 32);
+    if (rc) return rc;
+  }
+  if (c->prm.encoding == LCPC_ENC_SDIG) {
+    const uint64_t need = n_rows_local * c->pre_dims.back().m;
+    if (need > c->tmp_cap) {
+      dev_free(c->d_tmp);
+      int rc = dev_alloc(c, &c->d_tmp, (size_t)need * elem_bytes(c));
+      if (rc) return rc;
+      c->tmp_cap = need;
+    }
+  }
+  return 0;
+}
+int ensure_cvs(lcpc_ctx* c, uint64_t n_chunks) {
+  const uint64_t need = n_chunks * c->n_cols;
+  if (need > c->cap_cvs) {
+    dev_free(c->d_cvs);
+    int rc = dev_alloc(c, &c->d_cvs, (size_t)need * 32);
+    if (rc) return rc;
+    c->cap_cvs = need;
+  }
+  return 0;
+}
+int ensure_scratch(lcpc_ctx* c, uint64_t bytes) {
+  if (bytes > c->scratch_cap) {
+    dev_free(c->d_scratch);
+    int rc = dev_alloc(c, &c->d_scratch, (size_t)bytes);
+    if (rc) return rc;
+    c->scratch_cap = bytes;
+  }
+  return 0;
+}
+
+// leaf message = 32 + F * n_rows bytes -> BLAKE3 chunks of 1 KiB
+uint64_t leaf_chunks(const lcpc_ctx* c, uint64_t n_rows) { return (32 + elem_bytes(c) * n_rows + 1023) / 1024; }
+
+// rows / chunks of shard `rank` (DESIGN.md "multi-GPU"): chunk-aligned row blocks
+void shard_layout(const lcpc_ctx* c, uint64_t n_rows, uint64_t* rb, uint64_t* re, uint64_t* cb, uint64_t* ce, uint64_t* nch) {
+  const uint64_t n_chunks = leaf_chunks(c, n_rows);
+  const uint64_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1, g = G > 1 ? c->prm.shard_rank : 0;
+  const uint64_t c0 = n_chunks * g / G, c1 = n_chunks * (g + 1) / G;
+  const uint64_t F = elem_bytes(c);
+  auto first_row = [&](uint64_t chunk) -> uint64_t {   // first row whose bytes start in or after this chunk
+    if (chunk == 0) return 0;
+    const uint64_t byte = chunk * 1024 - 32;             // F | 1024 is enforced for sharded contexts
+    uint64_t r = byte / F;
+    return r < n_rows ? r : n_rows;
+  };
+  *cb = c0; *ce = c1; *nch = n_chunks;
+  *rb = first_row(c0);
+  *re = c1 >= n_chunks ? n_rows : first_row(c1);
+  if (c0 == c1) *re = *rb;
+}
+
+// ---- encode all local rows: coeffs -> comm ----------------------------------------------------------
+int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, uint64_t n_valid, uint32_t* dst,
+                       uint64_t n_rows, hipStream_t st) {
+  if (n_rows == 0) return 0;
+  if (c->prm.encoding == LCPC_ENC_LIGERO) {
+    bool first = true;
+    for (const Pass& p : c->passes) {
+      NttPassArgs a;
+      a.src = first ? src : dst;
+      a.dst = dst;
+      a.roots = c->d_roots;
+      a.src_stride = first ? src_stride : c->n_cols;
+      a.dst_stride = c->n_cols;
+      a.n_valid = first ? n_valid : c->n_cols;
+      a.n_rows = n_rows;
+      a.log_n = c->log_n; a.t0 = p.t0; a.s = p.s; a.log_tj = p.log_tj;
+      HIPCHK(c, launch_ntt_pass(c->NL, p.log_tile, a, st));
+      c->launches[0]++;
+      first = false;
+    }
+    return 0;
+  }
+  // Brakedown: systematic part, then precodes down, R-S base case, postcodes up (encode.rs:36-94)
+  if (n_rows > 65535) { c->err = "brakedown: more than 65535 rows per launch not supported"; return LCPC_ERR_TOO_BIG; }
+  if (src != dst || src_stride != c->n_cols) {
+    HIPCHK(c, launch_pad_rows(c->NL, src, src_stride, dst, c->n_cols, n_valid, n_rows, st));
+    c->launches[0]++;
+  }
+  const size_t t = c->d_pre.size();
+  uint64_t in_start = 0;
+  SpmvArgs a{};
+  a.mat = dst; a.stride = c->n_cols; a.n_rows = n_rows;
+  for (size_t i = 0; i + 1 < t; i++) {
+    const uint64_t in_end = in_start + c->d_pre[i].n_in;
+    a.out_alt = nullptr; a.in_off = in_start; a.out_off = in_end;
+    a.rowptr = c->d_pre[i].rowptr; a.colidx = c->d_pre[i].colidx; a.vals = c->d_pre[i].vals; a.m = c->d_pre[i].n_out;
+    HIPCHK(c, launch_spmv(c->NL, a, st));
+    c->launches[0]++;
+    in_start = in_end;
+  }
+  const DevCsr& pl = c->d_pre[t - 1];
+  const uint64_t in_end = in_start + pl.n_in;
+  a.out_alt = c->d_tmp; a.out_alt_stride = pl.n_out; a.in_off = in_start; a.out_off = 0;
+  a.rowptr = pl.rowptr; a.colidx = pl.colidx; a.vals = pl.vals; a.m = pl.n_out;
+  HIPCHK(c, launch_spmv(c->NL, a, st));
+  const uint64_t out_end = in_end + c->d_post[t - 1].n_in;
+  HIPCHK(c, launch_sdig_rs(c->NL, c->d_tmp, pl.n_out, (uint32_t)pl.n_out, dst, c->n_cols, in_end,
+                           (uint32_t)c->d_post[t - 1].n_in, n_rows, c->d_r2, st));
+  c->launches[0] += 2;
+  in_start = in_end + pl.n_out;
+  uint64_t out_start = out_end;
+  for (size_t ii = t; ii-- > 0;) {
+    in_start -= c->d_pre[ii].n_out;
+    a.out_alt = nullptr; a.in_off = in_start; a.out_off = out_start;
+    a.rowptr = c->d_post[ii].rowptr; a.colidx = c->d_post[ii].colidx; a.vals = c->d_post[ii].vals; a.m = c->d_post[ii].n_out;
+    HIPCHK(c, launch_spmv(c->NL, a, st));
+    c->launches[0]++;
+    out_start += c->d_post[ii].n_out;
+  }
+  return 0;
+}
+
+// hash_columns + merkle_tree on the local comm (unsharded) -- lib.rs:690-704
+int merkleize_device(lcpc_ctx* c, hipStream_t st) {
+  const uint64_t n_chunks = leaf_chunks(c, c->n_rows);
+  LeafArgs la{};
+  la.comm = c->d_comm; la.row_stride = c->n_cols; la.n_cols = c->n_cols; la.row_base = 0;
+  la.n_rows_total = c->n_rows; la.chunk_begin = 0; la.n_chunks_local = (uint32_t)n_chunks; la.n_chunks_total = (uint32_t)n_chunks;
+  if (n_chunks == 1) {
+    la.out = c->d_hashes;
+    HIPCHK(c, launch_leaf_chunks(c->NL, la, st));
+    c->launches[1]++;
+  } else {
+    int rc = ensure_cvs(c, n_chunks);
+    if (rc) return rc;
+    la.out = c->d_cvs;
+    HIPCHK(c, launch_leaf_chunks(c->NL, la, st));
+    HIPCHK(c, launch_leaf_finish(c->d_cvs, (uint32_t)n_chunks, c->n_cols, c->d_hashes, st));
+    c->launches[1] += 2;
+  }
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], st));
+  if (c->np2 > c->n_cols)   // hashes[n_cols..np2) stay zero (lib.rs:656-666)
+    HIPCHK(c, hipMemsetAsync(c->d_hashes + c->n_cols * 8, 0, (size_t)(c->np2 - c->n_cols) * 32, st));
+  if (c->np2 > 1) {
+    HIPCHK(c, launch_merkle_tree(c->d_hashes, c->np2, st));
+    c->launches[2]++;
+  }
+  return 0;
+}
+
+int finish_timing(lcpc_ctx* c, hipStream_t st) {
+  if (!c->timing) return 0;
+  HIPCHK(c, hipEventRecord(c->ev[3], st));
+  HIPCHK(c, hipEventSynchronize(c->ev[3]));
+  (void)hipEventElapsedTime(&c->last.encode_ms, c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&c->last.hash_ms, c->ev[1], c->ev[2]);
+  (void)hipEventElapsedTime(&c->last.merkle_ms, c->ev[2], c->ev[3]);
+  (void)hipEventElapsedTime(&c->last.total_ms, c->ev[0], c->ev[3]);
+  c->last.encode_launches = c->launches[0];
+  c->last.hash_launches = c->launches[1];
+  c->last.merkle_launches = c->launches[2];
+  return 0;
+}
+
+// commit with the padded coefficient matrix already in c->d_coeffs
+int commit_resident(lcpc_ctx* c, hipStream_t st, uint8_t* root) {
+  c->launches[0] = c->launches[1] = c->launches[2] = 0;
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
+  int rc = encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st);
+  if (rc) return rc;
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], st));
+  if ((rc = merkleize_device(c, st))) return rc;
+  if ((rc = finish_timing(c, st))) return rc;
+  c->committed = true;
+  if (root) {
+    HIPCHK(c, hipMemcpyAsync(root, c->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
+int set_rows(lcpc_ctx* c, uint64_t n_coeffs) {
+  if (n_coeffs == 0) return LCPC_ERR_ARG;
+  c->n_rows = (n_coeffs + c->n_per_row - 1) / c->n_per_row;    // get_dims (ligero lib.rs:166-169)
+  c->row_begin = 0;
+  c->n_rows_local = c->n_rows;
+  return ensure_buffers(c, c->n_rows);
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int lcpc_abi_version(void) { return LCPC_ABI_VERSION; }
+
+const char* lcpc_strerror(int s) {
+  switch (s) {
+    case LCPC_OK: return "ok";
+    case LCPC_ERR_TOO_BIG: return "n_cols is too large for this encoding";
+    case LCPC_ERR_ENCODE: return "encoding error";
+    case LCPC_ERR_COMMIT: return "inconsistent commitment fields";
+    case LCPC_ERR_COLUMN_NUMBER: return "bad column number";
+    case LCPC_ERR_OUTER_TENSOR: return "outer tensor: wrong size";
+    case LCPC_ERR_DIMS: return "dimensions not valid for this encoding";
+    case LCPC_ERR_ARG: return "invalid argument";
+    case LCPC_ERR_STATE: return "no commitment in this context";
+    case LCPC_ERR_HIP: return "HIP runtime error";
+    case LCPC_ERR_NOMEM: return "out of device memory";
+    case LCPC_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case LCPC_VERR_NUM_COL_OPENS: return "wrong number of column openings in proof";
+    case LCPC_VERR_COLUMN_PATH: return "column verification: merkle path failed";
+    case LCPC_VERR_COLUMN_EVAL: return "column verification: eval dot product failed";
+    case LCPC_VERR_COLUMN_DEGREE: return "column verification: degree test dot product failed";
+    case LCPC_VERR_OUTER_TENSOR: return "outer tensor: wrong size";
+    case LCPC_VERR_INNER_TENSOR: return "inner tensor: wrong size";
+    case LCPC_VERR_ENCODING_DIMS: return "encoding dimension mismatch";
+    case LCPC_VERR_ENCODE: return "encoding error";
+    case LCPC_VERR_MALFORMED: return "malformed proof bytes";
+  }
+  return "unknown status";
+}
+const char* lcpc_last_error(const lcpc_ctx* c) { return c ? c->err.c_str() : ""; }
+
+int lcpc_static_get_dims(const lcpc_params* p, uint64_t* nr, uint64_t* np, uint64_t* nc) {
+  if (!p || !nr || !np || !nc) return LCPC_ERR_ARG;
+  const FieldDesc* f = field_desc((int)p->field);
+  if (!f || p->n_coeffs == 0) return LCPC_ERR_ARG;
+  if (p->encoding == LCPC_ENC_LIGERO) {
+    if (p->rho_num == 0 || p->rho_num >= p->rho_den) return LCPC_ERR_ARG;
+    return ligero_get_dims(*f, p->n_coeffs, p->rho_num, p->rho_den, nr, np, nc) ? LCPC_ERR_TOO_BIG : 0;
+  } else if (p->encoding == LCPC_ENC_SDIG) {
+    SdigSpec s;
+    const int code = p->sdig_code ? (int)p->sdig_code : 3;
+    uint64_t npr;
+    if (!sdig_spec(code, &s) || !sdig_n_per_row(*f, p->n_coeffs, code, &npr)) return LCPC_ERR_ARG;
+    std::vector<LevelDims> pre, post;
+    if (!sdig_level_dims(s, npr, (double)f->flog2(), pre, post)) return LCPC_ERR_DIMS;
+    *nr = (p->n_coeffs + npr - 1) / npr; *np = npr; *nc = sdig_codeword_length(pre, post);
+    return 0;
+  }
+  return LCPC_ERR_ARG;
+}
+
+int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
+  if (!p || !out) return LCPC_ERR_ARG;
+  *out = nullptr;
+  const FieldDesc* f = field_desc((int)p->field);
+  if (!f || p->hash != LCPC_HASH_BLAKE3) return LCPC_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) return LCPC_ERR_NO_DEVICE;
+  if (hipSetDevice(p->device) != hipSuccess) return LCPC_ERR_NO_DEVICE;
+  lcpc_ctx* c = new lcpc_ctx();
+  c->prm = *p;
+  c->f = f; c->L = f->L; c->NL = 2 * f->L;
+  if (c->prm.sdig_code == 0) c->prm.sdig_code = 3;
+  if (c->prm.shard_count > 1 && (c->prm.shard_rank >= c->prm.shard_count || 1024 % (8 * f->L) != 0)) {
+    delete c;
+    return LCPC_ERR_ARG;      // row sharding needs rows that do not straddle BLAKE3 chunks (F | 1024)
+  }
+  int rc = 0;
+  if (p->encoding == LCPC_ENC_LIGERO) {
+    if (p->rho_num == 0 || p->rho_num >= p->rho_den) { delete c; return LCPC_ERR_ARG; }
+    uint64_t nr, np_, nc;
+    if (p->n_per_row && p->n_cols) { np_ = p->n_per_row; nc = p->n_cols; }      // new_from_dims (ligero lib.rs:138-148)
+    else if ((rc = lcpc_static_get_dims(p, &nr, &np_, &nc))) { delete c; return rc; }
+    if (!(np_ < nc) || (nc & (nc - 1)) || log2_ceil(nc) > f->S) { delete c; return LCPC_ERR_DIMS; }   // _dims_ok + precomp_fft
+    c->n_per_row = np_; c->n_cols = nc; c->log_n = (unsigned)log2_ceil(nc);
+    std::vector<uint64_t> roots;
+    roots_table(*f, c->log_n, roots);
+    if ((rc = dev_alloc(c, &c->d_roots, roots.size() * 8))) { lcpc_ctx_destroy(c); return rc; }
+    if (hipMemcpy(c->d_roots, roots.data(), roots.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
+    plan_passes(c);
+  } else if (p->encoding == LCPC_ENC_SDIG) {
+    if (!sdig_spec((int)c->prm.sdig_code, &c->spec)) { delete c; return LCPC_ERR_ARG; }
+    uint64_t npr = p->n_per_row;
+    if (!(p->n_per_row && p->n_cols)) {
+      if (!sdig_n_per_row(*f, p->n_coeffs, (int)c->prm.sdig_code, &npr)) { delete c; return LCPC_ERR_ARG; }
+    }
+    std::vector<CsrMatrix> pre, post;
+    if (!sdig_generate(*f, c->spec, npr, p->seed, pre, post, c->pre_dims, c->post_dims)) { delete c; return LCPC_ERR_DIMS; }
+    c->n_per_row = npr;
+    c->n_cols = sdig_codeword_length(c->pre_dims, c->post_dims);
+    if (p->n_per_row && p->n_cols && p->n_cols != c->n_cols) { delete c; return LCPC_ERR_DIMS; }   // new_from_dims assert
+    auto upload = [&](const CsrMatrix& m, DevCsr& d) -> int {
+      d.n_in = m.n_in; d.n_out = m.n_out;
+      int r;
+      if ((r = dev_alloc(c, &d.rowptr, m.rowptr.size() * 4))) return r;
+      if ((r = dev_alloc(c, &d.colidx, m.colidx.size() * 4))) return r;
+      if ((r = dev_alloc(c, &d.vals, m.vals.size() * 8))) return r;
+      HIPCHK(c, hipMemcpy(d.rowptr, m.rowptr.data(), m.rowptr.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(d.colidx, m.colidx.data(), m.colidx.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(d.vals, m.vals.data(), m.vals.size() * 8, hipMemcpyHostToDevice));
+      return 0;
+    };
+    c->d_pre.resize(pre.size());
+    c->d_post.resize(post.size());
+    for (size_t i = 0; i < pre.size() && !rc; i++) { rc = upload(pre[i], c->d_pre[i]); if (!rc) rc = upload(post[i], c->d_post[i]); }
+    if (!rc) rc = dev_alloc(c, &c->d_r2, 8 * f->L);
+    if (!rc && hipMemcpy(c->d_r2, f->r2, 8 * f->L, hipMemcpyHostToDevice) != hipSuccess) rc = LCPC_ERR_HIP;
+    if (rc) { lcpc_ctx_destroy(c); return rc; }
+  } else {
+    delete c;
+    return LCPC_ERR_ARG;
+  }
+  c->np2 = next_pow2(c->n_cols);
+  c->path_len = (uint32_t)log2_ceil(c->n_cols);
+  for (auto& e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
+  *out = c;
+  return 0;
+}
+
+void lcpc_ctx_destroy(lcpc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->prm.device);
+  dev_free(c->d_roots); dev_free(c->d_r2); dev_free(c->d_tmp);
+  for (auto* v : {&c->d_pre, &c->d_post})
+    for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); }
+  dev_free(c->d_coeffs); dev_free(c->d_comm); dev_free(c->d_hashes); dev_free(c->d_cvs); dev_free(c->d_scratch);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  delete c;
+}
+
+int lcpc_get_dims(const lcpc_ctx* c, uint64_t len, uint64_t* nr, uint64_t* np, uint64_t* nc) {
+  if (!c || len == 0) return LCPC_ERR_ARG;
+  if (nr) *nr = (len + c->n_per_row - 1) / c->n_per_row;
+  if (np) *np = c->n_per_row;
+  if (nc) *nc = c->n_cols;
+  return 0;
+}
+int lcpc_dims_ok(const lcpc_ctx* c, uint64_t n_per_row, uint64_t n_cols) {
+  if (!c) return 0;
+  bool ok = n_per_row < n_cols && n_per_row == c->n_per_row && n_cols == c->n_cols;
+  if (c->prm.encoding == LCPC_ENC_LIGERO) ok = ok && (n_cols & (n_cols - 1)) == 0;
+  return ok ? 1 : 0;
+}
+uint64_t lcpc_get_n_col_opens(const lcpc_ctx* c) {
+  if (!c) return 0;
+  return c->prm.encoding == LCPC_ENC_LIGERO ? ligero_n_col_opens(c->prm.rho_num, c->prm.rho_den) : sdig_n_col_opens((int)c->prm.sdig_code);
+}
+uint64_t lcpc_get_n_degree_tests(const lcpc_ctx* c) { return c ? n_degree_tests(128, c->n_cols, c->f->flog2()) : 0; }
+uint32_t lcpc_field_limbs(const lcpc_ctx* c) { return c ? (uint32_t)c->L : 0; }
+
+int lcpc_encode_rows(lcpc_ctx* c, uint64_t* rows, uint64_t n_rows) {
+  if (!c || !rows) return LCPC_ERR_ARG;
+  if (n_rows == 0) return 0;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  const size_t bytes = (size_t)n_rows * c->n_cols * elem_bytes(c);
+  int rc = ensure_scratch(c, bytes);
+  if (rc) return rc;
+  if (c->prm.encoding == LCPC_ENC_SDIG) {
+    const uint64_t need = n_rows * c->pre_dims.back().m;
+    if (need > c->tmp_cap) {
+      dev_free(c->d_tmp);
+      if ((rc = dev_alloc(c, &c->d_tmp, (size_t)need * elem_bytes(c)))) return rc;
+      c->tmp_cap = need;
+    }
+  }
+  HIPCHK(c, hipMemcpy(c->d_scratch, rows, bytes, hipMemcpyHostToDevice));
+  // the trait contract (lib.rs:651-652): entries >= n_per_row are zero on entry; they are read as given here
+  if ((rc = encode_rows_device(c, c->d_scratch, c->n_cols, c->n_cols, c->d_scratch, n_rows, nullptr))) return rc;
+  HIPCHK(c, hipMemcpy(rows, c->d_scratch, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lcpc_commit_device(lcpc_ctx* c, const uint64_t* coeffs_dev, uint64_t n_coeffs, void* stream, uint8_t* root) {
+  if (!c || !coeffs_dev) return LCPC_ERR_ARG;
+  if (c->prm.shard_count > 1) return LCPC_ERR_STATE;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  hipStream_t st = (hipStream_t)stream;
+  int rc = set_rows(c, n_coeffs);
+  if (rc) return rc;
+  const size_t eb = elem_bytes(c);
+  // local copy of coeffs with zero padding (lib.rs:636-645); LcCommit keeps it for prove
+  HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs_dev, (size_t)n_coeffs * eb, hipMemcpyDeviceToDevice, st));
+  const uint64_t padded = c->n_rows * c->n_per_row;
+  if (padded > n_coeffs)
+    HIPCHK(c, hipMemsetAsync(reinterpret_cast<uint8_t*>(c->d_coeffs) + (size_t)n_coeffs * eb, 0, (size_t)(padded - n_coeffs) * eb, st));
+  return commit_resident(c, st, root);
+}
+
+int lcpc_commit(lcpc_ctx* c, const uint64_t* coeffs, uint64_t n_coeffs, uint8_t* root) {
+  if (!c || !coeffs) return LCPC_ERR_ARG;
+  if (c->prm.shard_count > 1) return LCPC_ERR_STATE;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  int rc = set_rows(c, n_coeffs);
+  if (rc) return rc;
+  const size_t eb = elem_bytes(c);
+  HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs, (size_t)n_coeffs * eb, hipMemcpyHostToDevice, nullptr));
+  const uint64_t padded = c->n_rows * c->n_per_row;
+  if (padded > n_coeffs)
+    HIPCHK(c, hipMemsetAsync(reinterpret_cast<uint8_t*>(c->d_coeffs) + (size_t)n_coeffs * eb, 0, (size_t)(padded - n_coeffs) * eb, nullptr));
+  return commit_resident(c, nullptr, root);
+}
+
+int lcpc_commit_from_parts(lcpc_ctx* c, const uint64_t* comm, const uint64_t* coeffs, uint64_t n_rows, uint8_t* root) {
+  if (!c || !comm || n_rows == 0) return LCPC_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  c->n_rows = n_rows; c->row_begin = 0; c->n_rows_local = n_rows;
+  int rc = ensure_buffers(c, n_rows);
+  if (rc) return rc;
+  const size_t eb = elem_bytes(c);
+  HIPCHK(c, hipMemcpy(c->d_comm, comm, (size_t)n_rows * c->n_cols * eb, hipMemcpyHostToDevice));
+  if (coeffs) HIPCHK(c, hipMemcpy(c->d_coeffs, coeffs, (size_t)n_rows * c->n_per_row * eb, hipMemcpyHostToDevice));
+  else HIPCHK(c, hipMemset(c->d_coeffs, 0, (size_t)n_rows * c->n_per_row * eb));
+  c->launches[0] = c->launches[1] = c->launches[2] = 0;
+  if (c->timing) { HIPCHK(c, hipEventRecord(c->ev[0], nullptr)); HIPCHK(c, hipEventRecord(c->ev[1], nullptr)); }
+  if ((rc = merkleize_device(c, nullptr))) return rc;
+  if ((rc = finish_timing(c, nullptr))) return rc;
+  c->committed = true;
+  if (root) HIPCHK(c, hipMemcpy(root, c->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lcpc_get_root(lcpc_ctx* c, uint8_t root[32]) {
+  if (!c || !root) return LCPC_ERR_ARG;
+  if (!c->committed) return LCPC_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  HIPCHK(c, hipMemcpy(root, c->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+int lcpc_commit_dims(const lcpc_ctx* c, uint64_t* nr, uint64_t* np, uint64_t* nc, uint64_t* nh) {
+  if (!c) return LCPC_ERR_ARG;
+  if (!c->committed) return LCPC_ERR_STATE;
+  if (nr) *nr = c->n_rows;
+  if (np) *np = c->n_per_row;
+  if (nc) *nc = c->n_cols;
+  if (nh) *nh = 2 * c->np2 - 1;
+  return 0;
+}
+int lcpc_get_hashes(lcpc_ctx* c, uint8_t* hashes) {
+  if (!c || !hashes) return LCPC_ERR_ARG;
+  if (!c->committed) return LCPC_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  HIPCHK(c, hipMemcpy(hashes, c->d_hashes, (size_t)(2 * c->np2 - 1) * 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+int lcpc_get_comm(lcpc_ctx* c, uint64_t row0, uint64_t n, uint64_t* out) {
+  if (!c || !out) return LCPC_ERR_ARG;
+  if (!c->committed) return LCPC_ERR_STATE;
+  if (row0 < c->row_begin || row0 + n > c->row_begin + c->n_rows_local) return LCPC_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  HIPCHK(c, hipMemcpy(out, reinterpret_cast<uint8_t*>(c->d_comm) + (size_t)(row0 - c->row_begin) * c->n_cols * eb,
+                      (size_t)n * c->n_cols * eb, hipMemcpyDeviceToHost));
+  return 0;
+}
+int lcpc_get_coeffs(lcpc_ctx* c, uint64_t row0, uint64_t n, uint64_t* out) {
+  if (!c || !out) return LCPC_ERR_ARG;
+  if (!c->committed) return LCPC_ERR_STATE;
+  if (row0 < c->row_begin || row0 + n > c->row_begin + c->n_rows_local) return LCPC_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  HIPCHK(c, hipMemcpy(out, reinterpret_cast<uint8_t*>(c->d_coeffs) + (size_t)(row0 - c->row_begin) * c->n_per_row * eb,
+                      (size_t)n * c->n_per_row * eb, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- collapse / open ---------------------------------------------------------------------------------
+// split the row range so that the grid has >= ~2k workgroups even for narrow matrices
+static uint32_t collapse_splits(const lcpc_ctx* c) {
+  const uint64_t col_blocks = (c->n_per_row + 255) / 256;
+  uint32_t n_splits = 1;
+  while (n_splits < 64 && col_blocks * n_splits < 2048 && c->n_rows_local / (n_splits * 2) >= 16) n_splits *= 2;
+  return n_splits;
+}
+static int collapse_local(lcpc_ctx* c, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_out) {
+  const uint32_t n_splits = collapse_splits(c);
+  CollapseArgs a{};
+  a.coeffs = c->d_coeffs; a.tensors = d_tensors; a.n_rows = c->n_rows_local; a.n_per_row = c->n_per_row;
+  a.n_tensors = n_tensors; a.n_splits = n_splits;
+  if (n_splits == 1) {
+    a.out = d_out;
+    HIPCHK(c, launch_collapse(c->NL, a, st));
+    return 0;
+  }
+  const size_t eb = elem_bytes(c);
+  const size_t part_bytes = (size_t)n_splits * n_tensors * c->n_per_row * eb;
+  // partials live at the end of scratch (callers reserve it)
+  uint32_t* d_part = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(c->d_scratch) + c->scratch_cap - part_bytes);
+  a.out = d_part;
+  HIPCHK(c, launch_collapse(c->NL, a, st));
+  HIPCHK(c, launch_field_sum(c->NL, d_part, n_splits, (uint64_t)n_tensors * c->n_per_row, d_out, st));
+  return 0;
+}
+static size_t collapse_scratch_bytes(const lcpc_ctx* c, uint32_t n_tensors) {
+  return (size_t)collapse_splits(c) * n_tensors * c->n_per_row * elem_bytes(c);
+}
+
+int lcpc_collapse_device(lcpc_ctx* c, const uint64_t* tensors_dev, uint32_t n_tensors, void* stream, uint64_t* polys_dev) {
+  if (!c || !tensors_dev || !polys_dev || n_tensors == 0) return LCPC_ERR_ARG;
+  if (!c->committed) return LCPC_ERR_STATE;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t eb = elem_bytes(c);
+  int rc = ensure_scratch(c, collapse_scratch_bytes(c, 2));
+  if (rc) return rc;
+  for (uint32_t t = 0; t < n_tensors; t += 2) {
+    const uint32_t nt = (n_tensors - t) >= 2 ? 2 : 1;
+    rc = collapse_local(c, reinterpret_cast<const uint32_t*>(tensors_dev) + (size_t)t * c->n_rows_local * c->NL, nt, st,
+                        reinterpret_cast<uint32_t*>(polys_dev) + (size_t)t * c->n_per_row * c->NL);
+    if (rc) return rc;
+  }
+  (void)eb;
+  return 0;
+}
+
+int lcpc_collapse(lcpc_ctx* c, const uint64_t* tensors, uint32_t n_tensors, uint64_t* polys) {
+  if (!c || !tensors || !polys || n_tensors == 0) return LCPC_ERR_ARG;
+  if (!c->committed) return LCPC_ERR_STATE;
+  const size_t eb = elem_bytes(c);
+  const size_t tb = (size_t)n_tensors * c->n_rows_local * eb, pb = (size_t)n_tensors * c->n_per_row * eb;
+  uint64_t *d_t = nullptr, *d_p = nullptr;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    int rc;
+    if ((rc = dev_alloc(c, &d_t, tb))) return rc;
+    if ((rc = dev_alloc(c, &d_p, pb))) { dev_free(d_t); return rc; }
+    if (hipMemcpy(d_t, tensors, tb, hipMemcpyHostToDevice) != hipSuccess) { dev_free(d_t); dev_free(d_p); return LCPC_ERR_HIP; }
+  }
+  int rc = lcpc_collapse_device(c, d_t, n_tensors, nullptr, d_p);
+  if (!rc && hipMemcpy(polys, d_p, pb, hipMemcpyDeviceToHost) != hipSuccess) rc = LCPC_ERR_HIP;
+  dev_free(d_t); dev_free(d_p);
+  return rc;
+}
+
+int lcpc_field_sum_device(lcpc_ctx* c, const uint64_t* parts, uint32_t n_parts, uint64_t n_elems, void* stream, uint64_t* out) {
+  if (!c || !parts || !out || n_parts == 0) return LCPC_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  HIPCHK(c, launch_field_sum(c->NL, reinterpret_cast<const uint32_t*>(parts), n_parts, n_elems, reinterpret_cast<uint32_t*>(out),
+                             (hipStream_t)stream));
+  return 0;
+}
+
+int lcpc_open_columns(lcpc_ctx* c, const uint64_t* cols, uint32_t n, uint64_t* col_vals, uint8_t* paths) {
+  if (!c || !cols || (!col_vals && !paths)) return LCPC_ERR_ARG;
+  if (!c->committed) return LCPC_ERR_STATE;
+  for (uint32_t i = 0; i < n; i++)
+    if (cols[i] >= c->n_cols) return LCPC_ERR_COLUMN_NUMBER;        // lib.rs:797-799
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  const size_t vb = (size_t)n * c->n_rows_local * eb, pb = (size_t)n * c->path_len * 32, cb = (size_t)n * 8;
+  int rc = ensure_scratch(c, vb + pb + cb + 64);
+  if (rc) return rc;
+  uint8_t* base = reinterpret_cast<uint8_t*>(c->d_scratch);
+  uint64_t* d_cols = reinterpret_cast<uint64_t*>(base);
+  uint32_t* d_vals = reinterpret_cast<uint32_t*>(base + ((cb + 31) & ~(size_t)31));
+  uint32_t* d_paths = reinterpret_cast<uint32_t*>(base + ((cb + 31) & ~(size_t)31) + ((vb + 31) & ~(size_t)31));
+  HIPCHK(c, hipMemcpy(d_cols, cols, cb, hipMemcpyHostToDevice));
+  if (col_vals) {
+    HIPCHK(c, launch_gather_columns(c->NL, c->d_comm, c->n_rows_local, c->n_cols, d_cols, n, d_vals, nullptr));
+    HIPCHK(c, hipMemcpy(col_vals, d_vals, vb, hipMemcpyDeviceToHost));
+  }
+  if (paths && c->path_len) {
+    HIPCHK(c, launch_gather_paths(c->d_hashes, c->np2, c->path_len, d_cols, n, d_paths, nullptr));
+    HIPCHK(c, hipMemcpy(paths, d_paths, pb, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+// ---- transcript ------------------------------------------------------------------------------------------
+lcpc_transcript* lcpc_transcript_new(const uint8_t* label, size_t len) { return new lcpc_transcript(label, len); }
+lcpc_transcript* lcpc_transcript_clone(const lcpc_transcript* t) { return t ? new lcpc_transcript(*t) : nullptr; }
+void lcpc_transcript_append_message(lcpc_transcript* t, const uint8_t* label, size_t llen, const uint8_t* msg, size_t mlen) {
+  if (t) t->t.append_message(label, llen, msg, mlen);
+}
+void lcpc_transcript_challenge_bytes(lcpc_transcript* t, const uint8_t* label, size_t llen, uint8_t* out, size_t n) {
+  if (t) t->t.challenge_bytes(label, llen, out, n);
+}
+void lcpc_transcript_free(lcpc_transcript* t) { delete t; }
+
+// ---- prove (lib.rs:1004-1093) ----------------------------------------------------------------------------
+static void put_u64(std::vector<uint8_t>& w, uint64_t v) { const uint8_t* p = reinterpret_cast<const uint8_t*>(&v); w.insert(w.end(), p, p + 8); }
+static void put_bytes(std::vector<uint8_t>& w, const void* d, size_t n) { const uint8_t* p = static_cast<const uint8_t*>(d); w.insert(w.end(), p, p + n); }
+static void absorb_poly(Transcript& tr, const uint8_t* label, const FieldDesc& f, const uint64_t* poly, uint64_t n) {
+  uint64_t t[MAXL];
+  for (uint64_t i = 0; i < n; i++) {
+    h_canon(f, t, poly + i * f.L);                                            // to_repr, little-endian (lib.rs:47-57)
+    tr.append_message(label, 6, reinterpret_cast<const uint8_t*>(t), 8 * f.L);
+  }
+}
+
+int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t** proof, uint64_t* proof_len,
+               uint64_t* cols_opened) {
+  if (!c || !outer || !trw || !proof || !proof_len) return LCPC_ERR_ARG;
+  if (!c->committed) return LCPC_ERR_STATE;
+  if (c->prm.shard_count > 1) return LCPC_ERR_STATE;     // sharded prove is driven by the caller (collapse_device + all_gather)
+  if (!lcpc_dims_ok(c, c->n_per_row, c->n_cols)) return LCPC_ERR_COMMIT;      // check_comm lib.rs:1015
+  if (n_outer != c->n_rows) return LCPC_ERR_OUTER_TENSOR;                     // lib.rs:1016-1018
+  const FieldDesc& f = *c->f;
+  const int L = f.L;
+  Transcript& tr = trw->t;
+  const uint64_t n_deg = lcpc_get_n_degree_tests(c), n_open = lcpc_get_n_col_opens(c);
+  const uint64_t np = c->n_per_row, nr = c->n_rows;
+  std::vector<uint64_t> tensors(2 * nr * L), polys(2 * np * L), p_eval(np * L);
+  std::vector<std::vector<uint64_t>> p_random(n_deg);
+  bool have_eval = false;
+  for (uint64_t i = 0; i < n_deg; i++) {                                      // lib.rs:1024-1050
+    uint8_t key[32];
+    tr.challenge_bytes(LBL_DT, 6, key, 32);
+    ChaCha20Rng rng(key);
+    for (uint64_t r = 0; r < nr; r++) rng.field_random(f, &tensors[r * L]);
+    uint32_t nt = 1;
+    if (i == 0) {   // the eval tensor is independent of the transcript: fuse it into the first pass over coeffs
+      memcpy(&tensors[nr * L], outer, nr * L * 8);
+      nt = 2;
+    }
+    int rc = lcpc_collapse(c, tensors.data(), nt, polys.data());
+    if (rc) return rc;
+    p_random[i].assign(polys.begin(), polys.begin() + np * L);
+    if (nt == 2) { memcpy(p_eval.data(), &polys[np * L], np * L * 8); have_eval = true; }
+    absorb_poly(tr, LBL_PR, f, p_random[i].data(), np);
+  }
+  if (!have_eval) {                                                           // lib.rs:1053-1064
+    int rc = lcpc_collapse(c, outer, 1, p_eval.data());
+    if (rc) return rc;
+  }
+  absorb_poly(tr, LBL_PE, f, p_eval.data(), np);                              // lib.rs:1066-1068
+  uint8_t key[32];
+  tr.challenge_bytes(LBL_CO, 6, key, 32);                                     // lib.rs:1071-1080
+  ChaCha20Rng rng(key);
+  std::vector<uint64_t> cols(n_open);
+  for (auto& x : cols) x = rng.uniform(c->n_cols);
+  if (cols_opened) memcpy(cols_opened, cols.data(), n_open * 8);
+  std::vector<uint64_t> vals((size_t)n_open * nr * L);
+  std::vector<uint8_t> paths((size_t)n_open * c->path_len * 32 + 32);
+  int rc = lcpc_open_columns(c, cols.data(), (uint32_t)n_open, vals.data(), paths.data());   // lib.rs:1081-1084
+  if (rc) return rc;
+  // bincode 1.3 of WrappedLcEvalProof (lib.rs:550-560): n_cols, p_eval, p_random_vec, columns
+  std::vector<uint8_t> w;
+  w.reserve(32 + (1 + n_deg) * (np * L * 8 + 8) + n_open * (nr * L * 8 + 16 + c->path_len * 40));
+  put_u64(w, c->n_cols);
+  put_u64(w, np); put_bytes(w, p_eval.data(), np * L * 8);
+  put_u64(w, n_deg);
+  for (auto& pr : p_random) { put_u64(w, np); put_bytes(w, pr.data(), np * L * 8); }
+  put_u64(w, n_open);
+  for (uint64_t k = 0; k < n_open; k++) {
+    put_u64(w, nr); put_bytes(w, &vals[k * nr * L], nr * L * 8);
+    put_u64(w, c->path_len);
+    for (uint32_t l = 0; l < c->path_len; l++) { put_u64(w, 32); put_bytes(w, &paths[((size_t)k * c->path_len + l) * 32], 32); }
+  }
+  uint8_t* out = static_cast<uint8_t*>(malloc(w.size() ? w.size() : 1));
+  if (!out) return LCPC_ERR_NOMEM;
+  memcpy(out, w.data(), w.size());
+  *proof = out; *proof_len = w.size();
+  return 0;
+}
+
+// ---- verify (lib.rs:832-1000) ----------------------------------------------------------------------------
+namespace {
+struct Rd {
+  const uint8_t* p; uint64_t len, pos = 0; bool bad = false;
+  uint64_t u64_() { uint64_t v = 0; if (pos + 8 > len) { bad = true; return 0; } memcpy(&v, p + pos, 8); pos += 8; return v; }
+  const uint8_t* take(uint64_t n) { if (n > len - pos) { bad = true; return nullptr; } const uint8_t* q = p + pos; pos += n; return q; }
+};
+void hash_column_host(const FieldDesc& f, const uint64_t* col, uint64_t n_rows, uint8_t out[32]) {
+  std::vector<uint8_t> msg(32 + n_rows * 8 * f.L, 0);
+  for (uint64_t r = 0; r < n_rows; r++) {
+    uint64_t t[MAXL];
+    h_canon(f, t, col + r * f.L);
+    memcpy(&msg[32 + r * 8 * f.L], t, 8 * f.L);
+  }
+  blake3_host(msg.data(), msg.size(), out);
+}
+}  // namespace
+
+int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint64_t n_outer, const uint64_t* inner, uint64_t n_inner,
+                const uint8_t* proof, uint64_t proof_len, lcpc_transcript* trw, uint64_t* eval_out) {
+  if (!c || !root || !outer || !inner || !proof || !trw || !eval_out) return LCPC_ERR_ARG;
+  const FieldDesc& f = *c->f;
+  const int L = f.L;
+  const uint64_t F = 8 * L;
+  Transcript& tr = trw->t;
+  Rd r{proof, proof_len};
+  const uint64_t n_cols = r.u64_();
+  const uint64_t n_per_row = r.u64_();
+  if (r.bad || n_per_row > proof_len / F) return LCPC_VERR_MALFORMED;
+  std::vector<uint64_t> p_eval(n_per_row * L);
+  { const uint8_t* q = r.take(n_per_row * F); if (!q) return LCPC_VERR_MALFORMED; memcpy(p_eval.data(), q, n_per_row * F); }
+  const uint64_t n_deg_pf = r.u64_();
+  if (r.bad || n_deg_pf > 4096) return LCPC_VERR_MALFORMED;
+  std::vector<std::vector<uint64_t>> p_random(n_deg_pf);
+  for (auto& v : p_random) {
+    const uint64_t l = r.u64_();
+    if (r.bad || l > proof_len / F) return LCPC_VERR_MALFORMED;
+    const uint8_t* q = r.take(l * F);
+    if (!q) return LCPC_VERR_MALFORMED;
+    v.resize(l * L);
+    memcpy(v.data(), q, l * F);
+  }
+  const uint64_t n_columns = r.u64_();
+  if (r.bad || n_columns > proof_len / 8) return LCPC_VERR_MALFORMED;
+  std::vector<std::vector<uint64_t>> cols(n_columns);
+  std::vector<std::vector<uint8_t>> paths(n_columns);
+  for (uint64_t i = 0; i < n_columns; i++) {
+    const uint64_t l = r.u64_();
+    if (r.bad || l > proof_len / F) return LCPC_VERR_MALFORMED;
+    const uint8_t* q = r.take(l * F);
+    if (!q) return LCPC_VERR_MALFORMED;
+    cols[i].resize(l * L);
+    memcpy(cols[i].data(), q, l * F);
+    const uint64_t pl = r.u64_();
+    if (r.bad || pl > proof_len / 40) return LCPC_VERR_MALFORMED;
+    paths[i].resize(pl * 32);
+    for (uint64_t k = 0; k < pl; k++) {
+      const uint64_t dl = r.u64_();
+      const uint8_t* d = r.take(32);
+      if (r.bad || dl != 32 || !d) return LCPC_VERR_MALFORMED;     // Output<D> is 32 bytes
+      memcpy(&paths[i][k * 32], d, 32);
+    }
+  }
+  if (r.pos != proof_len) return LCPC_VERR_MALFORMED;
+  const uint64_t n_col_opens = lcpc_get_n_col_opens(c);                        // lib.rs:845-860
+  if (n_col_opens != n_columns || n_col_opens == 0) return LCPC_VERR_NUM_COL_OPENS;
+  const uint64_t n_rows = cols[0].size() / L;
+  if (n_inner != n_per_row) return LCPC_VERR_INNER_TENSOR;
+  if (n_outer != n_rows) return LCPC_VERR_OUTER_TENSOR;
+  if (!lcpc_dims_ok(c, n_per_row, n_cols)) return LCPC_VERR_ENCODING_DIMS;
+  const uint64_t n_deg = lcpc_get_n_degree_tests(c);
+  if (n_deg_pf < n_deg) return LCPC_VERR_MALFORMED;                            // reference indexes p_random_vec[i] (would panic)
+  for (uint64_t i = 0; i < n_deg; i++) if (p_random[i].size() != n_per_row * L) return LCPC_VERR_MALFORMED;
+  for (auto& cv : cols) if (cv.size() != n_rows * L) return LCPC_VERR_MALFORMED;
+  // step 1: random tensors, transcript; rows to encode = p_random[0..n_deg) then p_eval (lib.rs:868-920)
+  std::vector<std::vector<uint64_t>> rand_tensors(n_deg, std::vector<uint64_t>(n_rows * L));
+  std::vector<uint64_t> enc((n_deg + 1) * n_cols * L, 0);
+  for (uint64_t i = 0; i < n_deg; i++) {
+    uint8_t key[32];
+    tr.challenge_bytes(LBL_DT, 6, key, 32);
+    ChaCha20Rng rng(key);
+    for (uint64_t k = 0; k < n_rows; k++) rng.field_random(f, &rand_tensors[i][k * L]);
+    memcpy(&enc[i * n_cols * L], p_random[i].data(), n_per_row * F);
+    absorb_poly(tr, LBL_PR, f, p_random[i].data(), n_per_row);
+  }
+  absorb_poly(tr, LBL_PE, f, p_eval.data(), n_per_row);
+  uint8_t key[32];
+  tr.challenge_bytes(LBL_CO, 6, key, 32);
+  ChaCha20Rng rng(key);
+  memcpy(&enc[n_deg * n_cols * L], p_eval.data(), n_per_row * F);
+  int rc = lcpc_encode_rows(c, enc.data(), n_deg + 1);                         // the 1+n_deg row encodes run on the GPU
+  if (rc) return rc == LCPC_ERR_ENCODE ? LCPC_VERR_ENCODE : rc;
+  // step 3: per-column checks (lib.rs:923-944)
+  for (uint64_t i = 0; i < n_columns; i++) {
+    const uint64_t cn = rng.uniform(n_cols);
+    bool rnd = true, evl = true;
+    for (uint64_t d = 0; d <= n_deg; d++) {
+      const uint64_t* tensor = d < n_deg ? rand_tensors[d].data() : outer;
+      uint64_t acc[MAXL] = {0, 0, 0, 0}, t[MAXL];
+      for (uint64_t k = 0; k < n_rows; k++) { h_mul(f, t, tensor + k * L, &cols[i][k * L]); h_add(f, acc, acc, t); }
+      const bool ok = h_eq(f, acc, &enc[(d * n_cols + cn) * L]);             // verify_column_value lib.rs:985-1000
+      if (d < n_deg) rnd = rnd && ok; else evl = ok;
+    }
+    uint8_t h[32], blk[64];                                                    // verify_column_path lib.rs:955-982
+    hash_column_host(f, cols[i].data(), n_rows, h);
+    uint64_t cc = cn;
+    for (uint64_t k = 0; k < paths[i].size() / 32; k++) {
+      const uint8_t* pk = &paths[i][k * 32];
+      if (cc % 2 == 0) { memcpy(blk, h, 32); memcpy(blk + 32, pk, 32); } else { memcpy(blk, pk, 32); memcpy(blk + 32, h, 32); }
+      blake3_host(blk, 64, h);
+      cc >>= 1;
+    }
+    const bool pth = memcmp(h, root, 32) == 0;
+    if (!rnd) return LCPC_VERR_COLUMN_DEGREE;
+    if (!evl) return LCPC_VERR_COLUMN_EVAL;
+    if (!pth) return LCPC_VERR_COLUMN_PATH;
+  }
+  uint64_t acc[MAXL] = {0, 0, 0, 0}, t[MAXL];                                  // lib.rs:947-951
+  for (uint64_t k = 0; k < n_per_row; k++) { h_mul(f, t, inner + k * L, &p_eval[k * L]); h_add(f, acc, acc, t); }
+  memcpy(eval_out, acc, F);
+  return 0;
+}
+
+void lcpc_root_bincode(const uint8_t root[32], uint8_t out[40]) {
+  const uint64_t l = 32;
+  memcpy(out, &l, 8);
+  memcpy(out + 8, root, 32);
+}
+void lcpc_free(void* p) { free(p); }
+
+// ---- row-sharded commit ------------------------------------------------------------------------------------
+int lcpc_shard_layout(const lcpc_ctx* c, uint64_t n_rows_total, uint64_t* rb, uint64_t* re, uint64_t* cb, uint64_t* ce, uint64_t* nch) {
+  if (!c || n_rows_total == 0) return LCPC_ERR_ARG;
+  uint64_t a, b, x, y, z;
+  shard_layout(c, n_rows_total, &a, &b, &x, &y, &z);
+  if (rb) *rb = a;
+  if (re) *re = b;
+  if (cb) *cb = x;
+  if (ce) *ce = y;
+  if (nch) *nch = z;
+  return 0;
+}
+
+int lcpc_commit_shard_device(lcpc_ctx* c, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint8_t* cvs_dev) {
+  if (!c || n_rows_total == 0 || !cvs_dev) return LCPC_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t rb, re, cb, ce, nch;
+  shard_layout(c, n_rows_total, &rb, &re, &cb, &ce, &nch);
+  c->n_rows = n_rows_total; c->row_begin = rb; c->n_rows_local = re - rb;
+  c->chunk_begin = cb; c->chunk_end = ce; c->n_chunks = nch;
+  int rc = ensure_buffers(c, c->n_rows_local ? c->n_rows_local : 1);
+  if (rc) return rc;
+  c->launches[0] = c->launches[1] = c->launches[2] = 0;
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
+  if (c->n_rows_local) {
+    if (!coeffs_local) return LCPC_ERR_ARG;
+    HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs_local, (size_t)c->n_rows_local * c->n_per_row * elem_bytes(c), hipMemcpyDeviceToDevice, st));
+    if ((rc = encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st))) return rc;
+  }
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], st));
+  if (ce > cb) {
+    LeafArgs la{};
+    la.comm = c->d_comm; la.row_stride = c->n_cols; la.n_cols = c->n_cols; la.row_base = (int64_t)rb;
+    la.n_rows_total = n_rows_total; la.chunk_begin = (uint32_t)cb; la.n_chunks_local = (uint32_t)(ce - cb);
+    la.n_chunks_total = (uint32_t)nch;
+    la.out = reinterpret_cast<uint32_t*>(cvs_dev);
+    HIPCHK(c, launch_leaf_chunks(c->NL, la, st));
+    c->launches[1]++;
+  }
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], st));
+  return 0;
+}
+
+int lcpc_commit_finish_device(lcpc_ctx* c, const uint8_t* all_cvs, uint64_t n_rows_total, void* stream, uint8_t* root) {
+  if (!c || !all_cvs || n_rows_total != c->n_rows) return LCPC_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t nch = leaf_chunks(c, n_rows_total);
+  if (nch == 1) {
+    HIPCHK(c, hipMemcpyAsync(c->d_hashes, all_cvs, (size_t)c->n_cols * 32, hipMemcpyDeviceToDevice, st));
+  } else {
+    int rc = ensure_cvs(c, nch);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_cvs, all_cvs, (size_t)nch * c->n_cols * 32, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, launch_leaf_finish(c->d_cvs, (uint32_t)nch, c->n_cols, c->d_hashes, st));
+    c->launches[1]++;
+  }
+  if (c->np2 > c->n_cols)
+    HIPCHK(c, hipMemsetAsync(c->d_hashes + c->n_cols * 8, 0, (size_t)(c->np2 - c->n_cols) * 32, st));
+  if (c->np2 > 1) { HIPCHK(c, launch_merkle_tree(c->d_hashes, c->np2, st)); c->launches[2]++; }
+  c->committed = true;
+  if (c->timing) {
+    HIPCHK(c, hipEventRecord(c->ev[3], st));
+    HIPCHK(c, hipEventSynchronize(c->ev[3]));
+    (void)hipEventElapsedTime(&c->last.encode_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->last.hash_ms, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&c->last.merkle_ms, c->ev[2], c->ev[3]);   // includes the caller's exchange
+    (void)hipEventElapsedTime(&c->last.total_ms, c->ev[0], c->ev[3]);
+    c->last.encode_launches = c->launches[0]; c->last.hash_launches = c->launches[1]; c->last.merkle_launches = c->launches[2];
+  }
+  if (root) {
+    HIPCHK(c, hipMemcpyAsync(root, c->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
+int lcpc_set_timing(lcpc_ctx* c, int enable) { if (!c) return LCPC_ERR_ARG; c->timing = enable != 0; return 0; }
+int lcpc_get_timings(lcpc_ctx* c, lcpc_timings* out) { if (!c || !out) return LCPC_ERR_ARG; *out = c->last; return 0; }
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+"""helpers shared by the CPU (oracle) and GPU (HIP) test files."""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def hex_to_limbs(h, L):
+    v = int(h, 16)
+    return np.array([(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(L)], np.uint64)
+
+
+def golden_coeffs(oracle, case):
+    """the deterministic inputs of tests/golden/make_golden.py, as (n, L) Montgomery limbs."""
+    fid, n = case["field"], case["n_coeffs"]
+    L = oracle.limbs(fid)
+    if case["coeffs"] == "iota":
+        v = np.arange(1, n + 1, dtype=np.uint64)
+        out = np.zeros((n, L), np.uint64)
+        oracle.lib().lo_f_from_u64(fid, oracle.ptr(v), oracle.ptr(out), n)
+        return out
+    return oracle.random_elems(fid, n, case["seed"])
+
+
+def powers(oracle, fid, x_int, n, start_exp_step=1):
+    """[x^(k*step)] for k < n as Montgomery limbs (python ints -> oracle conversion)."""
+    import pyref as P
+    F = P.FIELDS[fid]
+    base = pow(x_int, start_exp_step, F.p)
+    vals, cur = [], 1
+    for _ in range(n):
+        vals.append(cur)
+        cur = cur * base % F.p
+    return oracle.to_mont(fid, vals)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def mk_transcript(T, root, n_col_opens):
+    # lcpc-ligero-pc/src/tests.rs:243-245
+    tr = T(b"test transcript")
+    tr.append_message(b"polycommit", bytes(root))
+    tr.append_message(b"ncols", int(n_col_opens).to_bytes(8, "big"))
+    return tr

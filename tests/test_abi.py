@@ -1,0 +1,82 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/lcpc_hip.h declares,
+fails loudly without a GPU (no CPU fallback), and its host-side dims logic matches the oracle."""
+import os
+import re
+
+import pytest
+
+import lcpc_amd
+from lcpc_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "lcpc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lcpc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = header_symbols()
+    assert len(syms) >= 35
+    L = _lib.lib()
+    for s in syms:
+        assert hasattr(L, s), "missing export: " + s
+    assert sorted(_lib.SYMBOLS) == syms, "ctypes table and header disagree"
+    assert L.lcpc_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(lcpc_amd.LcpcError) as e:
+        lcpc_amd.LigeroEncoding.new(lcpc_amd.FT63, 1 << 10)
+    assert e.value.code == -18          # LCPC_ERR_NO_DEVICE
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lcpc_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("no CPU fallback", "") or f == "_lib.py" or "imports oracle" in txt, f
+                assert "lcpc_oracle" not in txt and "pyref" not in txt, f
+
+
+def test_static_dims_match_oracle(oracle):
+    import ctypes as C
+    import random
+    rnd = random.Random(2)
+    for fid in (0, 3):
+        for rho in ((1, 2), (1, 4), (38, 39)):
+            for _ in range(60):
+                n = rnd.randrange(2, 1 << rnd.randrange(2, 30))
+                a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+                assert oracle.lib().lo_ligero_get_dims(fid, n, rho[0], rho[1], C.byref(a), C.byref(b), C.byref(c)) == 0
+                assert lcpc_amd.static_get_dims(fid, lcpc_amd.ENC_LIGERO, n, rho=rho) == (a.value, b.value, c.value)
+        for code in range(1, 7):
+            for _ in range(20):
+                n = rnd.randrange(50, 1 << rnd.randrange(7, 30))
+                a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+                assert oracle.lib().lo_sdig_get_dims(fid, n, code, C.byref(a), C.byref(b), C.byref(c)) == 0
+                assert lcpc_amd.static_get_dims(fid, lcpc_amd.ENC_SDIG, n, code=code) == (a.value, b.value, c.value)
+
+
+def test_transcript_matches_oracle(oracle):
+    import random
+    rnd = random.Random(4)
+    t1, t2 = lcpc_amd.Transcript(b"test protocol"), oracle.Transcript(b"test protocol")
+    t1.append_message(b"some label", b"some data")
+    t2.append_message(b"some label", b"some data")
+    assert t1.challenge_bytes(b"challenge", 32).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    t2.challenge_bytes(b"challenge", 32)
+    for _ in range(30):
+        m = bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 400)))
+        t1.append_message(b"lbl", m)
+        t2.append_message(b"lbl", m)
+        k = rnd.randrange(1, 300)
+        assert t1.challenge_bytes(b"ch", k) == t2.challenge_bytes(b"ch", k)
+    t3 = t1.clone()
+    assert t3.challenge_bytes(b"x", 16) == t1.challenge_bytes(b"x", 16)

@@ -1,0 +1,82 @@
+// tools/ubench_valu.hip -- integer-VALU throughput microbenchmark for gfx950.
+// Measures the issue rate of the instructions a 256-bit Montgomery multiply can be built from,
+// so DESIGN.md can price the NTT against a *measured* integer ceiling (the HBM roofline does not
+// bind a 255-bit field).  Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o ubench_valu
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+typedef uint32_t u32; typedef uint64_t u64;
+#define CHECK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n",hipGetErrorString(e),__LINE__); return 1;}}while(0)
+#define ITERS 2048
+#define UNROLL 8
+
+#define KERNEL(name, DECL, BODY, SINK) \
+__global__ void __launch_bounds__(256) name(u32* out, u32 seed){ \
+  u32 x=threadIdx.x*2654435761u+seed, y=x^0x9e3779b9u; DECL; \
+  for(int it=0; it<ITERS; ++it){ _Pragma("unroll") for(int u=0;u<UNROLL;++u){ BODY; } } \
+  out[blockIdx.x*blockDim.x+threadIdx.x]=SINK; }
+
+// 8 independent accumulator chains each
+KERNEL(k_mad_u64_u32, u64 a0=x;u64 a1=y;u64 a2=x+1;u64 a3=y+1;u64 a4=x+2;u64 a5=y+2;u64 a6=x+3;u64 a7=y+3,
+  asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+               "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x),"v"(y) : "vcc"),
+  (u32)(a0^a1^a2^a3^a4^a5^a6^a7))
+KERNEL(k_mad_addc, u64 a0=x;u64 a1=y;u64 a2=x+1;u64 a3=y+1; u32 h0=0;u32 h1=0;u32 h2=0;u32 h3=0,
+  asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_addc_co_u32 %4, vcc, 0, %4, vcc\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_addc_co_u32 %5, vcc, 0, %5, vcc\n"
+               "v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_addc_co_u32 %6, vcc, 0, %6, vcc\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n v_addc_co_u32 %7, vcc, 0, %7, vcc\n"
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(h0),"+v"(h1),"+v"(h2),"+v"(h3) : "v"(x),"v"(y) : "vcc"),
+  (u32)(a0^a1^a2^a3)^h0^h1^h2^h3)
+KERNEL(k_mad_dep, u64 a0=x,
+  asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+               "v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n v_mad_u64_u32 %0, vcc, %1, %2, %0\n"
+     : "+v"(a0) : "v"(x),"v"(y) : "vcc"),
+  (u32)(a0))
+#define OP8(OPSTR) asm volatile(OPSTR " %0, %8, %9\n" OPSTR " %1, %8, %9\n" OPSTR " %2, %8, %9\n" OPSTR " %3, %8, %9\n" OPSTR " %4, %8, %9\n" OPSTR " %5, %8, %9\n" OPSTR " %6, %8, %9\n" OPSTR " %7, %8, %9\n" \
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x),"v"(y))
+#define DECL8 u32 a0=x;u32 a1=y;u32 a2=x+1;u32 a3=y+1;u32 a4=x+2;u32 a5=y+2;u32 a6=x+3;u32 a7=y+3
+KERNEL(k_mul_lo_u32, DECL8, OP8("v_mul_lo_u32"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_mul_hi_u32, DECL8, OP8("v_mul_hi_u32"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_mul_u32_u24, DECL8, OP8("v_mul_u32_u24"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_mul_hi_u32_u24, DECL8, OP8("v_mul_hi_u32_u24"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_add_u32, DECL8, OP8("v_add_u32"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_xor_b32, DECL8, OP8("v_xor_b32"), a0^a1^a2^a3^a4^a5^a6^a7)
+#define OP8_3(OPSTR) asm volatile(OPSTR " %0, %8, %9, %0\n" OPSTR " %1, %8, %9, %1\n" OPSTR " %2, %8, %9, %2\n" OPSTR " %3, %8, %9, %3\n" OPSTR " %4, %8, %9, %4\n" OPSTR " %5, %8, %9, %5\n" OPSTR " %6, %8, %9, %6\n" OPSTR " %7, %8, %9, %7\n" \
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x),"v"(y))
+KERNEL(k_mad_u32_u24, DECL8, OP8_3("v_mad_u32_u24"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_alignbit, DECL8, OP8_3("v_alignbit_b32"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_add3_u32, DECL8, OP8_3("v_add3_u32"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_fma_f32, DECL8, OP8_3("v_fma_f32"), a0^a1^a2^a3^a4^a5^a6^a7)
+#define DECL8D double a0=x;double a1=y;double a2=x+1;double a3=y+1;double a4=x+2;double a5=y+2;double a6=x+3;double a7=y+3; double dx=1.0+1e-9*x; double dy=1e-9*y
+KERNEL(k_fma_f64, DECL8D,
+  asm volatile("v_fma_f64 %0, %8, %0, %9\n v_fma_f64 %1, %8, %1, %9\n v_fma_f64 %2, %8, %2, %9\n v_fma_f64 %3, %8, %3, %9\n v_fma_f64 %4, %8, %4, %9\n v_fma_f64 %5, %8, %5, %9\n v_fma_f64 %6, %8, %6, %9\n v_fma_f64 %7, %8, %7, %9\n"
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(dx),"v"(dy)),
+  (u32)(a0+a1+a2+a3+a4+a5+a6+a7))
+KERNEL(k_lshl_add_u64, u64 a0=x;u64 a1=y;u64 a2=x+1;u64 a3=y+1;u64 a4=x+2;u64 a5=y+2;u64 a6=x+3;u64 a7=y+3; u64 xx=x,
+  asm volatile("v_lshl_add_u64 %0, %0, 0, %8\n v_lshl_add_u64 %1, %1, 0, %8\n v_lshl_add_u64 %2, %2, 0, %8\n v_lshl_add_u64 %3, %3, 0, %8\n v_lshl_add_u64 %4, %4, 0, %8\n v_lshl_add_u64 %5, %5, 0, %8\n v_lshl_add_u64 %6, %6, 0, %8\n v_lshl_add_u64 %7, %7, 0, %8\n"
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(xx)),
+  (u32)(a0^a1^a2^a3^a4^a5^a6^a7))
+
+template <typename K> static double run(K kern, const char* name, int ops_per_body, int waves_per_simd, u32* d){
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  int blocks = 256 * waves_per_simd;   // 256 CUs x (waves_per_simd) blocks of 256 threads = 4 waves => waves/SIMD
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, 1u);
+  hipDeviceSynchronize();
+  float best=1e30f;
+  for(int r=0;r<5;r++){ hipEventRecord(e0); hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, (u32)r); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); if(ms<best)best=ms; }
+  double lane_ops = (double)blocks*256*ITERS*UNROLL*ops_per_body;
+  double rate = lane_ops/(best*1e-3);  // lane-ops / s
+  printf("%-22s waves/SIMD=%d  %8.3f ms  %8.2f Tlane-op/s  (%.2f cyc/wave-instr/SIMD @2.4GHz)\n", name, waves_per_simd, best, rate/1e12, 2.4e9*1024*64/rate);
+  return rate;
+}
+int main(){
+  u32* d; CHECK(hipMalloc(&d, 256*8*256*4));
+  hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p,0)); printf("device %s CUs=%d clock=%d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
+  for(int w : {1,2,4}){
+    run(k_mad_u64_u32,"v_mad_u64_u32",8,w,d); run(k_mad_addc,"mad_u64+addc (pairs)",4,w,d); run(k_mad_dep,"v_mad_u64_u32 dep",8,w,d);
+    run(k_mul_lo_u32,"v_mul_lo_u32",8,w,d); run(k_mul_hi_u32,"v_mul_hi_u32",8,w,d);
+    run(k_mul_u32_u24,"v_mul_u32_u24",8,w,d); run(k_mul_hi_u32_u24,"v_mul_hi_u32_u24",8,w,d); run(k_mad_u32_u24,"v_mad_u32_u24",8,w,d);
+    run(k_lshl_add_u64,"v_lshl_add_u64",8,w,d); run(k_fma_f32,"v_fma_f32",8,w,d); run(k_fma_f64,"v_fma_f64",8,w,d);
+  }
+  return 0;
+}
