@@ -188,6 +188,85 @@ template <int NL> LCPC_DEV Fe<NL> fe_canon(const Fe<NL>& a) {
   return fe_reduce_once<NL>(t, t[NL]);
 }
 
+
+// ---- reduced-radix Montgomery multiply for Ft255 (the headline field) --------------------------
+// Measured on gfx950 (profiles/r01_ubench_valu.txt): v_mad_u64_u32 issues at ~half the f32-FMA rate,
+// but every carry-propagating add after it costs about as much again, and the 32-bit-limb CIOS above
+// spends >2/3 of its instructions on 64-bit carry emulation.  With 9 limbs of 29 bits a whole Comba
+// column (<= 9 products < 2^58 plus <= 8 reduction products) fits one 64-bit accumulator, so the
+// product AND the Montgomery reduction are a pure chain of 153 v_mad_u64_u32 with no carry handling.
+// p == 1 mod 2^29, hence -p^-1 == -1 mod 2^29 and the quotient digit is a negate-and-mask.
+// The multiplier (a twiddle) is pre-converted on the host to the radix-2^261 Montgomery form
+// w * 2^261 mod p, so  REDC_261( a*R * w*2^261 ) = (a*w)*R : data stays in ff_derive's R = 2^256 form.
+struct P29 {
+  static constexpr u32 M = (1u << 29) - 1;
+  static constexpr u32 limb(int k) {   // k-th 29-bit limb of the Ft255 modulus
+    const int b = 29 * k, w = b / 32, sh = b % 32;
+    u64 lo = Mod<8>::P[w];
+    u64 hi = (w + 1 < 8) ? Mod<8>::P[w + 1] : 0;
+    return (u32)(((lo | (hi << 32)) >> sh) & M);
+  }
+};
+struct Fe29 {
+  u32 v[9];
+};
+// packed 8x32 -> 9x29 (value unchanged, limbs < 2^29)
+LCPC_DEV Fe29 fe_to29(const Fe<8>& a) {
+  Fe29 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int b = 29 * k, w = b / 32, sh = b % 32;
+    u32 x;
+    if (sh == 0) x = a.v[w];
+    else if (w + 1 < 8) x = __builtin_amdgcn_alignbit(a.v[w + 1], a.v[w], sh);
+    else x = a.v[w] >> sh;
+    r.v[k] = x & P29::M;
+  }
+  return r;
+}
+// 9x29 (limbs < 2^29, value < 2^256) -> packed 8x32
+LCPC_DEV void fe_from29(u32 out[8], const u32 l[9]) {
+#pragma unroll
+  for (int w = 0; w < 8; w++) {
+    const int b = 32 * w, k = b / 29, s = b % 29;      // word w starts at bit s of limb k
+    u32 x = l[k] >> s;
+    x |= l[k + 1] << (29 - s);
+    if (58 - s < 32 && k + 2 < 9) x |= l[k + 2] << (58 - s);
+    out[w] = x;
+  }
+}
+// r = a * b29 * 2^-261 mod p, fully reduced, packed.  a: packed element < p; b29: 9 limbs < 2^29.
+LCPC_DEV Fe<8> fe_mul_r29(const Fe<8>& a, const Fe29& b) {
+  const Fe29 x = fe_to29(a);
+  u32 m[9], r[9];
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < 9) acc += (u64)x.v[i] * b.v[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (i < k && j >= 1 && j < 9) acc += (u64)m[i] * P29::limb(j);
+    }
+    if (k < 9) {
+      m[k] = (0u - (u32)acc) & P29::M;
+      acc += m[k];                    // + m_k * p_0, p_0 = 1: low 29 bits become zero
+      acc >>= 29;
+    } else {
+      r[k - 9] = (u32)acc & P29::M;
+      acc >>= 29;
+    }
+  }
+  r[8] = (u32)acc;
+  u32 t[8];
+  fe_from29(t, r);
+  return fe_reduce_once<8>(t, 0u);     // REDC output < 2p < 2^256
+}
+
 // ---- lazy (unreduced) accumulation: sum of products, one Montgomery reduction at the end -------
 // Used by collapse_columns and the expander SpMV: acc += a*b as a plain 2NL(+1)-limb integer.
 // With <= 2^32 terms of size < p^2 < 2^(64NL-2) the sum fits 2NL+1 limbs.

@@ -10,6 +10,7 @@ struct NttPassArgs {
   const uint32_t* src;     // row-major, src_stride elements per row
   uint32_t* dst;           // row-major, dst_stride elements per row (may alias src when strides match)
   const uint32_t* roots;   // roots[i] = w^i (Montgomery), i < n/2
+  const uint32_t* roots29; // Ft255 only: w^i * 2^261 mod p as 9 x 29-bit limbs, 12-word stride (fe_mul_r29)
   uint64_t src_stride, dst_stride;
   uint64_t n_valid;        // elements >= n_valid of every src row read as zero (fused zero padding)
   uint64_t n_rows;

@@ -106,9 +106,18 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
       const u64 widx = (g1 & gap_mask) << t;     // exponent of w, < n/2
       const Fe<NL> x = lds_get<NL, LT>(lds, e1);
       const Fe<NL> y = lds_get<NL, LT>(lds, e2);
-      const Fe<NL> w = fe_load<NL>(a.roots + widx * NL);
       lds_put<NL, LT>(lds, e1, fe_add<NL>(x, y));
-      lds_put<NL, LT>(lds, e2, fe_mul<NL>(fe_sub<NL>(x, y), w));
+      if constexpr (NL == 8) {
+        const uint4* wp = reinterpret_cast<const uint4*>(a.roots29 + widx * 12);
+        const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+        Fe29 w;
+        w.v[0] = w0.x; w.v[1] = w0.y; w.v[2] = w0.z; w.v[3] = w0.w;
+        w.v[4] = w1.x; w.v[5] = w1.y; w.v[6] = w1.z; w.v[7] = w1.w; w.v[8] = w2.x;
+        lds_put<NL, LT>(lds, e2, fe_mul_r29(fe_sub<NL>(x, y), w));
+      } else {
+        const Fe<NL> w = fe_load<NL>(a.roots + widx * NL);
+        lds_put<NL, LT>(lds, e2, fe_mul<NL>(fe_sub<NL>(x, y), w));
+      }
     }
     __syncthreads();
   }

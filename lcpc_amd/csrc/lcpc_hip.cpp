@@ -45,6 +45,7 @@ struct lcpc_ctx {
   // Ligero
   unsigned log_n = 0;
   uint32_t* d_roots = nullptr;
+  uint32_t* d_roots29 = nullptr;   // Ft255: twiddles in radix-2^29 / R'=2^261 Montgomery form (field_dev.h fe_mul_r29)
   std::vector<Pass> passes;
   // Brakedown
   SdigSpec spec{};
@@ -201,6 +202,7 @@ int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, ui
       a.src = first ? src : dst;
       a.dst = dst;
       a.roots = c->d_roots;
+      a.roots29 = c->d_roots29;
       a.src_stride = first ? src_stride : c->n_cols;
       a.dst_stride = c->n_cols;
       a.n_valid = first ? n_valid : c->n_cols;
@@ -404,6 +406,24 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
     roots_table(*f, c->log_n, roots);
     if ((rc = dev_alloc(c, &c->d_roots, roots.size() * 8))) { lcpc_ctx_destroy(c); return rc; }
     if (hipMemcpy(c->d_roots, roots.data(), roots.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
+    if (f->L == 4) {
+      // w*R (R = 2^256) -> w*2^261 mod p (five doublings), split into 9 limbs of 29 bits, 12-word stride
+      const size_t nroots = roots.size() / 4;
+      std::vector<uint32_t> r29(nroots * 12, 0);
+      for (size_t i = 0; i < nroots; i++) {
+        uint64_t t[4];
+        memcpy(t, &roots[i * 4], 32);
+        for (int d = 0; d < 5; d++) h_add(*f, t, t, t);
+        for (int k = 0; k < 9; k++) {
+          const int b = 29 * k, w = b / 64, sh = b % 64;
+          uint64_t x = t[w] >> sh;
+          if (sh > 35 && w + 1 < 4) x |= t[w + 1] << (64 - sh);
+          r29[i * 12 + k] = (uint32_t)(x & ((1u << 29) - 1));
+        }
+      }
+      if ((rc = dev_alloc(c, &c->d_roots29, r29.size() * 4))) { lcpc_ctx_destroy(c); return rc; }
+      if (hipMemcpy(c->d_roots29, r29.data(), r29.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
+    }
     plan_passes(c);
   } else if (p->encoding == LCPC_ENC_SDIG) {
     if (!sdig_spec((int)c->prm.sdig_code, &c->spec)) { delete c; return LCPC_ERR_ARG; }
@@ -448,7 +468,7 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
 void lcpc_ctx_destroy(lcpc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->prm.device);
-  dev_free(c->d_roots); dev_free(c->d_r2); dev_free(c->d_tmp);
+  dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_r2); dev_free(c->d_tmp);
   for (auto* v : {&c->d_pre, &c->d_post})
     for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); }
   dev_free(c->d_coeffs); dev_free(c->d_comm); dev_free(c->d_hashes); dev_free(c->d_cvs); dev_free(c->d_scratch);

@@ -36,10 +36,11 @@ def exchange_chunk_cvs(local_cvs, n_chunks_total, group=None):
     n_cols = local_cvs.shape[1]
     pad = torch.zeros((kmax, n_cols, 32), dtype=torch.uint8, device=local_cvs.device)
     pad[:local_cvs.shape[0]] = local_cvs
-    out = torch.empty((world, kmax, n_cols, 32), dtype=torch.uint8, device=local_cvs.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    flat = torch.empty((world * kmax, n_cols, 32), dtype=torch.uint8, device=local_cvs.device)
+    dist.all_gather_into_tensor(flat, pad, group=group)      # rank g's block lands at rows [g*kmax, (g+1)*kmax)
     if all(e - b == kmax for b, e in split):
-        return out.view(world * kmax, n_cols, 32)
+        return flat
+    out = flat.view(world, kmax, n_cols, 32)
     return torch.cat([out[g, :e - b] for g, (b, e) in enumerate(split)], dim=0)
 
 

@@ -874,6 +874,71 @@ void lo_hash_column(int fid, const u64 *col, u64 n_rows, u8 out[32]) {
   }
   b3_final(&d, out);
 }
+/* chunk CV of one column: chunk `ch` of the message 0^32 || repr(col[0]) || ... (bytes [1024 ch, 1024 ch + 1024)) */
+int lo_leaf_chunk_cvs(int fid, const u64 *comm, u64 n_cols, u64 row_base, u64 n_local, u64 n_rows, u64 cb, u64 ce, u8 *cvs) {
+  const fld_t *f = getf(fid);
+  if (!f) return LO_ERR_ARG;
+  const int L = f->L;
+  const u64 F = 8 * L, total = 32 + F * n_rows, n_chunks = (total + 1023) / 1024;
+  u8 *msg = malloc(1024);
+  for (u64 ch = cb; ch < ce; ch++)
+    for (u64 col = 0; col < n_cols; col++) {
+      const u64 off = ch * 1024, len = total - off < 1024 ? total - off : 1024;
+      for (u64 b = 0; b < len;) {              /* assemble the chunk's bytes from the prefix and the local rows */
+        const u64 pos = off + b;
+        if (pos < 32) { msg[b++] = 0; continue; }
+        const u64 row = (pos - 32) / F, within = (pos - 32) % F;
+        if (row < row_base || row >= row_base + n_local) { free(msg); return LO_ERR_ARG; }
+        u64 t[MAXL];
+        DISPATCH_L(f, fcanon(t, comm + ((row - row_base) * n_cols + col) * L, f, L));
+        u64 take = F - within;
+        if (take > len - b) take = len - b;
+        memcpy(msg + b, (const u8 *)t + within, take);
+        b += take;
+      }
+      u32 cv[8];
+      memcpy(cv, B3_IV, 32);
+      const u64 nb = (len + 63) / 64;
+      for (u64 b = 0; b < nb; b++) {
+        u32 blk[16] = { 0 };
+        const u64 bl = len - 64 * b < 64 ? len - 64 * b : 64;
+        memcpy(blk, msg + 64 * b, bl);
+        u32 flags = (b == 0 ? B3_CHUNK_START : 0) | (b == nb - 1 ? (B3_CHUNK_END | (n_chunks == 1 ? B3_ROOT : 0)) : 0);
+        b3_compress(cv, blk, ch, (u32)bl, flags);
+      }
+      memcpy(cvs + ((ch - cb) * n_cols + col) * 32, cv, 32);
+    }
+  free(msg);
+  return 0;
+}
+static void b3_tree_from_cvs(const u32 (*cv)[8], u64 n, int is_root, u32 out[8]) {
+  if (n == 1) { memcpy(out, cv[0], 32); return; }
+  u64 left = 1;
+  while (left * 2 < n) left *= 2;
+  u32 blk[16];
+  b3_tree_from_cvs(cv, left, 0, blk);
+  b3_tree_from_cvs(cv + left, n - left, 0, blk + 8);
+  memcpy(out, B3_IV, 32);
+  b3_compress(out, blk, 0, 64, B3_PARENT | (is_root ? B3_ROOT : 0));
+}
+int lo_finish_from_cvs(const u8 *all, u64 n_chunks, u64 n_cols, u8 *hashes) {
+  const u64 w0 = np2(n_cols);
+  memset(hashes, 0, (2 * w0 - 1) * 32);
+  u32 (*tmp)[8] = malloc(n_chunks * 32);
+  for (u64 col = 0; col < n_cols; col++) {
+    for (u64 ch = 0; ch < n_chunks; ch++) memcpy(tmp[ch], all + (ch * n_cols + col) * 32, 32);
+    u32 out[8];
+    b3_tree_from_cvs((const u32 (*)[8])tmp, n_chunks, 1, out);
+    memcpy(hashes + 32 * col, out, 32);
+  }
+  free(tmp);
+  u64 width = w0, ins = 0, outs = w0;
+  while (width > 1) {
+    for (u64 i = 0; i < width / 2; i++) merkle_pair(hashes + 32 * (ins + 2 * i), hashes + 32 * (outs + i));
+    ins = outs; outs += width / 2; width /= 2;
+  }
+  return 0;
+}
 void lo_merkleize_ser(lo_commit *c) { /* lib.rs:1127-1158 */
   const int L = c->f->L;
   u64 *col = malloc(c->n_rows * L * 8 + 8);

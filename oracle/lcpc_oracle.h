@@ -106,6 +106,13 @@ void lo_merkleize_ser(lo_commit *);                  /* lib.rs:1127-1158 */
 int  lo_collapse_columns(const lo_commit *, const uint64_t *tensor, uint64_t n_tensor, uint64_t *poly, int n_threads);
 int  lo_open_column(const lo_commit *, uint64_t column, uint64_t *col_out, uint8_t *path_out);
 void lo_hash_column(int fid, const uint64_t *col, uint64_t n_rows, uint8_t out[32]);
+/* row-sharded hashing (DESIGN.md multi-GPU): BLAKE3 chaining values of leaf-message chunks
+ * [chunk_begin, chunk_end) for every column, from the rows [row_base, row_base + n_rows_local) of comm;
+ * cvs[(chunk - chunk_begin) * n_cols + col][32].  With a single chunk the "CV" is the final digest. */
+int  lo_leaf_chunk_cvs(int fid, const uint64_t *comm_local, uint64_t n_cols, uint64_t row_base, uint64_t n_rows_local,
+                       uint64_t n_rows_total, uint64_t chunk_begin, uint64_t chunk_end, uint8_t *cvs);
+/* fold all chunk CVs of every column into leaf digests (BLAKE3 parent rule), then the Merkle tree */
+int  lo_finish_from_cvs(const uint8_t *all_cvs, uint64_t n_chunks, uint64_t n_cols, uint8_t *hashes /* (2*np2-1)*32 */);
 
 /* ---- prove / verify (bincode 1.3 wire format) ---- */
 int  lo_prove(const lo_commit *, const lo_enc *, const uint64_t *outer_tensor, uint64_t n_outer,

@@ -83,6 +83,8 @@ def lib():
             "lo_collapse_columns": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_int]),
             "lo_open_column": (C.c_int, [vp, C.c_uint64, vp, vp]),
             "lo_hash_column": (None, [C.c_int, vp, C.c_uint64, vp]),
+            "lo_leaf_chunk_cvs": (C.c_int, [C.c_int, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]),
+            "lo_finish_from_cvs": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),
             "lo_prove": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp, vp, vp]),
             "lo_verify": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp, vp]),
             "lo_free": (None, [vp]),
@@ -349,3 +351,22 @@ def hash_column(fid, col):
     out = np.zeros(32, np.uint8)
     lib().lo_hash_column(fid, ptr(col), col.size // limbs(fid), ptr(out))
     return out.tobytes()
+
+
+def leaf_chunk_cvs(fid, comm_local, n_cols, row_base, n_rows_local, n_rows_total, chunk_begin, chunk_end):
+    comm_local = np.ascontiguousarray(comm_local, np.uint64)
+    out = np.zeros((max(chunk_end - chunk_begin, 0), n_cols, 32), np.uint8)
+    if out.size:
+        rc = lib().lo_leaf_chunk_cvs(fid, ptr(comm_local), n_cols, row_base, n_rows_local, n_rows_total, chunk_begin, chunk_end, ptr(out))
+        if rc:
+            raise RuntimeError("lo_leaf_chunk_cvs: %d" % rc)
+    return out
+
+
+def finish_from_cvs(all_cvs, n_cols):
+    all_cvs = np.ascontiguousarray(all_cvs, np.uint8)
+    n_chunks = all_cvs.shape[0]
+    np2 = 1 << max(0, (n_cols - 1).bit_length())
+    hashes = np.zeros((2 * np2 - 1, 32), np.uint8)
+    lib().lo_finish_from_cvs(ptr(all_cvs), n_chunks, n_cols, ptr(hashes))
+    return hashes

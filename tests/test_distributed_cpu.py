@@ -1,0 +1,109 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo process groups run lcpc_amd.distributed.sharded_commit with a
+stand-in engine built on the *oracle* (the product engine is HIP-only), so the shard layout, the padded
+all-gather of chunk chaining values and the reassembly order are exercised end to end and must reproduce the
+unsharded oracle root.  Also checks chunk_split() against the C library's lcpc_shard_layout arithmetic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from lcpc_amd.distributed import chunk_split, sharded_commit
+
+
+class OracleShardEngine:
+    """CPU stand-in for HipShardEngine: same three methods, oracle arithmetic."""
+
+    def __init__(self, fid, n_per_row, n_cols, rank, world):
+        self.fid, self.L = fid, O.limbs(fid)
+        self.enc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+        self.n_per_row, self.n_cols, self.rank, self.world = n_per_row, n_cols, rank, world
+        self.hashes = None
+
+    def layout(self, n_rows):
+        F = 8 * self.L
+        n_chunks = (32 + F * n_rows + 1023) // 1024
+        cb, ce = chunk_split(n_chunks, self.world)[self.rank]
+
+        def first_row(ch):
+            return 0 if ch == 0 else min(n_rows, (ch * 1024 - 32) // F)
+        rb = first_row(cb)
+        re = n_rows if ce >= n_chunks else first_row(ce)
+        if cb == ce:
+            re = rb
+        return rb, re, cb, ce, n_chunks
+
+    def commit_shard(self, local_coeffs, n_rows):
+        rb, re, cb, ce, _ = self.layout(n_rows)
+        rows = local_coeffs.numpy().view(np.uint64).reshape(re - rb, self.n_per_row, self.L)
+        comm = np.zeros((re - rb, self.n_cols, self.L), np.uint64)
+        for r in range(re - rb):
+            comm[r, :self.n_per_row] = rows[r]
+            comm[r] = self.enc.encode(comm[r].copy()).reshape(self.n_cols, self.L)
+        cvs = O.leaf_chunk_cvs(self.fid, comm, self.n_cols, rb, re - rb, n_rows, cb, ce)
+        return torch.from_numpy(cvs)
+
+    def commit_finish(self, all_cvs, n_rows, want_root=True):
+        self.hashes = O.finish_from_cvs(all_cvs.numpy(), self.n_cols)
+        return self.hashes[-1].tobytes()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = OracleShardEngine(fid, n_per_row, n_cols, rank, world)
+        rb, re, _, _, _ = eng.layout(n_rows)
+        coeffs = O.random_elems(fid, n_rows * n_per_row, 17).reshape(n_rows, n_per_row, -1)
+        local = torch.from_numpy(coeffs[rb:re].copy().view(np.int64))
+        root = sharded_commit(eng, local, n_rows)
+        q.put((rank, root, eng.hashes.tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fid,n_rows,n_per_row,n_cols", [
+    (2, 3, 70, 32, 64),      # ft255: 3 chunks over 2 ranks (uneven), rows 0..62 | 63..69
+    (2, 0, 300, 16, 32),     # ft63: 128 rows per chunk
+    (3, 3, 40, 16, 32),      # 2 chunks over 3 ranks: one rank owns nothing
+])
+def test_sharded_commit_gloo(world, fid, n_rows, n_per_row, n_cols):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fid, n_rows, n_per_row, n_cols, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # unsharded oracle commit of the same coefficients
+    enc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+    coeffs = O.random_elems(fid, n_rows * n_per_row, 17)
+    oc = O.Commit.commit(coeffs, enc)
+    for rank, root, hashes in res:
+        assert root == oc.get_root(), "rank %d" % rank
+        assert hashes == oc.hashes().tobytes()
+
+
+def test_chunk_split_is_a_partition():
+    for n in range(1, 70):
+        for w in (1, 2, 3, 4, 8):
+            sp = chunk_split(n, w)
+            assert sp[0][0] == 0 and sp[-1][1] == n
+            assert all(sp[i][1] == sp[i + 1][0] for i in range(w - 1))
+            assert max(e - b for b, e in sp) - min(e - b for b, e in sp) <= 1

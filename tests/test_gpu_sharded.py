@@ -1,0 +1,64 @@
+"""Row-sharded commit on the GPU: G shard contexts on one device (one per would-be rank), the all-gather
+emulated by concatenating their chunk-CV tensors in rank order -- must equal the unsharded HIP commit and the
+oracle, for the layouts the 8-GPU bench uses.  (The real exchange is torch.distributed over RCCL; its
+assembly logic is covered on CPU by tests/test_distributed_cpu.py.)"""
+import numpy as np
+import pytest
+import torch
+
+import lcpc_amd
+from lcpc_amd import LcCommit, LigeroEncoding, SdigEncoding
+from lcpc_amd.distributed import HipShardEngine, chunk_split
+
+pytestmark = pytest.mark.gpu
+
+
+def run_sharded(mk_enc, G, coeffs_rows, n_rows):
+    """coeffs_rows: torch int64 cuda tensor [n_rows, n_per_row, L]"""
+    engines = [HipShardEngine(mk_enc((g, G))) for g in range(G)]
+    cvs = []
+    for g, eng in enumerate(engines):
+        rb, re, cb, ce, nch = eng.layout(n_rows)
+        local = coeffs_rows[rb:re].contiguous()
+        cvs.append(eng.commit_shard(local, n_rows))
+        assert (cb, ce) == chunk_split(nch, G)[g]
+        assert cvs[-1].shape[0] == ce - cb
+    all_cvs = torch.cat(cvs, dim=0).contiguous()
+    roots = [eng.commit_finish(all_cvs.clone(), n_rows) for eng in engines]
+    return roots, engines
+
+
+@pytest.mark.parametrize("fid,n_rows,n_per_row,n_cols,G", [
+    (3, 512, 256, 512, 8),      # headline row count: 17 chunks over 8 ranks (2,2,2,2,2,2,2,3)
+    (3, 512, 256, 512, 2),
+    (3, 1024, 128, 256, 8),     # C4 row count: 33 chunks
+    (3, 70, 64, 128, 4),        # 3 chunks over 4 ranks: one rank owns nothing
+    (0, 300, 128, 256, 2),      # ft63: 128 rows per chunk
+    (1, 200, 64, 128, 4),       # ft127
+    (3, 20, 64, 128, 2),        # single chunk: the "CV" is already the digest
+])
+def test_sharded_equals_unsharded(oracle, fid, n_rows, n_per_row, n_cols, G):
+    O = oracle
+    L = O.limbs(fid)
+    coeffs = O.random_elems(fid, n_rows * n_per_row, 19)
+    dev = torch.from_numpy(coeffs.view(np.int64)).cuda().reshape(n_rows, n_per_row, L)
+    roots, engines = run_sharded(lambda sh: LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=sh), G, dev, n_rows)
+    ref = LcCommit.commit(coeffs, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols))
+    oc = O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4)
+    assert ref.get_root() == oc.get_root()
+    for r in roots:
+        assert r == ref.get_root()
+    # every rank ends with the full hashes array; its comm holds exactly its own rows
+    for g, eng in enumerate(engines):
+        c = LcCommit(eng.enc)
+        assert (c.hashes() == ref.hashes()).all()
+        rb, re, _, _, _ = eng.layout(n_rows)
+        if re > rb:
+            assert (c.comm(rb, re - rb) == oc.comm().reshape(n_rows, -1)[rb:re].reshape(-1, L)).all()
+
+
+def test_sharding_rejects_straddling_field():
+    # ft191 rows (24 B) straddle 1 KiB chunk boundaries: row sharding is refused rather than silently wrong
+    with pytest.raises(lcpc_amd.LcpcError) as e:
+        LigeroEncoding.new_from_dims(2, 64, 128, shard=(0, 2))
+    assert e.value.code == lcpc_amd.ERR_ARG
