@@ -115,6 +115,125 @@ template <int NL> LCPC_DEV Fe<NL> fe_sub(const Fe<NL>& a, const Fe<NL>& b) {
   for (int i = 0; i < NL; i++) d.v[i] = br ? s.v[i] : d.v[i];
   return d;
 }
+
+// ---- Ft255 add / sub as explicit VCC carry chains ---------------------------------------------
+// hipcc lowers the portable u64-based add/sub above to ~90 instructions (64-bit adds + moves);
+// the hardware carry chain is 8 + 8 + 8.  Two asm statements each, so that no carry flag lives
+// across a statement boundary (hipcc does not model VCC inside an asm string).
+#define LCPC_P8_1 "0x02a4f200"
+#define LCPC_P8_2 "0x86595f30"
+#define LCPC_P8_3 "0xef73c790"
+#define LCPC_P8_4 "0xb9575969"
+#define LCPC_P8_5 "0xfda9df04"
+#define LCPC_P8_6 "0x6e4d2900"
+#define LCPC_P8_7 "0x663c799b"
+template <> LCPC_DEV Fe<8> fe_add<8>(const Fe<8>& a, const Fe<8>& b) {
+  Fe<8> r;
+  u32 d0, d1, d2, d3, d4, d5, d6, d7;
+  asm("v_add_co_u32 %0, vcc, %8, %16\n\t"
+      "v_addc_co_u32 %1, vcc, %9, %17, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %10, %18, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %11, %19, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %12, %20, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %13, %21, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %14, %22, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %15, %23, vcc"
+      : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7])
+      : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+        "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+      : "vcc");
+  // d = r - p; keep r if that borrows (r < p)
+  asm("v_subrev_co_u32 %8, vcc, 1, %0\n\t"
+      "v_subbrev_co_u32 %9, vcc, %16, %1, vcc\n\t"
+      "v_subbrev_co_u32 %10, vcc, %17, %2, vcc\n\t"
+      "v_subbrev_co_u32 %11, vcc, %18, %3, vcc\n\t"
+      "v_subbrev_co_u32 %12, vcc, %19, %4, vcc\n\t"
+      "v_subbrev_co_u32 %13, vcc, %20, %5, vcc\n\t"
+      "v_subbrev_co_u32 %14, vcc, %21, %6, vcc\n\t"
+      "v_subbrev_co_u32 %15, vcc, %22, %7, vcc\n\t"
+      "v_cndmask_b32 %0, %8, %0, vcc\n\t"
+      "v_cndmask_b32 %1, %9, %1, vcc\n\t"
+      "v_cndmask_b32 %2, %10, %2, vcc\n\t"
+      "v_cndmask_b32 %3, %11, %3, vcc\n\t"
+      "v_cndmask_b32 %4, %12, %4, vcc\n\t"
+      "v_cndmask_b32 %5, %13, %5, vcc\n\t"
+      "v_cndmask_b32 %6, %14, %6, vcc\n\t"
+      "v_cndmask_b32 %7, %15, %7, vcc"
+      : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7]),
+        "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+      : "v"(Mod<8>::P[1]), "v"(Mod<8>::P[2]), "v"(Mod<8>::P[3]), "v"(Mod<8>::P[4]), "v"(Mod<8>::P[5]), "v"(Mod<8>::P[6]), "v"(Mod<8>::P[7])
+      : "vcc");
+  return r;
+}
+template <> LCPC_DEV Fe<8> fe_sub<8>(const Fe<8>& a, const Fe<8>& b) {
+  Fe<8> r;
+  u32 mask, t0, t1, t2, t3, t4, t5, t6, t7;
+  asm("v_sub_co_u32 %0, vcc, %9, %17\n\t"
+      "v_subb_co_u32 %1, vcc, %10, %18, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %11, %19, vcc\n\t"
+      "v_subb_co_u32 %3, vcc, %12, %20, vcc\n\t"
+      "v_subb_co_u32 %4, vcc, %13, %21, vcc\n\t"
+      "v_subb_co_u32 %5, vcc, %14, %22, vcc\n\t"
+      "v_subb_co_u32 %6, vcc, %15, %23, vcc\n\t"
+      "v_subb_co_u32 %7, vcc, %16, %24, vcc\n\t"
+      "v_cndmask_b32 %8, 0, -1, vcc"
+      : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]),
+        "=&v"(mask)
+      : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+        "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7])
+      : "vcc");
+  // r += p & mask  (mask = all ones iff a < b)
+  asm("v_and_b32 %8, 1, %16\n\t"
+      "v_and_b32 %9, " LCPC_P8_1 ", %16\n\t"
+      "v_and_b32 %10, " LCPC_P8_2 ", %16\n\t"
+      "v_and_b32 %11, " LCPC_P8_3 ", %16\n\t"
+      "v_and_b32 %12, " LCPC_P8_4 ", %16\n\t"
+      "v_and_b32 %13, " LCPC_P8_5 ", %16\n\t"
+      "v_and_b32 %14, " LCPC_P8_6 ", %16\n\t"
+      "v_and_b32 %15, " LCPC_P8_7 ", %16\n\t"
+      "v_add_co_u32 %0, vcc, %0, %8\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
+      "v_addc_co_u32 %7, vcc, %7, %15, vcc"
+      : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+      : "v"(mask)
+      : "vcc");
+  return r;
+}
+// t (8 limbs) in [0, 2p) -> [0, p): the 8-limb specialisation of fe_reduce_once with top == 0
+LCPC_DEV Fe<8> fe_reduce_once8(const u32* t) {
+  Fe<8> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  u32 d0, d1, d2, d3, d4, d5, d6, d7;
+  asm("v_subrev_co_u32 %8, vcc, 1, %0\n\t"
+      "v_subbrev_co_u32 %9, vcc, %16, %1, vcc\n\t"
+      "v_subbrev_co_u32 %10, vcc, %17, %2, vcc\n\t"
+      "v_subbrev_co_u32 %11, vcc, %18, %3, vcc\n\t"
+      "v_subbrev_co_u32 %12, vcc, %19, %4, vcc\n\t"
+      "v_subbrev_co_u32 %13, vcc, %20, %5, vcc\n\t"
+      "v_subbrev_co_u32 %14, vcc, %21, %6, vcc\n\t"
+      "v_subbrev_co_u32 %15, vcc, %22, %7, vcc\n\t"
+      "v_cndmask_b32 %0, %8, %0, vcc\n\t"
+      "v_cndmask_b32 %1, %9, %1, vcc\n\t"
+      "v_cndmask_b32 %2, %10, %2, vcc\n\t"
+      "v_cndmask_b32 %3, %11, %3, vcc\n\t"
+      "v_cndmask_b32 %4, %12, %4, vcc\n\t"
+      "v_cndmask_b32 %5, %13, %5, vcc\n\t"
+      "v_cndmask_b32 %6, %14, %6, vcc\n\t"
+      "v_cndmask_b32 %7, %15, %7, vcc"
+      : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7]),
+        "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+      : "v"(Mod<8>::P[1]), "v"(Mod<8>::P[2]), "v"(Mod<8>::P[3]), "v"(Mod<8>::P[4]), "v"(Mod<8>::P[5]), "v"(Mod<8>::P[6]), "v"(Mod<8>::P[7])
+      : "vcc");
+  return r;
+}
+
 // conditional final subtraction: t (NL limbs + top word) in [0, 2p) -> [0, p)
 template <int NL> LCPC_DEV Fe<NL> fe_reduce_once(const u32* t, u32 top) {
   Fe<NL> d, r;
@@ -264,7 +383,7 @@ LCPC_DEV Fe<8> fe_mul_r29(const Fe<8>& a, const Fe29& b) {
   r[8] = (u32)acc;
   u32 t[8];
   fe_from29(t, r);
-  return fe_reduce_once<8>(t, 0u);     // REDC output < 2p < 2^256
+  return fe_reduce_once8(t);           // REDC output < 2p < 2^256
 }
 
 // ---- lazy (unreduced) accumulation: sum of products, one Montgomery reduction at the end -------

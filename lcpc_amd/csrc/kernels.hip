@@ -62,6 +62,33 @@ __device__ __forceinline__ void lds_put(u32* lds, u32 e, const Fe<NL>& a) {
   }
 }
 
+// twiddle multiply: d * w^widx (Montgomery).  Ft255 uses the 29-bit-limb table (fe_mul_r29).
+template <int NL> struct Tw {
+  Fe<NL> w;
+};
+template <> struct Tw<8> {
+  Fe29 w;
+};
+template <int NL>
+__device__ __forceinline__ Tw<NL> tw_load(const NttPassArgs& a, u32 widx) {
+  Tw<NL> t;
+  if constexpr (NL == 8) {
+    const uint4* wp = reinterpret_cast<const uint4*>(a.roots29 + (size_t)widx * 12);
+    const uint4 w0 = wp[0], w1 = wp[1];
+    const u32 w8 = a.roots29[(size_t)widx * 12 + 8];
+    t.w.v[0] = w0.x; t.w.v[1] = w0.y; t.w.v[2] = w0.z; t.w.v[3] = w0.w;
+    t.w.v[4] = w1.x; t.w.v[5] = w1.y; t.w.v[6] = w1.z; t.w.v[7] = w1.w; t.w.v[8] = w8;
+  } else {
+    t.w = fe_load<NL>(a.roots + (size_t)widx * NL);
+  }
+  return t;
+}
+template <int NL>
+__device__ __forceinline__ Fe<NL> tw_mul(const Fe<NL>& d, const Tw<NL>& t) {
+  if constexpr (NL == 8) return fe_mul_r29(d, t.w);
+  else return fe_mul<NL>(d, t.w);
+}
+
 template <int NL, int LT>
 __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -69,61 +96,95 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
   const u32 lb = k - t0 - s;                    // bits below the pass's i-field
   const u32 lbt = lb < ltj ? lb : ltj;          // lo-bits that live inside the tile
   const u32 T = 1u << (s + ltj);                // tile elements (<= 2^LT)
-  const u64 tiles_per_row = (u64)1 << (k - s - ltj);
+  const u32 tiles_per_row = 1u << (k - s - ltj);
   const u64 row = blockIdx.x / tiles_per_row;
-  const u64 tile = blockIdx.x % tiles_per_row;
-  const u64 o0 = tile << ltj;                   // first outer index of the tile
+  const u32 tile = blockIdx.x % tiles_per_row;
+  const u32 o0 = tile << ltj;                   // first outer index of the tile
   const u32 tid = threadIdx.x;
   const u32 lp_mask = (1u << lbt) - 1, i_mask = (1u << s) - 1;
-  const u64 lo_mask = ((u64)1 << lb) - 1;
+  const u32 lo_mask = (1u << lb) - 1;
 
-  auto gindex = [&](u32 e) -> u64 {              // LDS slot -> element index within the row
+  auto gindex = [&](u32 e) -> u32 {              // LDS slot -> element index within the row (k <= 30)
     const u32 lp = e & lp_mask, i = (e >> lbt) & i_mask, hp = e >> (lbt + s);
-    const u64 outer = o0 | ((u64)hp << lbt) | lp;
-    return ((outer >> lb) << (lb + s)) | ((u64)i << lb) | (outer & lo_mask);
+    const u32 outer = o0 | (hp << lbt) | lp;
+    return ((outer >> lb) << (lb + s)) | (i << lb) | (outer & lo_mask);
   };
 
   const u32* src = a.src + row * a.src_stride * NL;
   for (u32 e = tid; e < T; e += 256) {
-    const u64 g = gindex(e);
-    Fe<NL> v = (g < a.n_valid) ? fe_load<NL>(src + g * NL) : fe_zero<NL>();
+    const u32 g = gindex(e);
+    Fe<NL> v = (g < a.n_valid) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
     lds_put<NL, LT>(lds, e, v);
   }
   __syncthreads();
 
-  for (u32 u = 0; u < s; u++) {
+  u32 u = 0;
+  // ---- radix-4 rounds: local stages (u, u+1) on the four slots i0 + c*Q, c = 0..3 --------------
+  for (; u + 1 < s; u += 2) {
     const u32 t = t0 + u;
-    const u32 hb = s - u - 1;                    // bit of i that distinguishes the butterfly pair
-    const u64 gap_mask = ((u64)1 << (k - t - 1)) - 1;
+    const u32 hb = s - u - 1;                    // pair bit of stage u; stage u+1 uses hb-1
+    const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
+    const bool last_two = (t + 2 == k);          // stages k-2, k-1: twiddles are 1, w^(n/4), 1
+    for (u32 q = tid; q < T / 4; q += 256) {
+      const u32 lp = q & lp_mask;
+      const u32 j = (q >> lbt) & (i_mask >> 2);
+      const u32 hp = q >> (lbt + s - 2);
+      const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+      const u32 e0 = (((hp << s) | i0) << lbt) | lp;
+      const u32 dq = 1u << (hb - 1 + lbt);
+      const u32 g0 = gindex(e0), g1 = gindex(e0 + dq);
+      Fe<NL> x0 = lds_get<NL, LT>(lds, e0), x1 = lds_get<NL, LT>(lds, e0 + dq);
+      Fe<NL> x2 = lds_get<NL, LT>(lds, e0 + 2 * dq), x3 = lds_get<NL, LT>(lds, e0 + 3 * dq);
+      if (last_two) {
+        // stage k-2: (x0,x2) twiddle w^0 = 1, (x1,x3) twiddle w^(n/4); stage k-1: twiddle 1 everywhere
+        const Tw<NL> wq = tw_load<NL>(a, 1u << (k - 2));
+        const Fe<NL> b0 = fe_add<NL>(x0, x2), b2 = fe_sub<NL>(x0, x2);
+        const Fe<NL> b1 = fe_add<NL>(x1, x3), b3 = tw_mul<NL>(fe_sub<NL>(x1, x3), wq);
+        lds_put<NL, LT>(lds, e0, fe_add<NL>(b0, b1));
+        lds_put<NL, LT>(lds, e0 + dq, fe_sub<NL>(b0, b1));
+        lds_put<NL, LT>(lds, e0 + 2 * dq, fe_add<NL>(b2, b3));
+        lds_put<NL, LT>(lds, e0 + 3 * dq, fe_sub<NL>(b2, b3));
+      } else {
+        const Tw<NL> w0 = tw_load<NL>(a, (g0 & gm0) << t);
+        const Tw<NL> w1 = tw_load<NL>(a, (g1 & gm0) << t);
+        const Tw<NL> w2 = tw_load<NL>(a, (g0 & gm1) << (t + 1));
+        const Fe<NL> b0 = fe_add<NL>(x0, x2), b2 = tw_mul<NL>(fe_sub<NL>(x0, x2), w0);
+        const Fe<NL> b1 = fe_add<NL>(x1, x3), b3 = tw_mul<NL>(fe_sub<NL>(x1, x3), w1);
+        lds_put<NL, LT>(lds, e0, fe_add<NL>(b0, b1));
+        lds_put<NL, LT>(lds, e0 + dq, tw_mul<NL>(fe_sub<NL>(b0, b1), w2));
+        lds_put<NL, LT>(lds, e0 + 2 * dq, fe_add<NL>(b2, b3));
+        lds_put<NL, LT>(lds, e0 + 3 * dq, tw_mul<NL>(fe_sub<NL>(b2, b3), w2));
+      }
+    }
+    __syncthreads();
+  }
+  // ---- radix-2 tail when s is odd --------------------------------------------------------------
+  for (; u < s; u++) {
+    const u32 t = t0 + u;
+    const u32 hb = s - u - 1;
+    const u32 gm = (1u << (k - t - 1)) - 1;
     for (u32 q = tid; q < T / 2; q += 256) {
       const u32 lp = q & lp_mask;
       const u32 j = (q >> lbt) & (i_mask >> 1);
       const u32 hp = q >> (lbt + s - 1);
       const u32 i = ((j >> hb) << (hb + 1)) | (j & ((1u << hb) - 1));
-      const u32 e1 = ((((hp << s) | i)) << lbt) | lp;
+      const u32 e1 = (((hp << s) | i) << lbt) | lp;
       const u32 e2 = e1 + (1u << (hb + lbt));
-      const u64 g1 = gindex(e1);
-      const u64 widx = (g1 & gap_mask) << t;     // exponent of w, < n/2
-      const Fe<NL> x = lds_get<NL, LT>(lds, e1);
-      const Fe<NL> y = lds_get<NL, LT>(lds, e2);
+      const u32 widx = (gindex(e1) & gm) << t;
+      const Fe<NL> x = lds_get<NL, LT>(lds, e1), y = lds_get<NL, LT>(lds, e2);
       lds_put<NL, LT>(lds, e1, fe_add<NL>(x, y));
-      if constexpr (NL == 8) {
-        const uint4* wp = reinterpret_cast<const uint4*>(a.roots29 + widx * 12);
-        const uint4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
-        Fe29 w;
-        w.v[0] = w0.x; w.v[1] = w0.y; w.v[2] = w0.z; w.v[3] = w0.w;
-        w.v[4] = w1.x; w.v[5] = w1.y; w.v[6] = w1.z; w.v[7] = w1.w; w.v[8] = w2.x;
-        lds_put<NL, LT>(lds, e2, fe_mul_r29(fe_sub<NL>(x, y), w));
+      if (t + 1 == k) {
+        lds_put<NL, LT>(lds, e2, fe_sub<NL>(x, y));          // last stage: twiddle w^0 = 1
       } else {
-        const Fe<NL> w = fe_load<NL>(a.roots + widx * NL);
-        lds_put<NL, LT>(lds, e2, fe_mul<NL>(fe_sub<NL>(x, y), w));
+        const Tw<NL> w = tw_load<NL>(a, widx);
+        lds_put<NL, LT>(lds, e2, tw_mul<NL>(fe_sub<NL>(x, y), w));
       }
     }
     __syncthreads();
   }
 
   u32* dst = a.dst + row * a.dst_stride * NL;
-  for (u32 e = tid; e < T; e += 256) fe_store<NL>(dst + gindex(e) * NL, lds_get<NL, LT>(lds, e));
+  for (u32 e = tid; e < T; e += 256) fe_store<NL>(dst + (size_t)gindex(e) * NL, lds_get<NL, LT>(lds, e));
 }
 
 template <int NL, int LT>

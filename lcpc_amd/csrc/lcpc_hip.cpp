@@ -401,6 +401,7 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
     if (p->n_per_row && p->n_cols) { np_ = p->n_per_row; nc = p->n_cols; }      // new_from_dims (ligero lib.rs:138-148)
     else if ((rc = lcpc_static_get_dims(p, &nr, &np_, &nc))) { delete c; return rc; }
     if (!(np_ < nc) || (nc & (nc - 1)) || log2_ceil(nc) > f->S) { delete c; return LCPC_ERR_DIMS; }   // _dims_ok + precomp_fft
+    if (log2_ceil(nc) > 30) { delete c; return LCPC_ERR_TOO_BIG; }      // device kernels index a row with 32 bits
     c->n_per_row = np_; c->n_cols = nc; c->log_n = (unsigned)log2_ceil(nc);
     std::vector<uint64_t> roots;
     roots_table(*f, c->log_n, roots);
