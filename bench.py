@@ -141,9 +141,20 @@ def main():
     ntt_launches = max(1, tm.encode_launches)
     ntt_ms = tm.encode_ms / ntt_launches
     achieved = (enc_bytes / ntt_launches) / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_latest.json")
+    if os.path.exists(pmc_path):
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+        pmc = json.load(open(pmc_path))
+        for kname, v in pmc["kernels"].items():
+            if kname.startswith("ntt_pass_kernel<8"):
+                traffic = round((2.0 * v["FETCH_KB"] + v["WRITE_KB"]) * 1024 / 1e9, 3)
+                traffic_src = "profiles/r01_pmc_latest.json (rocprofv3 --pmc; GB per launch = 2*FETCH_SIZE + WRITE_SIZE; " \
+                              "2-pass NTT: each pass reads+writes the matrix, pass 1 also writes LcCommit.coeffs)"
     roofline = {"bound": "hbm", "kernel": "ntt_pass_kernel<8,*> (row NTT, %d launches per commit)" % ntt_launches,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_unit": "GB/launch", "traffic_source": traffic_src,
+                "algorithmic_GB_per_launch": round(enc_bytes / ntt_launches / 1e9, 3),
                 "avg_launch_ms": round(ntt_ms, 4),
                 "note": "255-bit modular multiply makes this kernel integer-VALU-bound, not HBM-bound (DESIGN.md)",
                 "commit_GBps": round(commit_bytes / (tm.total_ms * 1e-3) / 1e9, 1) if tm.total_ms > 0 else None,

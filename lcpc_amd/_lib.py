@@ -84,6 +84,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("lcpc_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback)" % LIB_PATH)
+        try:
+            # when torch shares the process (tests, bench.py) its bundled HIP runtime must be the one that gets
+            # loaded first; loading ROCm's copy first leaves torch unable to see the GPU ("No HIP GPUs are available")
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch

@@ -73,6 +73,47 @@ template <int NL> LCPC_DEV void fe_store(u32* __restrict__ p, const Fe<NL>& a) {
   }
 }
 
+
+// streaming (touch-once) variants: non-temporal hint keeps the L2 for the twiddle table
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+template <int NL> LCPC_DEV Fe<NL> fe_load_nt(const u32* __restrict__ p) {
+  Fe<NL> r;
+  if constexpr (NL % 4 == 0) {
+    const u32x4_t* q = reinterpret_cast<const u32x4_t*>(p);
+#pragma unroll
+    for (int i = 0; i < NL / 4; i++) {
+      u32x4_t t = __builtin_nontemporal_load(q + i);
+      r.v[4 * i] = t.x; r.v[4 * i + 1] = t.y; r.v[4 * i + 2] = t.z; r.v[4 * i + 3] = t.w;
+    }
+  } else {
+    const u32x2_t* q = reinterpret_cast<const u32x2_t*>(p);
+#pragma unroll
+    for (int i = 0; i < NL / 2; i++) {
+      u32x2_t t = __builtin_nontemporal_load(q + i);
+      r.v[2 * i] = t.x; r.v[2 * i + 1] = t.y;
+    }
+  }
+  return r;
+}
+template <int NL> LCPC_DEV void fe_store_nt(u32* __restrict__ p, const Fe<NL>& a) {
+  if constexpr (NL % 4 == 0) {
+    u32x4_t* q = reinterpret_cast<u32x4_t*>(p);
+#pragma unroll
+    for (int i = 0; i < NL / 4; i++) {
+      u32x4_t t = {a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]};
+      __builtin_nontemporal_store(t, q + i);
+    }
+  } else {
+    u32x2_t* q = reinterpret_cast<u32x2_t*>(p);
+#pragma unroll
+    for (int i = 0; i < NL / 2; i++) {
+      u32x2_t t = {a.v[2 * i], a.v[2 * i + 1]};
+      __builtin_nontemporal_store(t, q + i);
+    }
+  }
+}
+
 // ---- add / sub --------------------------------------------------------------------------------
 // r = a + b mod p; 2p < 2^(32 NL) so the plain sum never carries out.
 template <int NL> LCPC_DEV Fe<NL> fe_add(const Fe<NL>& a, const Fe<NL>& b) {
@@ -384,6 +425,50 @@ LCPC_DEV Fe<8> fe_mul_r29(const Fe<8>& a, const Fe29& b) {
   u32 t[8];
   fe_from29(t, r);
   return fe_reduce_once8(t);           // REDC output < 2p < 2^256
+}
+
+
+// Montgomery form (R = 2^256) -> canonical value for Ft255, reduction only: a * 2^-256 = REDC_261(a * 2^5).
+// The "product" a << 5 needs no multiplies; the 9-step reduction is 72 v_mad_u64_u32, carry-free.
+LCPC_DEV Fe<8> fe_canon_r29(const Fe<8>& a) {
+  // limbs of (a << 5): bit b of the shifted value is bit b-5 of a
+  u32 x[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int b = 29 * k - 5;            // first source bit of limb k (negative for k = 0)
+    u32 v;
+    if (k == 0) v = (a.v[0] << 5);
+    else {
+      const int w = b / 32, sh = b % 32;
+      if (sh == 0) v = a.v[w];
+      else if (w + 1 < 8) v = __builtin_amdgcn_alignbit(a.v[w + 1], a.v[w], sh);
+      else v = a.v[w] >> sh;
+    }
+    x[k] = v & P29::M;
+  }
+  u32 m[9], r[9];
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    if (k < 9) acc += x[k];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (i < k && j >= 1 && j < 9) acc += (u64)m[i] * P29::limb(j);
+    }
+    if (k < 9) {
+      m[k] = (0u - (u32)acc) & P29::M;
+      acc += m[k];
+      acc >>= 29;
+    } else {
+      r[k - 9] = (u32)acc & P29::M;
+      acc >>= 29;
+    }
+  }
+  r[8] = (u32)acc;
+  u32 t[8];
+  fe_from29(t, r);
+  return fe_reduce_once8(t);
 }
 
 // ---- lazy (unreduced) accumulation: sum of products, one Montgomery reduction at the end -------

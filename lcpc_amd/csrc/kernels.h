@@ -13,6 +13,8 @@ struct NttPassArgs {
   const uint32_t* roots29; // Ft255 only: w^i * 2^261 mod p as 9 x 29-bit limbs, 12-word stride (fe_mul_r29)
   uint64_t src_stride, dst_stride;
   uint64_t n_valid;        // elements >= n_valid of every src row read as zero (fused zero padding)
+  uint64_t n_src_total;    // flat src elements >= n_src_total read as zero (ragged last row)
+  uint32_t* copy_dst;      // if non-null (first pass): padded copy of src, same strides (LcCommit.coeffs)
   uint64_t n_rows;
   uint32_t log_n, t0, s, log_tj;   // stages [t0, t0+s) on tiles of 2^s x 2^log_tj elements
 };

@@ -97,8 +97,21 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
   const u32 lbt = lb < ltj ? lb : ltj;          // lo-bits that live inside the tile
   const u32 T = 1u << (s + ltj);                // tile elements (<= 2^LT)
   const u32 tiles_per_row = 1u << (k - s - ltj);
-  const u64 row = blockIdx.x / tiles_per_row;
-  const u32 tile = blockIdx.x % tiles_per_row;
+  // XCD-aware mapping: workgroup b runs on XCD b % 8 (each XCD has a private L2).  The twiddles a tile needs
+  // are the same for every row, so each XCD walks ALL rows of one tile back-to-back before moving to its next
+  // tile: the tile's twiddle set (<= 2 x tile size) stays resident in that XCD's L1/L2 instead of being
+  // evicted by the streamed tile data.  (Placement only affects speed, never results.)
+  u64 row;
+  u32 tile;
+  if (tiles_per_row >= 8) {
+    const u32 xcd = blockIdx.x & 7u;
+    const u64 q = blockIdx.x >> 3;
+    tile = (u32)(q / a.n_rows) * 8u + xcd;
+    row = q % a.n_rows;
+  } else {
+    row = blockIdx.x / tiles_per_row;
+    tile = blockIdx.x % tiles_per_row;
+  }
   const u32 o0 = tile << ltj;                   // first outer index of the tile
   const u32 tid = threadIdx.x;
   const u32 lp_mask = (1u << lbt) - 1, i_mask = (1u << s) - 1;
@@ -113,8 +126,10 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
   const u32* src = a.src + row * a.src_stride * NL;
   for (u32 e = tid; e < T; e += 256) {
     const u32 g = gindex(e);
-    Fe<NL> v = (g < a.n_valid) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
+    Fe<NL> v = (g < a.n_valid && row * a.src_stride + g < a.n_src_total) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
     lds_put<NL, LT>(lds, e, v);
+    // fused `coeffs` copy (lcpc-2d lib.rs:636-645): every message element is loaded exactly once, here
+    if (a.copy_dst != nullptr && g < a.n_valid) fe_store<NL>(a.copy_dst + (row * a.src_stride + g) * NL, v);
   }
   __syncthreads();
 
@@ -228,7 +243,8 @@ __device__ __forceinline__ void leaf_fill_block(u32 m[16], const LeafArgs& a, u6
     const int64_t row = row0 + x;
     if (row >= 0 && (u64)row < a.n_rows_total) {
       const u32* p = a.comm + ((u64)(row - a.row_base) * a.row_stride + col) * NL;
-      el[x] = fe_canon<NL>(fe_load<NL>(p));
+      if constexpr (NL == 8) el[x] = fe_canon_r29(fe_load<NL>(p));
+      else el[x] = fe_canon<NL>(fe_load<NL>(p));
     } else {
       el[x] = fe_zero<NL>();
     }

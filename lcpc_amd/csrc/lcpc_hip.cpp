@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -193,7 +194,7 @@ void shard_layout(const lcpc_ctx* c, uint64_t n_rows, uint64_t* rb, uint64_t* re
 
 // ---- encode all local rows: coeffs -> comm ----------------------------------------------------------
 int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, uint64_t n_valid, uint32_t* dst,
-                       uint64_t n_rows, hipStream_t st) {
+                       uint64_t n_rows, hipStream_t st, uint64_t n_src_total = ~(uint64_t)0, uint32_t* copy_dst = nullptr) {
   if (n_rows == 0) return 0;
   if (c->prm.encoding == LCPC_ENC_LIGERO) {
     bool first = true;
@@ -206,6 +207,8 @@ int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, ui
       a.src_stride = first ? src_stride : c->n_cols;
       a.dst_stride = c->n_cols;
       a.n_valid = first ? n_valid : c->n_cols;
+      a.n_src_total = first ? n_src_total : ~(uint64_t)0;
+      a.copy_dst = first ? copy_dst : nullptr;
       a.n_rows = n_rows;
       a.log_n = c->log_n; a.t0 = p.t0; a.s = p.s; a.log_tj = p.log_tj;
       HIPCHK(c, launch_ntt_pass(c->NL, p.log_tile, a, st));
@@ -297,10 +300,11 @@ int finish_timing(lcpc_ctx* c, hipStream_t st) {
 }
 
 // commit with the padded coefficient matrix already in c->d_coeffs
-int commit_resident(lcpc_ctx* c, hipStream_t st, uint8_t* root) {
+int commit_resident(lcpc_ctx* c, hipStream_t st, uint8_t* root, const uint32_t* ext_src = nullptr, uint64_t n_ext = 0) {
   c->launches[0] = c->launches[1] = c->launches[2] = 0;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
-  int rc = encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st);
+  int rc = ext_src ? encode_rows_device(c, ext_src, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st, n_ext, c->d_coeffs)
+                   : encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st);
   if (rc) return rc;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], st));
   if ((rc = merkleize_device(c, st))) return rc;
@@ -529,7 +533,11 @@ int lcpc_commit_device(lcpc_ctx* c, const uint64_t* coeffs_dev, uint64_t n_coeff
   int rc = set_rows(c, n_coeffs);
   if (rc) return rc;
   const size_t eb = elem_bytes(c);
-  // local copy of coeffs with zero padding (lib.rs:636-645); LcCommit keeps it for prove
+  if (c->prm.encoding == LCPC_ENC_LIGERO) {
+    // the padded local copy of coeffs (lib.rs:636-645; LcCommit keeps it for prove) is written by the first
+    // NTT pass while it streams the caller's buffer: no separate D2D copy
+    return commit_resident(c, st, root, reinterpret_cast<const uint32_t*>(coeffs_dev), n_coeffs);
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs_dev, (size_t)n_coeffs * eb, hipMemcpyDeviceToDevice, st));
   const uint64_t padded = c->n_rows * c->n_per_row;
   if (padded > n_coeffs)
@@ -647,43 +655,44 @@ static size_t collapse_scratch_bytes(const lcpc_ctx* c, uint32_t n_tensors) {
   return (size_t)collapse_splits(c) * n_tensors * c->n_per_row * elem_bytes(c);
 }
 
+// scratch layout for collapse: [tensors (host entry only)] [polys (host entry only)] ... [partials at the end]
+static int collapse_run(lcpc_ctx* c, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_polys) {
+  for (uint32_t t = 0; t < n_tensors; t += 2) {
+    const uint32_t nt = (n_tensors - t) >= 2 ? 2 : 1;
+    int rc = collapse_local(c, d_tensors + (size_t)t * c->n_rows_local * c->NL, nt, st, d_polys + (size_t)t * c->n_per_row * c->NL);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int lcpc_collapse_device(lcpc_ctx* c, const uint64_t* tensors_dev, uint32_t n_tensors, void* stream, uint64_t* polys_dev) {
   if (!c || !tensors_dev || !polys_dev || n_tensors == 0) return LCPC_ERR_ARG;
   if (!c->committed) return LCPC_ERR_STATE;
   std::lock_guard<std::mutex> g(c->mu);
   HIPCHK(c, hipSetDevice(c->prm.device));
-  hipStream_t st = (hipStream_t)stream;
-  const size_t eb = elem_bytes(c);
   int rc = ensure_scratch(c, collapse_scratch_bytes(c, 2));
   if (rc) return rc;
-  for (uint32_t t = 0; t < n_tensors; t += 2) {
-    const uint32_t nt = (n_tensors - t) >= 2 ? 2 : 1;
-    rc = collapse_local(c, reinterpret_cast<const uint32_t*>(tensors_dev) + (size_t)t * c->n_rows_local * c->NL, nt, st,
-                        reinterpret_cast<uint32_t*>(polys_dev) + (size_t)t * c->n_per_row * c->NL);
-    if (rc) return rc;
-  }
-  (void)eb;
-  return 0;
+  return collapse_run(c, reinterpret_cast<const uint32_t*>(tensors_dev), n_tensors, (hipStream_t)stream,
+                      reinterpret_cast<uint32_t*>(polys_dev));
 }
 
 int lcpc_collapse(lcpc_ctx* c, const uint64_t* tensors, uint32_t n_tensors, uint64_t* polys) {
   if (!c || !tensors || !polys || n_tensors == 0) return LCPC_ERR_ARG;
   if (!c->committed) return LCPC_ERR_STATE;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
   const size_t eb = elem_bytes(c);
-  const size_t tb = (size_t)n_tensors * c->n_rows_local * eb, pb = (size_t)n_tensors * c->n_per_row * eb;
-  uint64_t *d_t = nullptr, *d_p = nullptr;
-  {
-    std::lock_guard<std::mutex> g(c->mu);
-    HIPCHK(c, hipSetDevice(c->prm.device));
-    int rc;
-    if ((rc = dev_alloc(c, &d_t, tb))) return rc;
-    if ((rc = dev_alloc(c, &d_p, pb))) { dev_free(d_t); return rc; }
-    if (hipMemcpy(d_t, tensors, tb, hipMemcpyHostToDevice) != hipSuccess) { dev_free(d_t); dev_free(d_p); return LCPC_ERR_HIP; }
-  }
-  int rc = lcpc_collapse_device(c, d_t, n_tensors, nullptr, d_p);
-  if (!rc && hipMemcpy(polys, d_p, pb, hipMemcpyDeviceToHost) != hipSuccess) rc = LCPC_ERR_HIP;
-  dev_free(d_t); dev_free(d_p);
-  return rc;
+  const size_t tb = ((size_t)n_tensors * c->n_rows_local * eb + 255) & ~(size_t)255;
+  const size_t pb = ((size_t)n_tensors * c->n_per_row * eb + 255) & ~(size_t)255;
+  int rc = ensure_scratch(c, tb + pb + collapse_scratch_bytes(c, 2) + 256);
+  if (rc) return rc;
+  uint8_t* base = reinterpret_cast<uint8_t*>(c->d_scratch);
+  uint32_t* d_t = reinterpret_cast<uint32_t*>(base);
+  uint32_t* d_p = reinterpret_cast<uint32_t*>(base + tb);
+  HIPCHK(c, hipMemcpyAsync(d_t, tensors, (size_t)n_tensors * c->n_rows_local * eb, hipMemcpyHostToDevice, nullptr));
+  if ((rc = collapse_run(c, d_t, n_tensors, nullptr, d_p))) return rc;
+  HIPCHK(c, hipMemcpy(polys, d_p, (size_t)n_tensors * c->n_per_row * eb, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int lcpc_field_sum_device(lcpc_ctx* c, const uint64_t* parts, uint32_t n_parts, uint64_t n_elems, void* stream, uint64_t* out) {
@@ -756,6 +765,10 @@ int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transc
   Transcript& tr = trw->t;
   const uint64_t n_deg = lcpc_get_n_degree_tests(c), n_open = lcpc_get_n_col_opens(c);
   const uint64_t np = c->n_per_row, nr = c->n_rows;
+  const bool dbg = getenv("LCPC_DEBUG_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tp[8] = {now(), 0, 0, 0, 0, 0, 0, 0};
+  double t_collapse = 0, t_absorb = 0;
   std::vector<uint64_t> tensors(2 * nr * L), polys(2 * np * L), p_eval(np * L);
   std::vector<std::vector<uint64_t>> p_random(n_deg);
   bool have_eval = false;
@@ -769,17 +782,23 @@ int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transc
       memcpy(&tensors[nr * L], outer, nr * L * 8);
       nt = 2;
     }
+    double t0 = now();
     int rc = lcpc_collapse(c, tensors.data(), nt, polys.data());
     if (rc) return rc;
+    t_collapse += now() - t0;
     p_random[i].assign(polys.begin(), polys.begin() + np * L);
     if (nt == 2) { memcpy(p_eval.data(), &polys[np * L], np * L * 8); have_eval = true; }
+    t0 = now();
     absorb_poly(tr, LBL_PR, f, p_random[i].data(), np);
+    t_absorb += now() - t0;
   }
   if (!have_eval) {                                                           // lib.rs:1053-1064
     int rc = lcpc_collapse(c, outer, 1, p_eval.data());
     if (rc) return rc;
   }
+  tp[1] = now();
   absorb_poly(tr, LBL_PE, f, p_eval.data(), np);                              // lib.rs:1066-1068
+  tp[2] = now();
   uint8_t key[32];
   tr.challenge_bytes(LBL_CO, 6, key, 32);                                     // lib.rs:1071-1080
   ChaCha20Rng rng(key);
@@ -788,8 +807,10 @@ int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transc
   if (cols_opened) memcpy(cols_opened, cols.data(), n_open * 8);
   std::vector<uint64_t> vals((size_t)n_open * nr * L);
   std::vector<uint8_t> paths((size_t)n_open * c->path_len * 32 + 32);
+  tp[3] = now();
   int rc = lcpc_open_columns(c, cols.data(), (uint32_t)n_open, vals.data(), paths.data());   // lib.rs:1081-1084
   if (rc) return rc;
+  tp[4] = now();
   // bincode 1.3 of WrappedLcEvalProof (lib.rs:550-560): n_cols, p_eval, p_random_vec, columns
   std::vector<uint8_t> w;
   w.reserve(32 + (1 + n_deg) * (np * L * 8 + 8) + n_open * (nr * L * 8 + 16 + c->path_len * 40));
@@ -807,6 +828,9 @@ int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transc
   if (!out) return LCPC_ERR_NOMEM;
   memcpy(out, w.data(), w.size());
   *proof = out; *proof_len = w.size();
+  if (dbg)
+    fprintf(stderr, "[lcpc_prove] collapse %.2f ms, absorb p_random %.2f, absorb p_eval %.2f, challenges+alloc %.2f, open %.2f, bincode %.2f, total %.2f\n",
+            t_collapse, t_absorb, tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], now() - tp[4], now() - tp[0]);
   return 0;
 }
 

@@ -304,3 +304,27 @@ def test_recommit_same_context(oracle):
         coeffs = O.random_elems(3, n, n & 0xff)
         c = LcCommit.commit(coeffs, enc)
         assert c.get_root() == O.Commit.commit(coeffs, oenc).get_root()
+
+
+@pytest.mark.parametrize("kind,fid,n,rho", [("ligero", 3, 20000, (1, 4)), ("ligero", 0, 3001, (38, 39)), ("ligero", 1, 12345, (1, 2)),
+                                            ("sdig", 3, 5000, None), ("ligero", 3, 4096 * 3 - 1, (1, 2))])
+def test_commit_device_ragged(oracle, kind, fid, n, rho):
+    """lcpc_commit_device (coefficients resident in HBM; for Ligero the padded `coeffs` copy is written by the
+    first NTT pass): ragged lengths (last row partly zero-padded) must match the host-pointer path and the oracle."""
+    import torch
+    O = oracle
+    L = O.limbs(fid)
+    coeffs = O.random_elems(fid, n, 29)
+    if kind == "ligero":
+        enc, oenc = LigeroEncoding.new(fid, n, rho), O.Encoding.ligero(fid, n, rho)
+    else:
+        enc, oenc = SdigEncoding.new(fid, n, 4), O.Encoding.sdig(fid, n, 4)
+    dev = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    # poison the context's buffers with an earlier, longer commit so stale data would show
+    LcCommit.commit(O.random_elems(fid, n + enc.n_per_row, 30), enc)
+    c = LcCommit.commit_device(dev.data_ptr(), n, enc, torch.cuda.current_stream().cuda_stream)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+    assert c.get_root() == oc.get_root()
+    assert (c.comm() == oc.comm()).all() and (c.coeffs() == oc.coeffs()).all() and (c.hashes() == oc.hashes()).all()
+    t = O.random_elems(fid, c.n_rows, 31)
+    assert (c.eval_outer(t) == oc.collapse(t)).all()
