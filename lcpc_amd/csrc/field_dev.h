@@ -471,6 +471,59 @@ LCPC_DEV Fe<8> fe_canon_r29(const Fe<8>& a) {
   return fe_reduce_once8(t);
 }
 
+
+// ---- carry-free lazy dot product for Ft255 (Brakedown SpMM, collapse) ---------------------------
+// acc += x * v with x, v as 9 x 29-bit limbs: 81 v_mad_u64_u32 into 18 u64 columns, no carries.
+// A column receives <= 9 products < 2^58 per term, so up to 7 terms fit before lazy29_normalize()
+// must move the excess up; the value is Montgomery-reduced once per dot product (lazy29_reduce).
+struct Lazy29 {
+  u64 c[18];
+};
+LCPC_DEV void lazy29_zero(Lazy29& a) {
+#pragma unroll
+  for (int k = 0; k < 18; k++) a.c[k] = 0;
+}
+LCPC_DEV void lazy29_mac(Lazy29& a, const Fe29& x, const Fe29& v) {
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j < 9; j++) a.c[i + j] += (u64)x.v[i] * v.v[j];
+}
+LCPC_DEV void lazy29_normalize(Lazy29& a) {
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    a.c[k + 1] += a.c[k] >> 29;
+    a.c[k] &= P29::M;
+  }
+}
+// value * 2^-261 mod p, fully reduced, packed.  Requires value < 64 * p^2 (<= 64 terms of (x < p) * (v < p)),
+// so that the REDC output is < 2p.  v operands must be in the 2^261-Montgomery form (like the NTT twiddles).
+LCPC_DEV Fe<8> lazy29_reduce(Lazy29& a) {
+  lazy29_normalize(a);
+  u32 m[9], r[9];
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 18; k++) {
+    acc += a.c[k];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (i < k && j >= 1 && j < 9) acc += (u64)m[i] * P29::limb(j);
+    }
+    if (k < 9) {
+      m[k] = (0u - (u32)acc) & P29::M;
+      acc += m[k];
+      acc >>= 29;
+    } else {
+      r[k - 9] = (u32)acc & P29::M;
+      acc >>= 29;
+    }
+  }
+  u32 t[8];
+  fe_from29(t, r);
+  return fe_reduce_once8(t);
+}
+
 // ---- lazy (unreduced) accumulation: sum of products, one Montgomery reduction at the end -------
 // Used by collapse_columns and the expander SpMV: acc += a*b as a plain 2NL(+1)-limb integer.
 // With <= 2^32 terms of size < p^2 < 2^(64NL-2) the sum fits 2NL+1 limbs.

@@ -66,6 +66,27 @@ struct SpmvArgs {
   uint64_t m, n_rows;
 };
 hipError_t launch_spmv(int nl, const SpmvArgs& a, hipStream_t st);
+// ---- position-major ("transposed") Brakedown path: T[pos][row], row fastest -----------------------
+// rows x n_valid block of a row-major matrix -> T (leading dimension n_rows); and back
+hipError_t launch_transpose_to_t(int nl, const uint32_t* src, uint64_t src_stride, uint64_t n_valid, uint64_t n_rows,
+                                 uint32_t* t, hipStream_t st);
+hipError_t launch_transpose_from_t(int nl, const uint32_t* t, uint64_t n_pos, uint64_t n_rows, uint32_t* dst,
+                                   uint64_t dst_stride, hipStream_t st);
+struct SpmmTArgs {
+  uint32_t* t;                  // T[pos][row]
+  uint32_t* out_alt;            // if non-null: outputs go to out_alt[o][row] instead of t[out_off + o][row]
+  uint64_t n_rows;
+  uint64_t in_off, out_off;
+  const uint32_t* rowptr;       // [m+1]
+  const uint32_t* colidx;       // [nnz]
+  const uint32_t* vals;         // [nnz][NL]  Montgomery (R = 2^(32 NL))
+  const uint32_t* vals29;       // Ft255: [nnz][12]  value * 2^261 mod p as 9 x 29-bit limbs
+  uint64_t m;
+};
+hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st);
+hipError_t launch_sdig_rs_t(int nl, const uint32_t* in_t, uint32_t n_in, uint32_t* t, uint64_t out_off, uint32_t n_out,
+                            uint64_t n_rows, const uint32_t* r2, hipStream_t st);
+
 // Reed-Solomon base case (encode.rs:97-110): out[row][out_off + k] = sum_j in[row][j] (k+1)^j
 hipError_t launch_sdig_rs(int nl, const uint32_t* in, uint64_t in_stride, uint32_t n_in, uint32_t* mat, uint64_t stride,
                           uint64_t out_off, uint32_t n_out, uint64_t n_rows, const uint32_t* r2, hipStream_t st);

@@ -234,23 +234,37 @@ hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream
 // unit a row-sharded multi-GPU commit exchanges.  A second tiny kernel folds the CVs of a column with
 // BLAKE3's parent rule.  Element -> canonical little-endian bytes is one Montgomery reduction.
 // =================================================================================================
-template <int NL, int PH>
-__device__ __forceinline__ void leaf_fill_block(u32 m[16], const LeafArgs& a, u64 col, int64_t row0) {
-  constexpr int NEL = (PH + 16 + NL - 1) / NL;
+template <int NL, int PH> struct LeafRaw {
+  static constexpr int NEL = (PH + 16 + NL - 1) / NL;     // elements a 16-word block touches
   Fe<NL> el[NEL];
+};
+// issue the global loads of one 64-byte block's elements (Montgomery form, not yet converted)
+template <int NL, int PH>
+__device__ __forceinline__ void leaf_load_raw(LeafRaw<NL, PH>& r, const LeafArgs& a, u64 col, int64_t row0) {
 #pragma unroll
-  for (int x = 0; x < NEL; x++) {
+  for (int x = 0; x < LeafRaw<NL, PH>::NEL; x++) {
     const int64_t row = row0 + x;
-    if (row >= 0 && (u64)row < a.n_rows_total) {
-      const u32* p = a.comm + ((u64)(row - a.row_base) * a.row_stride + col) * NL;
-      if constexpr (NL == 8) el[x] = fe_canon_r29(fe_load<NL>(p));
-      else el[x] = fe_canon<NL>(fe_load<NL>(p));
-    } else {
-      el[x] = fe_zero<NL>();
-    }
+    if (row >= 0 && (u64)row < a.n_rows_total) r.el[x] = fe_load<NL>(a.comm + ((u64)(row - a.row_base) * a.row_stride + col) * NL);
+    else r.el[x] = fe_zero<NL>();        // the 32-byte zero prefix (rows -1, -2, ..) and the tail past the message
+  }
+}
+// Montgomery -> canonical little-endian words (PrimeField::to_repr), laid out as the block's 16 message words
+template <int NL, int PH>
+__device__ __forceinline__ void leaf_build_block(u32 m[16], const LeafRaw<NL, PH>& r) {
+  Fe<NL> c[LeafRaw<NL, PH>::NEL];
+#pragma unroll
+  for (int x = 0; x < LeafRaw<NL, PH>::NEL; x++) {
+    if constexpr (NL == 8) c[x] = fe_canon_r29(r.el[x]);
+    else c[x] = fe_canon<NL>(r.el[x]);
   }
 #pragma unroll
-  for (int p = 0; p < 16; p++) m[p] = el[(PH + p) / NL].v[(PH + p) % NL];
+  for (int p = 0; p < 16; p++) m[p] = c[(PH + p) / NL].v[(PH + p) % NL];
+}
+template <int NL, int PH>
+__device__ __forceinline__ void leaf_fill_block(u32 m[16], const LeafArgs& a, u64 col, int64_t row0) {
+  LeafRaw<NL, PH> r;
+  leaf_load_raw<NL, PH>(r, a, col, row0);
+  leaf_build_block<NL, PH>(m, r);
 }
 
 template <int NL>
@@ -264,24 +278,43 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
   const u32 nblocks = (chunk_len + 63) / 64;
   u32 cv[8];
   b3_set_iv(cv);
-  for (u32 b = 0; b < nblocks; b++) {
-    // element-word offset of this block's first word; the 32-byte zero prefix is words -8..-1
+  // element-word offset of block b's first word is 16*(16*chunk + b) - 8 (the zero prefix is words -8..-1)
+  auto block_row0 = [&](u32 b, int& ph) -> int64_t {
     const int64_t s0 = ((int64_t)chunk * 16 + b) * 16 - 8;
-    int64_t row0 = s0 >= 0 ? s0 / NL : -((-s0 + NL - 1) / NL);
-    const int ph = (int)(s0 - row0 * NL);
-    u32 m[16];
-    if constexpr (NL == 6) {
+    const int64_t r0 = s0 >= 0 ? s0 / NL : -((-s0 + NL - 1) / NL);
+    ph = (int)(s0 - r0 * NL);
+    return r0;
+  };
+  if constexpr (NL != 6) {
+    // every block starts on an element boundary (PH == 0): software-pipeline the loads one block ahead
+    int ph;
+    LeafRaw<NL, 0> cur, nxt;
+    leaf_load_raw<NL, 0>(cur, a, col, block_row0(0, ph));
+    for (u32 b = 0; b < nblocks; b++) {
+      if (b + 1 < nblocks) leaf_load_raw<NL, 0>(nxt, a, col, block_row0(b + 1, ph));
+      u32 m[16];
+      leaf_build_block<NL, 0>(m, cur);
+      const u32 rem = chunk_len - 64 * b;
+      const u32 blen = rem < 64 ? rem : 64;
+      u32 flags = (b == 0 ? B3_CHUNK_START : 0u);
+      if (b == nblocks - 1) flags |= B3_CHUNK_END | (a.n_chunks_total == 1 ? B3_ROOT : 0u);
+      b3_compress(cv, m, chunk, blen, flags);
+      cur = nxt;
+    }
+  } else {
+    for (u32 b = 0; b < nblocks; b++) {
+      int ph;
+      const int64_t row0 = block_row0(b, ph);
+      u32 m[16];
       if (ph == 0) leaf_fill_block<NL, 0>(m, a, col, row0);
       else if (ph == 2) leaf_fill_block<NL, 2>(m, a, col, row0);
       else leaf_fill_block<NL, 4>(m, a, col, row0);
-    } else {
-      leaf_fill_block<NL, 0>(m, a, col, row0);
+      const u32 rem = chunk_len - 64 * b;
+      const u32 blen = rem < 64 ? rem : 64;
+      u32 flags = (b == 0 ? B3_CHUNK_START : 0u);
+      if (b == nblocks - 1) flags |= B3_CHUNK_END | (a.n_chunks_total == 1 ? B3_ROOT : 0u);
+      b3_compress(cv, m, chunk, blen, flags);
     }
-    const u32 rem = chunk_len - 64 * b;
-    const u32 blen = rem < 64 ? rem : 64;
-    u32 flags = (b == 0 ? B3_CHUNK_START : 0u);
-    if (b == nblocks - 1) flags |= B3_CHUNK_END | (a.n_chunks_total == 1 ? B3_ROOT : 0u);
-    b3_compress(cv, m, chunk, blen, flags);
   }
   u32* o = a.out + ((u64)blockIdx.y * a.n_cols + col) * 8;
   *reinterpret_cast<uint4*>(o) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
@@ -609,6 +642,168 @@ hipError_t launch_sdig_rs(int nl, const u32* in, u64 in_stride, u32 n_in, u32* m
     case 8: hipLaunchKernelGGL(sdig_rs_kernel<8>, grid, dim3(64), 0, st, in, in_stride, n_in, mat, stride, out_off, n_out, r2); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+
+// =================================================================================================
+// K2 (fast path): Brakedown on a position-major copy T[pos][row] of the commitment rows.
+// The expander matrix is the same for every row, so with lane = row the CSR entries (column index, value)
+// are wave-uniform (scalar loads / SGPR multiplier operands) and every gathered operand is one contiguous
+// n_rows * F byte run.  Two tiled transposes (in: message, out: whole codeword) bracket the level chain.
+// =================================================================================================
+template <int NL>
+__global__ void __launch_bounds__(256) transpose_to_t_kernel(const u32* src, u64 src_stride, u64 n_valid, u64 n_rows, u32* t) {
+  // tile: 32 positions x 32 rows; LDS holds it row-major with a one-element pad
+  __shared__ u32 tile[32 * 33 * NL];
+  const u64 p0 = (u64)blockIdx.x * 32, r0 = (u64)blockIdx.y * 32;
+  const u32 tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  for (u32 rr = ty; rr < 32; rr += 8) {
+    const u64 r = r0 + rr, p = p0 + tx;
+    if (r < n_rows && p < n_valid) {
+      const Fe<NL> v = fe_load<NL>(src + (r * src_stride + p) * NL);
+#pragma unroll
+      for (int w = 0; w < NL; w++) tile[(rr * 33 + tx) * NL + w] = v.v[w];
+    }
+  }
+  __syncthreads();
+  for (u32 pp = ty; pp < 32; pp += 8) {
+    const u64 p = p0 + pp, r = r0 + tx;
+    if (r < n_rows && p < n_valid) {
+      Fe<NL> v;
+#pragma unroll
+      for (int w = 0; w < NL; w++) v.v[w] = tile[(tx * 33 + pp) * NL + w];
+      fe_store<NL>(t + (p * n_rows + r) * NL, v);
+    }
+  }
+}
+template <int NL>
+__global__ void __launch_bounds__(256) transpose_from_t_kernel(const u32* t, u64 n_pos, u64 n_rows, u32* dst, u64 dst_stride) {
+  __shared__ u32 tile[32 * 33 * NL];
+  const u64 p0 = (u64)blockIdx.x * 32, r0 = (u64)blockIdx.y * 32;
+  const u32 tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (u32 pp = ty; pp < 32; pp += 8) {
+    const u64 p = p0 + pp, r = r0 + tx;
+    if (r < n_rows && p < n_pos) {
+      const Fe<NL> v = fe_load<NL>(t + (p * n_rows + r) * NL);
+#pragma unroll
+      for (int w = 0; w < NL; w++) tile[(pp * 33 + tx) * NL + w] = v.v[w];
+    }
+  }
+  __syncthreads();
+  for (u32 rr = ty; rr < 32; rr += 8) {
+    const u64 r = r0 + rr, p = p0 + tx;
+    if (r < n_rows && p < n_pos) {
+      Fe<NL> v;
+#pragma unroll
+      for (int w = 0; w < NL; w++) v.v[w] = tile[(tx * 33 + rr) * NL + w];
+      fe_store<NL>(dst + (r * dst_stride + p) * NL, v);
+    }
+  }
+}
+#define LCPC_DISPATCH_NL(nl, CALL)                 \
+  switch (nl) {                                    \
+    case 2: { constexpr int NLV = 2; CALL; } break; \
+    case 4: { constexpr int NLV = 4; CALL; } break; \
+    case 6: { constexpr int NLV = 6; CALL; } break; \
+    case 8: { constexpr int NLV = 8; CALL; } break; \
+    default: return hipErrorInvalidValue;          \
+  }
+hipError_t launch_transpose_to_t(int nl, const u32* src, u64 src_stride, u64 n_valid, u64 n_rows, u32* t, hipStream_t st) {
+  if (!n_valid || !n_rows) return hipSuccess;
+  dim3 grid((unsigned)((n_valid + 31) / 32), (unsigned)((n_rows + 31) / 32));
+  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(transpose_to_t_kernel<NLV>, grid, dim3(256), 0, st, src, src_stride, n_valid, n_rows, t));
+  return hipGetLastError();
+}
+hipError_t launch_transpose_from_t(int nl, const u32* t, u64 n_pos, u64 n_rows, u32* dst, u64 dst_stride, hipStream_t st) {
+  if (!n_pos || !n_rows) return hipSuccess;
+  dim3 grid((unsigned)((n_pos + 31) / 32), (unsigned)((n_rows + 31) / 32));
+  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(transpose_from_t_kernel<NLV>, grid, dim3(256), 0, st, t, n_pos, n_rows, dst, dst_stride));
+  return hipGetLastError();
+}
+
+constexpr int SPMM_OPW = 4;       // outputs per workgroup
+template <int NL>
+__global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a) {
+  const u64 row = (u64)blockIdx.y * 128 + threadIdx.x;
+  const bool live = row < a.n_rows;
+  const u64 rr = live ? row : 0;                     // dead lanes recompute row 0 and do not store
+  const u32* xin = a.t + (a.in_off * a.n_rows + rr) * NL;
+  const size_t pstride = (size_t)a.n_rows * NL;      // words between consecutive positions
+  for (u32 oo = 0; oo < SPMM_OPW; oo++) {
+    const u64 o = (u64)blockIdx.x * SPMM_OPW + oo;
+    if (o >= a.m) break;
+    const u32 k0 = __builtin_amdgcn_readfirstlane(a.rowptr[o]);
+    const u32 k1 = __builtin_amdgcn_readfirstlane(a.rowptr[o + 1]);
+    Fe<NL> res;
+    if constexpr (NL == 8) {
+      res = fe_zero<NL>();
+      for (u32 kb = k0; kb < k1; kb += 60) {         // <= 60 terms per Montgomery reduction (lazy29_reduce bound)
+        const u32 ke = kb + 60 < k1 ? kb + 60 : k1;
+        Lazy29 acc;
+        lazy29_zero(acc);
+        u32 since = 0;
+        u32 col = __builtin_amdgcn_readfirstlane(a.colidx[kb]);
+        Fe<NL> x = fe_load<NL>(xin + (size_t)col * pstride);
+        for (u32 k = kb; k < ke; k++) {
+          Fe<NL> xn = x;
+          if (k + 1 < ke) {                          // prefetch the next gathered operand
+            const u32 cn = __builtin_amdgcn_readfirstlane(a.colidx[k + 1]);
+            xn = fe_load<NL>(xin + (size_t)cn * pstride);
+          }
+          Fe29 v;
+#pragma unroll
+          for (int i = 0; i < 9; i++) v.v[i] = __builtin_amdgcn_readfirstlane(a.vals29[(size_t)k * 12 + i]);
+          lazy29_mac(acc, fe_to29(x), v);
+          if (++since == 6) { lazy29_normalize(acc); since = 0; }
+          x = xn;
+        }
+        res = fe_add<NL>(res, lazy29_reduce(acc));
+      }
+    } else {
+      res = fe_zero<NL>();
+      for (u32 kb = k0; kb < k1; kb += 8) {
+        Wide<NL> w = wide_zero<NL>();
+        const u32 ke = kb + 8 < k1 ? kb + 8 : k1;
+        for (u32 k = kb; k < ke; k++) {
+          const u32 col = __builtin_amdgcn_readfirstlane(a.colidx[k]);
+          const Fe<NL> v = fe_load<NL>(a.vals + (size_t)k * NL);
+          wide_mac<NL>(w, v, fe_load<NL>(xin + (size_t)col * pstride));
+        }
+        res = fe_add<NL>(res, wide_reduce<NL>(w));
+      }
+    }
+    if (live) {
+      u32* dst = a.out_alt ? a.out_alt + (o * a.n_rows + row) * NL : a.t + ((a.out_off + o) * a.n_rows + row) * NL;
+      fe_store<NL>(dst, res);
+    }
+  }
+}
+hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st) {
+  if (a.m == 0 || a.n_rows == 0) return hipSuccess;
+  dim3 grid((unsigned)((a.m + SPMM_OPW - 1) / SPMM_OPW), (unsigned)((a.n_rows + 127) / 128));
+  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(spmm_t_kernel<NLV>, grid, dim3(128), 0, st, a));
+  return hipGetLastError();
+}
+
+template <int NL>
+__global__ void __launch_bounds__(128) sdig_rs_t_kernel(const u32* in_t, u32 n_in, u32* t, u64 out_off, u32 n_out, u64 n_rows,
+                                                       const u32* r2) {
+  const u64 row = (u64)blockIdx.y * 128 + threadIdx.x;
+  if (row >= n_rows) return;
+  const u32 k = blockIdx.x;
+  Fe<NL> raw = fe_zero<NL>();
+  raw.v[0] = k + 1;
+  const Fe<NL> x = fe_mul<NL>(raw, fe_load<NL>(r2));          // (k+1) in Montgomery form
+  Fe<NL> r = fe_zero<NL>();
+  for (u32 j = n_in; j-- > 0;) r = fe_add<NL>(fe_mul<NL>(r, x), fe_load<NL>(in_t + ((u64)j * n_rows + row) * NL));
+  fe_store<NL>(t + ((out_off + k) * n_rows + row) * NL, r);
+}
+hipError_t launch_sdig_rs_t(int nl, const u32* in_t, u32 n_in, u32* t, u64 out_off, u32 n_out, u64 n_rows, const u32* r2,
+                            hipStream_t st) {
+  if (!n_out || !n_rows) return hipSuccess;
+  dim3 grid(n_out, (unsigned)((n_rows + 127) / 128));
+  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(sdig_rs_t_kernel<NLV>, grid, dim3(128), 0, st, in_t, n_in, t, out_off, n_out, n_rows, r2));
   return hipGetLastError();
 }
 

@@ -25,8 +25,24 @@ namespace {
 struct DevCsr {
   uint64_t n_in = 0, n_out = 0;
   uint32_t *rowptr = nullptr, *colidx = nullptr, *vals = nullptr;
+  uint32_t* vals29 = nullptr;     // Ft255: values in the 29-bit-limb / 2^261 form (lazy29_mac)
 };
 struct Pass { uint32_t t0, s, log_tj; int log_tile; };
+
+// Ft255 element in ff_derive's Montgomery form (a * 2^256) -> a * 2^261 mod p as 9 limbs of 29 bits, 12-word stride:
+// the multiplier format of fe_mul_r29 / lazy29_mac (field_dev.h)
+void to_r29(const FieldDesc& f, const uint64_t* in4, uint32_t* out12) {
+  uint64_t t[4];
+  memcpy(t, in4, 32);
+  for (int d = 0; d < 5; d++) h_add(f, t, t, t);
+  for (int k = 0; k < 9; k++) {
+    const int b = 29 * k, w = b / 64, sh = b % 64;
+    uint64_t x = t[w] >> sh;
+    if (sh > 35 && w + 1 < 4) x |= t[w + 1] << (64 - sh);
+    out12[k] = (uint32_t)(x & ((1u << 29) - 1));
+  }
+  out12[9] = out12[10] = out12[11] = 0;
+}
 
 const uint8_t LBL_DT[] = "$l//DT", LBL_PR[] = "$l//PR", LBL_PE[] = "$l//PE", LBL_CO[] = "$l//CO";  // macros.rs:31-34
 
@@ -55,6 +71,8 @@ struct lcpc_ctx {
   uint32_t* d_r2 = nullptr;
   uint32_t* d_tmp = nullptr;       // last precode output, n_rows x m_last
   uint64_t tmp_cap = 0;
+  uint32_t* d_t = nullptr;         // Brakedown: position-major working copy T[pos][row] of the rows being encoded
+  uint64_t t_cap = 0;
   // commitment (device resident)
   bool committed = false;
   uint64_t n_rows = 0;             // rows of the whole commitment
@@ -218,12 +236,66 @@ int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, ui
     return 0;
   }
   // Brakedown: systematic part, then precodes down, R-S base case, postcodes up (encode.rs:36-94)
-  if (n_rows > 65535) { c->err = "brakedown: more than 65535 rows per launch not supported"; return LCPC_ERR_TOO_BIG; }
+  const size_t t = c->d_pre.size();
+  const DevCsr& pl = c->d_pre[t - 1];
+  {
+    const uint64_t need = n_rows * pl.n_out;
+    if (need > c->tmp_cap) {
+      dev_free(c->d_tmp);
+      int rc = dev_alloc(c, &c->d_tmp, (size_t)need * elem_bytes(c));
+      if (rc) return rc;
+      c->tmp_cap = need;
+    }
+  }
+  if (n_rows >= 16) {
+    // fast path: position-major working copy T[pos][row] (lane = row: contiguous gathers, wave-uniform matrix)
+    const uint64_t need = n_rows * c->n_cols;
+    if (need > c->t_cap) {
+      dev_free(c->d_t);
+      int rc = dev_alloc(c, &c->d_t, (size_t)need * elem_bytes(c));
+      if (rc) return rc;
+      c->t_cap = need;
+    }
+    HIPCHK(c, launch_transpose_to_t(c->NL, src, src_stride, n_valid, n_rows, c->d_t, st));
+    c->launches[0]++;
+    uint64_t in_start = 0;
+    SpmmTArgs a{};
+    a.t = c->d_t; a.n_rows = n_rows;
+    auto set_mat = [&](const DevCsr& m) { a.rowptr = m.rowptr; a.colidx = m.colidx; a.vals = m.vals; a.vals29 = m.vals29; a.m = m.n_out; };
+    for (size_t i = 0; i + 1 < t; i++) {
+      const uint64_t in_end = in_start + c->d_pre[i].n_in;
+      a.out_alt = nullptr; a.in_off = in_start; a.out_off = in_end;
+      set_mat(c->d_pre[i]);
+      HIPCHK(c, launch_spmm_t(c->NL, a, st));
+      c->launches[0]++;
+      in_start = in_end;
+    }
+    const uint64_t in_end = in_start + pl.n_in;
+    a.out_alt = c->d_tmp; a.in_off = in_start; a.out_off = 0;
+    set_mat(pl);
+    HIPCHK(c, launch_spmm_t(c->NL, a, st));
+    const uint64_t out_end = in_end + c->d_post[t - 1].n_in;
+    HIPCHK(c, launch_sdig_rs_t(c->NL, c->d_tmp, (uint32_t)pl.n_out, c->d_t, in_end, (uint32_t)c->d_post[t - 1].n_in, n_rows, c->d_r2, st));
+    c->launches[0] += 2;
+    in_start = in_end + pl.n_out;
+    uint64_t out_start = out_end;
+    for (size_t ii = t; ii-- > 0;) {
+      in_start -= c->d_pre[ii].n_out;
+      a.out_alt = nullptr; a.in_off = in_start; a.out_off = out_start;
+      set_mat(c->d_post[ii]);
+      HIPCHK(c, launch_spmm_t(c->NL, a, st));
+      c->launches[0]++;
+      out_start += c->d_post[ii].n_out;
+    }
+    HIPCHK(c, launch_transpose_from_t(c->NL, c->d_t, c->n_cols, n_rows, dst, c->n_cols, st));
+    c->launches[0]++;
+    return 0;
+  }
+  // few rows (the verifier's 1 + n_degree_tests single-row encodes): lane = output on the row-major rows
   if (src != dst || src_stride != c->n_cols) {
     HIPCHK(c, launch_pad_rows(c->NL, src, src_stride, dst, c->n_cols, n_valid, n_rows, st));
     c->launches[0]++;
   }
-  const size_t t = c->d_pre.size();
   uint64_t in_start = 0;
   SpmvArgs a{};
   a.mat = dst; a.stride = c->n_cols; a.n_rows = n_rows;
@@ -235,7 +307,6 @@ int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, ui
     c->launches[0]++;
     in_start = in_end;
   }
-  const DevCsr& pl = c->d_pre[t - 1];
   const uint64_t in_end = in_start + pl.n_in;
   a.out_alt = c->d_tmp; a.out_alt_stride = pl.n_out; a.in_off = in_start; a.out_off = 0;
   a.rowptr = pl.rowptr; a.colidx = pl.colidx; a.vals = pl.vals; a.m = pl.n_out;
@@ -415,17 +486,7 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
       // w*R (R = 2^256) -> w*2^261 mod p (five doublings), split into 9 limbs of 29 bits, 12-word stride
       const size_t nroots = roots.size() / 4;
       std::vector<uint32_t> r29(nroots * 12, 0);
-      for (size_t i = 0; i < nroots; i++) {
-        uint64_t t[4];
-        memcpy(t, &roots[i * 4], 32);
-        for (int d = 0; d < 5; d++) h_add(*f, t, t, t);
-        for (int k = 0; k < 9; k++) {
-          const int b = 29 * k, w = b / 64, sh = b % 64;
-          uint64_t x = t[w] >> sh;
-          if (sh > 35 && w + 1 < 4) x |= t[w + 1] << (64 - sh);
-          r29[i * 12 + k] = (uint32_t)(x & ((1u << 29) - 1));
-        }
-      }
+      for (size_t i = 0; i < nroots; i++) to_r29(*f, &roots[i * 4], &r29[i * 12]);
       if ((rc = dev_alloc(c, &c->d_roots29, r29.size() * 4))) { lcpc_ctx_destroy(c); return rc; }
       if (hipMemcpy(c->d_roots29, r29.data(), r29.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
     }
@@ -450,6 +511,13 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
       HIPCHK(c, hipMemcpy(d.rowptr, m.rowptr.data(), m.rowptr.size() * 4, hipMemcpyHostToDevice));
       HIPCHK(c, hipMemcpy(d.colidx, m.colidx.data(), m.colidx.size() * 4, hipMemcpyHostToDevice));
       HIPCHK(c, hipMemcpy(d.vals, m.vals.data(), m.vals.size() * 8, hipMemcpyHostToDevice));
+      if (f->L == 4) {
+        const size_t nnz = m.colidx.size();
+        std::vector<uint32_t> v29(nnz * 12 + 12);
+        for (size_t k = 0; k < nnz; k++) to_r29(*f, &m.vals[k * 4], &v29[k * 12]);
+        if ((r = dev_alloc(c, &d.vals29, v29.size() * 4))) return r;
+        HIPCHK(c, hipMemcpy(d.vals29, v29.data(), v29.size() * 4, hipMemcpyHostToDevice));
+      }
       return 0;
     };
     c->d_pre.resize(pre.size());
@@ -473,9 +541,9 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
 void lcpc_ctx_destroy(lcpc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->prm.device);
-  dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_r2); dev_free(c->d_tmp);
+  dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_r2); dev_free(c->d_tmp); dev_free(c->d_t);
   for (auto* v : {&c->d_pre, &c->d_post})
-    for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); }
+    for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); dev_free(d.vals29); }
   dev_free(c->d_coeffs); dev_free(c->d_comm); dev_free(c->d_hashes); dev_free(c->d_cvs); dev_free(c->d_scratch);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   delete c;

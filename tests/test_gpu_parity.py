@@ -328,3 +328,22 @@ def test_commit_device_ragged(oracle, kind, fid, n, rho):
     assert (c.comm() == oc.comm()).all() and (c.coeffs() == oc.coeffs()).all() and (c.hashes() == oc.hashes()).all()
     t = O.random_elems(fid, c.n_rows, 31)
     assert (c.eval_outer(t) == oc.collapse(t)).all()
+
+
+@pytest.mark.parametrize("fid,n_per_row,n_rows,seed,code", [(3, 300, 40, 1, 3), (3, 257, 130, 2, 3), (0, 500, 17, 3, 5),
+                                                            (1, 400, 33, 4, 1), (2, 350, 129, 5, 6), (3, 2000, 70, 6, 2)])
+def test_brakedown_many_rows_vs_oracle(oracle, fid, n_per_row, n_rows, seed, code):
+    """>= 16 rows selects the position-major SpMM path (lane = row, wave-uniform matrix entries, R29 lazy dot
+    products for Ft255 / wide accumulators otherwise): every field, row counts that are not multiples of the
+    128-lane row block or of the 32x32 transpose tile, a ragged last row."""
+    O = oracle
+    oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, seed, code)
+    _, _, n_cols = oenc.get_dims(n_per_row)
+    n = n_per_row * n_rows - 7
+    coeffs = O.random_elems(fid, n, 37)
+    enc = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, seed, code)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+    assert c.n_rows == n_rows == oc.n_rows
+    assert (c.comm() == oc.comm()).all()
+    assert (c.hashes() == oc.hashes()).all() and c.get_root() == oc.get_root()
