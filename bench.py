@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-len", type=int, default=24)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (debug: ranks may share a GPU)")
+    ap.add_argument("--force-device", type=int, default=None, help="debug: every rank uses this HIP device")
+    ap.add_argument("--check", action="store_true", help="debug: compare the sharded root with an unsharded commit of the same data")
     args = ap.parse_args()
 
     import torch
@@ -77,12 +80,17 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the lcpc HIP path has no CPU fallback")
+    if args.force_device is not None:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     fid, L, F = lcpc_amd.FT255, 4, 32
     n_total = 1 << args.log_len
@@ -114,6 +122,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.check and distributed:
+        # every rank regenerates the whole coefficient matrix (rank r's rows come from seed 1234 + r) and compares
+        # the sharded root with a plain single-context commit
+        root_sharded = step(sync=True)
+        parts = []
+        for r in range(world):
+            e_r = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=local_rank, shard=(r, world))
+            rb_r, re_r, _, _, _ = HipShardEngine(e_r).layout(n_rows_total)
+            parts.append(device_random_coeffs(torch, max(re_r - rb_r, 1) * n_per_row, L, 1234 + r, dev)[:(re_r - rb_r) * n_per_row])
+            del e_r
+        full = torch.cat(parts, dim=0).contiguous()
+        ref = LcCommit.commit_device(full.data_ptr(), n_coeffs_job, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=local_rank),
+                                     torch.cuda.current_stream().cuda_stream)
+        ok = ref.get_root() == root_sharded
+        print("[rank %d] sharded root %s unsharded root: %s" % (rank, "==" if ok else "!=", root_sharded.hex()), file=sys.stderr)
+        if not ok:
+            raise SystemExit("sharded commit root mismatch")
+        del full, parts, ref
+
     for _ in range(args.warmup):
         step()
     fence()
@@ -143,7 +170,7 @@ def main():
     achieved = (enc_bytes / ntt_launches) / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
     traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_latest.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and world == 1 and args.log_len == 26:
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
         pmc = json.load(open(pmc_path))
         for kname, v in pmc["kernels"].items():

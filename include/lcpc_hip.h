@@ -160,13 +160,19 @@ void lcpc_free(void *p);
  * commitment of n_rows_total rows; n_chunks_total = BLAKE3 chunks per leaf message. */
 int  lcpc_shard_layout(const lcpc_ctx *ctx, uint64_t n_rows_total, uint64_t *row_begin, uint64_t *row_end,
                        uint64_t *chunk_begin, uint64_t *chunk_end, uint64_t *n_chunks_total);
-/* phase 1: encode the local rows (coeffs_dev = local rows only, row-major) and reduce them to one
- * BLAKE3 chaining value per (local chunk, column): cvs_dev[(chunk - chunk_begin) * n_cols + col][32 B]. */
+/* The chunks of a shard are pre-merged on the GPU into aligned BLAKE3 subtree nodes (a node = 2^log_size
+ * consecutive chunks starting at a multiple of its size), which is what crosses the wire.  Pure function of
+ * (n_chunks_total, shard_count, shard_rank): node k of that shard starts at chunk first_chunk[k]. */
+int  lcpc_shard_nodes(uint64_t n_chunks_total, uint32_t shard_count, uint32_t shard_rank, uint32_t *n_nodes,
+                      uint64_t *first_chunk /* [64] */, uint32_t *log_size /* [64] */);
+/* phase 1: encode the local rows (coeffs_dev = local rows only, row-major, padded) and reduce them to one
+ * BLAKE3 chaining value per (local node, column): nodes_dev[k * n_cols + col][32 B], k < n_nodes. */
 int  lcpc_commit_shard_device(lcpc_ctx *ctx, const uint64_t *coeffs_local_dev, uint64_t n_rows_total,
-                              void *stream, uint8_t *cvs_dev);
-/* phase 2 (after the all-gather): all_cvs_dev[chunk * n_cols + col][32 B] for every chunk -> leaf
- * digests, Merkle tree, root. */
-int  lcpc_commit_finish_device(lcpc_ctx *ctx, const uint8_t *all_cvs_dev, uint64_t n_rows_total,
+                              void *stream, uint8_t *nodes_dev);
+/* phase 2 (after the all-gather): gathered_dev is the raw all-gather output, rank g's nodes at
+ * [(g * slots_per_rank + k) * n_cols + col][32 B] (slots_per_rank >= max nodes per rank; unused slots ignored)
+ * -> leaf digests, Merkle tree, root.  The buffer is clobbered. */
+int  lcpc_commit_finish_device(lcpc_ctx *ctx, uint8_t *gathered_dev, uint64_t n_rows_total, uint32_t slots_per_rank,
                                void *stream, uint8_t *root);
 /* collapse on the local rows only (tensor entries for the local rows); partial results are summed
  * mod p by lcpc_field_sum_device after an all-gather. */

@@ -58,8 +58,9 @@ SYMBOLS = {
     "lcpc_root_bincode": (None, [_vp, _vp]),
     "lcpc_free": (None, [_vp]),
     "lcpc_shard_layout": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "lcpc_shard_nodes": (_i32, [_u64, _u32, _u32, _vp, _vp, _vp]),
     "lcpc_commit_shard_device": (_i32, [_vp, _vp, _u64, _vp, _vp]),
-    "lcpc_commit_finish_device": (_i32, [_vp, _vp, _u64, _vp, _vp]),
+    "lcpc_commit_finish_device": (_i32, [_vp, _vp, _u64, _u32, _vp, _vp]),
     "lcpc_collapse_device": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "lcpc_field_sum_device": (_i32, [_vp, _vp, _u32, _u64, _vp, _vp]),
     "lcpc_set_timing": (_i32, [_vp, _i32]),

@@ -14,21 +14,31 @@ void keccak_f1600(uint64_t a[25]) {
       0x0000000080008009ull, 0x000000008000000Aull, 0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull,
       0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
       0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-  // rho offsets indexed by x + 5y, pi destination computed on the fly
-  static const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  // lane (x, y) lives at a[x + 5y]; rho offsets and pi destinations written out so the compiler keeps all 25
+  // lanes in registers
+  uint64_t a00 = a[0], a10 = a[1], a20 = a[2], a30 = a[3], a40 = a[4], a01 = a[5], a11 = a[6], a21 = a[7], a31 = a[8], a41 = a[9],
+           a02 = a[10], a12 = a[11], a22 = a[12], a32 = a[13], a42 = a[14], a03 = a[15], a13 = a[16], a23 = a[17], a33 = a[18],
+           a43 = a[19], a04 = a[20], a14 = a[21], a24 = a[22], a34 = a[23], a44 = a[24];
   for (int round = 0; round < 24; round++) {
-    uint64_t c[5], b[25];
-    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
-    for (int x = 0; x < 5; x++) {
-      const uint64_t d = c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
-      for (int y = 0; y < 25; y += 5) a[x + y] ^= d;
-    }
-    for (int x = 0; x < 5; x++)
-      for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(a[x + 5 * y], RHO[x + 5 * y]);
-    for (int y = 0; y < 25; y += 5)
-      for (int x = 0; x < 5; x++) a[x + y] = b[x + y] ^ (~b[(x + 1) % 5 + y] & b[(x + 2) % 5 + y]);
-    a[0] ^= RC[round];
+    const uint64_t c0 = a00 ^ a01 ^ a02 ^ a03 ^ a04, c1 = a10 ^ a11 ^ a12 ^ a13 ^ a14, c2 = a20 ^ a21 ^ a22 ^ a23 ^ a24,
+                   c3 = a30 ^ a31 ^ a32 ^ a33 ^ a34, c4 = a40 ^ a41 ^ a42 ^ a43 ^ a44;
+    const uint64_t d0 = c4 ^ rol64(c1, 1), d1 = c0 ^ rol64(c2, 1), d2 = c1 ^ rol64(c3, 1), d3 = c2 ^ rol64(c4, 1), d4 = c3 ^ rol64(c0, 1);
+    // theta + rho + pi: b[y][2x+3y] = rol(a[x][y] ^ d[x], rho[x][y])
+    const uint64_t b00 = a00 ^ d0, b13 = rol64(a01 ^ d0, 36), b21 = rol64(a02 ^ d0, 3), b34 = rol64(a03 ^ d0, 41), b42 = rol64(a04 ^ d0, 18);
+    const uint64_t b02 = rol64(a10 ^ d1, 1), b10 = rol64(a11 ^ d1, 44), b23 = rol64(a12 ^ d1, 10), b31 = rol64(a13 ^ d1, 45), b44 = rol64(a14 ^ d1, 2);
+    const uint64_t b04 = rol64(a20 ^ d2, 62), b12 = rol64(a21 ^ d2, 6), b20 = rol64(a22 ^ d2, 43), b33 = rol64(a23 ^ d2, 15), b41 = rol64(a24 ^ d2, 61);
+    const uint64_t b01 = rol64(a30 ^ d3, 28), b14 = rol64(a31 ^ d3, 55), b22 = rol64(a32 ^ d3, 25), b30 = rol64(a33 ^ d3, 21), b43 = rol64(a34 ^ d3, 56);
+    const uint64_t b03 = rol64(a40 ^ d4, 27), b11 = rol64(a41 ^ d4, 20), b24 = rol64(a42 ^ d4, 39), b32 = rol64(a43 ^ d4, 8), b40 = rol64(a44 ^ d4, 14);
+    // chi (bXY = lane x of row y), iota
+    a00 = b00 ^ (~b10 & b20) ^ RC[round]; a10 = b10 ^ (~b20 & b30); a20 = b20 ^ (~b30 & b40); a30 = b30 ^ (~b40 & b00); a40 = b40 ^ (~b00 & b10);
+    a01 = b01 ^ (~b11 & b21); a11 = b11 ^ (~b21 & b31); a21 = b21 ^ (~b31 & b41); a31 = b31 ^ (~b41 & b01); a41 = b41 ^ (~b01 & b11);
+    a02 = b02 ^ (~b12 & b22); a12 = b12 ^ (~b22 & b32); a22 = b22 ^ (~b32 & b42); a32 = b32 ^ (~b42 & b02); a42 = b42 ^ (~b02 & b12);
+    a03 = b03 ^ (~b13 & b23); a13 = b13 ^ (~b23 & b33); a23 = b23 ^ (~b33 & b43); a33 = b33 ^ (~b43 & b03); a43 = b43 ^ (~b03 & b13);
+    a04 = b04 ^ (~b14 & b24); a14 = b14 ^ (~b24 & b34); a24 = b24 ^ (~b34 & b44); a34 = b34 ^ (~b44 & b04); a44 = b44 ^ (~b04 & b14);
   }
+  a[0] = a00; a[1] = a10; a[2] = a20; a[3] = a30; a[4] = a40; a[5] = a01; a[6] = a11; a[7] = a21; a[8] = a31; a[9] = a41;
+  a[10] = a02; a[11] = a12; a[12] = a22; a[13] = a32; a[14] = a42; a[15] = a03; a[16] = a13; a[17] = a23; a[18] = a33; a[19] = a43;
+  a[20] = a04; a[21] = a14; a[22] = a24; a[23] = a34; a[24] = a44;
 }
 
 enum { SF_I = 1, SF_A = 2, SF_C = 4, SF_T = 8, SF_M = 16, SF_K = 32 };
@@ -51,8 +61,16 @@ void Transcript::run_f() {
   pos_begin_ = 0;
 }
 void Transcript::absorb(const uint8_t* d, size_t n) {
-  for (size_t i = 0; i < n; i++) {
-    st_.b[pos_++] ^= d[i];
+  // prove/verify absorb ~50 bytes per coefficient, n_per_row times in a row (lcpc-2d lib.rs:1045-1047): XOR in
+  // runs up to the rate boundary instead of byte-at-a-time
+  while (n > 0) {
+    size_t take = (size_t)(R - pos_);
+    if (take > n) take = n;
+    uint8_t* dst = st_.b + pos_;
+    for (size_t i = 0; i < take; i++) dst[i] ^= d[i];
+    pos_ = (uint8_t)(pos_ + take);
+    d += take;
+    n -= take;
     if (pos_ == R) run_f();
   }
 }

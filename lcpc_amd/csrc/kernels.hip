@@ -342,42 +342,57 @@ __device__ __forceinline__ void st8(u32* p, const u32 d[8]) {
   *reinterpret_cast<uint4*>(p + 4) = make_uint4(d[4], d[5], d[6], d[7]);
 }
 
-// BLAKE3 tree over the n chunk CVs of each column (left subtree = largest power of two < n): the
-// incremental stack algorithm, with the (wave-uniform) stack kept in the CV buffer itself.
-__global__ void __launch_bounds__(256) leaf_finish_kernel(u32* cvs, u32 n_chunks, u64 n_cols, u32* digests) {
+// BLAKE3 tree over the subtree CVs ("nodes") of each column.  Node j covers 2^node_log[j] consecutive chunks
+// starting at a multiple of its size (aligned power-of-two chunk groups are subtrees of the BLAKE3 tree); its CV
+// lives at cvs[node_slot[j]][col].  The incremental stack algorithm, generalised to aligned subtrees: after
+// adding a node of 2^l chunks, merge while bit l, l+1, ... of the running chunk count is clear.  The
+// (wave-uniform) stack is kept in the slots of already-consumed nodes.  root_flag = B3_ROOT for a whole leaf
+// message, 0 when this call only pre-merges a rank's chunk range into one subtree CV (row-sharded commit).
+__global__ void __launch_bounds__(256) leaf_finish_kernel(u32* cvs, const u32* node_slot, const u32* node_log, u32 n_nodes,
+                                                         u64 n_cols, u32* out, u32 root_flag) {
   const u64 col = (u64)blockIdx.x * 256 + threadIdx.x;
   if (col >= n_cols) return;
+  auto slot = [&](u32 j) -> u64 { return node_slot ? node_slot[j] : j; };
   u32 cv[8], left[8];
   u32 len = 0;
-  for (u32 c = 0; c < n_chunks; c++) {
-    ld8(cv, cvs + ((u64)c * n_cols + col) * 8);
-    if (c == n_chunks - 1) break;
-    u32 total = c + 1;
-    while ((total & 1) == 0) {
+  u64 total = 0;
+  for (u32 j = 0; j < n_nodes; j++) {
+    ld8(cv, cvs + (slot(j) * n_cols + col) * 8);
+    if (j == n_nodes - 1) break;
+    const u32 l = node_log ? node_log[j] : 0;
+    total += (u64)1 << l;
+    u64 t = total >> l;
+    while ((t & 1) == 0) {
       --len;
-      ld8(left, cvs + ((u64)len * n_cols + col) * 8);
-      u32 out[8];
-      b3_hash64(out, left, cv, B3_PARENT);
+      ld8(left, cvs + (slot(len) * n_cols + col) * 8);
+      u32 o[8];
+      b3_hash64(o, left, cv, B3_PARENT);
 #pragma unroll
-      for (int i = 0; i < 8; i++) cv[i] = out[i];
-      total >>= 1;
+      for (int i = 0; i < 8; i++) cv[i] = o[i];
+      t >>= 1;
     }
-    st8(cvs + ((u64)len * n_cols + col) * 8, cv);
+    st8(cvs + (slot(len) * n_cols + col) * 8, cv);
     ++len;
   }
   while (len > 0) {
     --len;
-    ld8(left, cvs + ((u64)len * n_cols + col) * 8);
-    u32 out[8];
-    b3_hash64(out, left, cv, B3_PARENT | (len == 0 ? B3_ROOT : 0u));
+    ld8(left, cvs + (slot(len) * n_cols + col) * 8);
+    u32 o[8];
+    b3_hash64(o, left, cv, B3_PARENT | (len == 0 ? root_flag : 0u));
 #pragma unroll
-    for (int i = 0; i < 8; i++) cv[i] = out[i];
+    for (int i = 0; i < 8; i++) cv[i] = o[i];
   }
-  st8(digests + col * 8, cv);
+  st8(out + col * 8, cv);
 }
 hipError_t launch_leaf_finish(u32* cvs, u32 n_chunks, u64 n_cols, u32* digests, hipStream_t st) {
-  hipLaunchKernelGGL(leaf_finish_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, cvs, n_chunks, n_cols,
-                     digests);
+  hipLaunchKernelGGL(leaf_finish_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, cvs, (const u32*)nullptr,
+                     (const u32*)nullptr, n_chunks, n_cols, digests, (u32)B3_ROOT);
+  return hipGetLastError();
+}
+hipError_t launch_leaf_finish_nodes(u32* cvs, const u32* node_slot, const u32* node_log, u32 n_nodes, u64 n_cols, u32* out,
+                                    bool root, hipStream_t st) {
+  hipLaunchKernelGGL(leaf_finish_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, cvs, node_slot, node_log, n_nodes,
+                     n_cols, out, root ? (u32)B3_ROOT : 0u);
   return hipGetLastError();
 }
 

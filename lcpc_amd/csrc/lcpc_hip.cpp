@@ -79,6 +79,8 @@ struct lcpc_ctx {
   uint64_t row_begin = 0, n_rows_local = 0;
   uint64_t chunk_begin = 0, chunk_end = 0, n_chunks = 0;
   uint32_t *d_coeffs = nullptr, *d_comm = nullptr, *d_hashes = nullptr, *d_cvs = nullptr;
+  uint32_t* d_node_tab = nullptr;  // sharded finish: node_slot[0..n) then node_log[0..n)
+  uint64_t node_tab_key = 0;       // (n_chunks << 16 | slots_per_rank) the table was built for
   uint64_t cap_rows = 0, cap_cvs = 0;
   // scratch for prove / collapse / open
   uint32_t* d_scratch = nullptr;
@@ -208,6 +210,18 @@ void shard_layout(const lcpc_ctx* c, uint64_t n_rows, uint64_t* rb, uint64_t* re
   *rb = first_row(c0);
   *re = c1 >= n_chunks ? n_rows : first_row(c1);
   if (c0 == c1) *re = *rb;
+}
+
+// aligned power-of-two decomposition of the chunk range [c0, c1): the subtree nodes a shard exchanges
+int shard_nodes(uint64_t c0, uint64_t c1, uint64_t* first, uint32_t* lg) {
+  int n = 0;
+  for (uint64_t pos = c0; pos < c1;) {
+    uint32_t l = 0;
+    while ((pos == 0 || (pos & (((uint64_t)2 << l) - 1)) == 0) && pos + ((uint64_t)2 << l) <= c1) l++;
+    first[n] = pos; lg[n] = l; n++;
+    pos += (uint64_t)1 << l;
+  }
+  return n;
 }
 
 // ---- encode all local rows: coeffs -> comm ----------------------------------------------------------
@@ -544,7 +558,7 @@ void lcpc_ctx_destroy(lcpc_ctx* c) {
   dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_r2); dev_free(c->d_tmp); dev_free(c->d_t);
   for (auto* v : {&c->d_pre, &c->d_post})
     for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); dev_free(d.vals29); }
-  dev_free(c->d_coeffs); dev_free(c->d_comm); dev_free(c->d_hashes); dev_free(c->d_cvs); dev_free(c->d_scratch);
+  dev_free(c->d_coeffs); dev_free(c->d_comm); dev_free(c->d_hashes); dev_free(c->d_cvs); dev_free(c->d_scratch); dev_free(c->d_node_tab);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   delete c;
 }
@@ -1045,8 +1059,16 @@ int lcpc_shard_layout(const lcpc_ctx* c, uint64_t n_rows_total, uint64_t* rb, ui
   return 0;
 }
 
-int lcpc_commit_shard_device(lcpc_ctx* c, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint8_t* cvs_dev) {
-  if (!c || n_rows_total == 0 || !cvs_dev) return LCPC_ERR_ARG;
+int lcpc_shard_nodes(uint64_t n_chunks, uint32_t G, uint32_t g, uint32_t* n_nodes, uint64_t* first, uint32_t* lg) {
+  if (!n_nodes || !first || !lg || n_chunks == 0) return LCPC_ERR_ARG;
+  if (G <= 1) { G = 1; g = 0; }
+  if (g >= G) return LCPC_ERR_ARG;
+  *n_nodes = (uint32_t)shard_nodes(n_chunks * g / G, n_chunks * (g + 1) / G, first, lg);
+  return 0;
+}
+
+int lcpc_commit_shard_device(lcpc_ctx* c, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint8_t* nodes_dev) {
+  if (!c || n_rows_total == 0 || !nodes_dev) return LCPC_ERR_ARG;
   std::lock_guard<std::mutex> g(c->mu);
   HIPCHK(c, hipSetDevice(c->prm.device));
   hipStream_t st = (hipStream_t)stream;
@@ -1060,36 +1082,80 @@ int lcpc_commit_shard_device(lcpc_ctx* c, const uint64_t* coeffs_local, uint64_t
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
   if (c->n_rows_local) {
     if (!coeffs_local) return LCPC_ERR_ARG;
-    HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs_local, (size_t)c->n_rows_local * c->n_per_row * elem_bytes(c), hipMemcpyDeviceToDevice, st));
-    if ((rc = encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st))) return rc;
+    if (c->prm.encoding == LCPC_ENC_LIGERO) {
+      rc = encode_rows_device(c, reinterpret_cast<const uint32_t*>(coeffs_local), c->n_per_row, c->n_per_row, c->d_comm,
+                              c->n_rows_local, st, ~(uint64_t)0, c->d_coeffs);        // coeffs copy fused into pass 1
+    } else {
+      HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs_local, (size_t)c->n_rows_local * c->n_per_row * elem_bytes(c), hipMemcpyDeviceToDevice, st));
+      rc = encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st);
+    }
+    if (rc) return rc;
   }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], st));
   if (ce > cb) {
+    uint64_t first[64];
+    uint32_t lg[64];
+    const int n_nodes = shard_nodes(cb, ce, first, lg);
+    bool all_single = true;
+    for (int k = 0; k < n_nodes; k++) all_single = all_single && lg[k] == 0;
     LeafArgs la{};
     la.comm = c->d_comm; la.row_stride = c->n_cols; la.n_cols = c->n_cols; la.row_base = (int64_t)rb;
     la.n_rows_total = n_rows_total; la.chunk_begin = (uint32_t)cb; la.n_chunks_local = (uint32_t)(ce - cb);
     la.n_chunks_total = (uint32_t)nch;
-    la.out = reinterpret_cast<uint32_t*>(cvs_dev);
-    HIPCHK(c, launch_leaf_chunks(c->NL, la, st));
-    c->launches[1]++;
+    if (all_single) {                       // nothing to pre-merge: chunk CVs are the nodes
+      la.out = reinterpret_cast<uint32_t*>(nodes_dev);
+      HIPCHK(c, launch_leaf_chunks(c->NL, la, st));
+      c->launches[1]++;
+    } else {
+      if ((rc = ensure_cvs(c, ce - cb))) return rc;
+      la.out = c->d_cvs;
+      HIPCHK(c, launch_leaf_chunks(c->NL, la, st));
+      c->launches[1]++;
+      for (int k = 0; k < n_nodes; k++) {   // one subtree CV per aligned block of chunks
+        uint32_t* blk = c->d_cvs + (first[k] - cb) * c->n_cols * 8;
+        uint32_t* out = reinterpret_cast<uint32_t*>(nodes_dev) + (size_t)k * c->n_cols * 8;
+        HIPCHK(c, launch_leaf_finish_nodes(blk, nullptr, nullptr, 1u << lg[k], c->n_cols, out, false, st));
+        c->launches[1]++;
+      }
+    }
   }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], st));
   return 0;
 }
 
-int lcpc_commit_finish_device(lcpc_ctx* c, const uint8_t* all_cvs, uint64_t n_rows_total, void* stream, uint8_t* root) {
-  if (!c || !all_cvs || n_rows_total != c->n_rows) return LCPC_ERR_ARG;
+int lcpc_commit_finish_device(lcpc_ctx* c, uint8_t* gathered, uint64_t n_rows_total, uint32_t slots_per_rank, void* stream, uint8_t* root) {
+  if (!c || !gathered || n_rows_total != c->n_rows || slots_per_rank == 0) return LCPC_ERR_ARG;
   std::lock_guard<std::mutex> g(c->mu);
   HIPCHK(c, hipSetDevice(c->prm.device));
   hipStream_t st = (hipStream_t)stream;
   const uint64_t nch = leaf_chunks(c, n_rows_total);
-  if (nch == 1) {
-    HIPCHK(c, hipMemcpyAsync(c->d_hashes, all_cvs, (size_t)c->n_cols * 32, hipMemcpyDeviceToDevice, st));
-  } else {
-    int rc = ensure_cvs(c, nch);
+  const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
+  // node table over all ranks, in chunk order: slot in the gathered buffer + log2(size)
+  std::vector<uint32_t> tab_slot, tab_log;
+  for (uint32_t r = 0; r < G; r++) {
+    uint64_t first[64];
+    uint32_t lg[64];
+    const int n = shard_nodes(nch * r / G, nch * (r + 1) / G, first, lg);
+    if ((uint32_t)n > slots_per_rank) return LCPC_ERR_ARG;
+    for (int k = 0; k < n; k++) { tab_slot.push_back(r * slots_per_rank + (uint32_t)k); tab_log.push_back(lg[k]); }
+  }
+  const uint32_t n_nodes = (uint32_t)tab_slot.size();
+  const uint64_t key = (nch << 24) ^ ((uint64_t)slots_per_rank << 8) ^ G;
+  if (!c->d_node_tab || c->node_tab_key != key) {
+    dev_free(c->d_node_tab);
+    c->d_node_tab = nullptr;
+    int rc = dev_alloc(c, &c->d_node_tab, (size_t)n_nodes * 8);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_cvs, all_cvs, (size_t)nch * c->n_cols * 32, hipMemcpyDeviceToDevice, st));
-    HIPCHK(c, launch_leaf_finish(c->d_cvs, (uint32_t)nch, c->n_cols, c->d_hashes, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_node_tab, tab_slot.data(), n_nodes * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_node_tab + n_nodes, tab_log.data(), n_nodes * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));      // tab_* are stack temporaries
+    c->node_tab_key = key;
+  }
+  if (nch == 1) {   // single-chunk message: the one "node" already carries ROOT (leaf_chunk_kernel)
+    HIPCHK(c, hipMemcpyAsync(c->d_hashes, gathered + (size_t)tab_slot[0] * c->n_cols * 32, (size_t)c->n_cols * 32, hipMemcpyDeviceToDevice, st));
+  } else {
+    HIPCHK(c, launch_leaf_finish_nodes(reinterpret_cast<uint32_t*>(gathered), c->d_node_tab, c->d_node_tab + n_nodes, n_nodes, c->n_cols,
+                                       c->d_hashes, true, st));
     c->launches[1]++;
   }
   if (c->np2 > c->n_cols)

@@ -3,16 +3,19 @@ RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 The commitment matrix is split by rows into blocks aligned to the 1 KiB BLAKE3 chunk boundaries of the leaf
 message `0^32 || col[0] || col[1] || ...` (lcpc-2d/src/lib.rs:719-735), so each rank can encode its rows and
-reduce them to ONE 32-byte chaining value per (chunk, column) with no communication.  The single exchange step
-of the path is an all-gather of those chaining values (n_cols x 32 B per chunk); every rank then folds the
-chunk CVs into leaf digests and builds the Merkle tree redundantly (it is ~1% of the work).  No other
-collective exists on the commit path.
+reduce them to chunk chaining values with no communication.  Before anything crosses the wire a rank merges
+its chunk range into *aligned subtree nodes* (2^l consecutive chunks starting at a multiple of 2^l are a
+subtree of the BLAKE3 tree), so it sends 1-2 CVs per column instead of one per chunk.  The single exchange
+step of the path is ONE all-gather of those node CVs (n_cols x 32 B per node, equal-sized padded blocks);
+every rank then folds the nodes into leaf digests straight out of the gather buffer (node table, no
+re-packing copy) and builds the Merkle tree redundantly (~1 % of the work).  No other collective exists on the
+commit path.
 
-The compute is delegated to an `engine` with three methods, so that the exchange/assembly logic here can be
-exercised on CPU (gloo, world_size 2) with a stand-in engine from the tests while the product engine is HIP:
+The compute is delegated to an `engine`, so that the exchange logic here can be exercised on CPU (gloo,
+world_size 2/3) with a stand-in engine from the tests while the product engine is HIP:
     layout(n_rows_total) -> (row_begin, row_end, chunk_begin, chunk_end, n_chunks_total)
-    commit_shard(local_coeffs, n_rows_total) -> torch.uint8 tensor [(chunk_end-chunk_begin), n_cols, 32]
-    commit_finish(all_cvs [n_chunks_total, n_cols, 32], n_rows_total) -> 32-byte root
+    commit_shard(local_coeffs, n_rows_total) -> uint8 tensor [n_nodes_of_this_rank, n_cols, 32]
+    commit_finish(gathered [world * slots, n_cols, 32], n_rows_total, slots) -> 32-byte root
 """
 import ctypes as C
 
@@ -27,21 +30,43 @@ def chunk_split(n_chunks, world):
     return [(n_chunks * g // world, n_chunks * (g + 1) // world) for g in range(world)]
 
 
-def exchange_chunk_cvs(local_cvs, n_chunks_total, group=None):
-    """all-gather of per-rank [k_g, n_cols, 32] uint8 tensors (k_g differs by at most one between ranks)
-    into the full [n_chunks_total, n_cols, 32] tensor, identical on every rank."""
+def aligned_nodes(c0, c1):
+    """[c0, c1) as maximal aligned power-of-two blocks [(first_chunk, log2 size)] -- must match shard_nodes()
+    in csrc/lcpc_hip.cpp (checked against lcpc_shard_nodes by tests/test_abi.py)."""
+    out, pos = [], c0
+    while pos < c1:
+        l = 0
+        while (pos == 0 or pos % (2 << l) == 0) and pos + (2 << l) <= c1:
+            l += 1
+        out.append((pos, l))
+        pos += 1 << l
+    return out
+
+
+def slots_per_rank(n_chunks, world):
+    return max(1, max(len(aligned_nodes(b, e)) for b, e in chunk_split(n_chunks, world)))
+
+
+def exchange_nodes(local_nodes, n_chunks_total, group=None):
+    """all-gather of per-rank [k_g, n_cols, 32] uint8 node CVs, padded to `slots` per rank; returns the raw
+    gather buffer [world * slots, n_cols, 32] (rank g's nodes at rows g*slots ...) and `slots`."""
     world = dist.get_world_size(group)
-    split = chunk_split(n_chunks_total, world)
-    kmax = max(e - b for b, e in split)
-    n_cols = local_cvs.shape[1]
-    pad = torch.zeros((kmax, n_cols, 32), dtype=torch.uint8, device=local_cvs.device)
-    pad[:local_cvs.shape[0]] = local_cvs
-    flat = torch.empty((world * kmax, n_cols, 32), dtype=torch.uint8, device=local_cvs.device)
-    dist.all_gather_into_tensor(flat, pad, group=group)      # rank g's block lands at rows [g*kmax, (g+1)*kmax)
-    if all(e - b == kmax for b, e in split):
-        return flat
-    out = flat.view(world, kmax, n_cols, 32)
-    return torch.cat([out[g, :e - b] for g, (b, e) in enumerate(split)], dim=0)
+    slots = slots_per_rank(n_chunks_total, world)
+    n_cols = local_nodes.shape[1]
+    if local_nodes.shape[0] == slots:
+        pad = local_nodes.contiguous()
+    else:
+        pad = torch.zeros((slots, n_cols, 32), dtype=torch.uint8, device=local_nodes.device)
+        pad[:local_nodes.shape[0]] = local_nodes
+    if dist.get_backend(group) == "gloo" and pad.is_cuda:
+        # debugging path (several ranks sharing one GPU, where RCCL refuses duplicate devices): stage through host
+        host = torch.empty((world * slots, n_cols, 32), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, pad.cpu(), group=group)
+        flat = host.to(local_nodes.device)
+    else:
+        flat = torch.empty((world * slots, n_cols, 32), dtype=torch.uint8, device=local_nodes.device)
+        dist.all_gather_into_tensor(flat, pad, group=group)  # rank g's block lands at rows [g*slots, (g+1)*slots)
+    return flat, slots
 
 
 class HipShardEngine:
@@ -49,6 +74,7 @@ class HipShardEngine:
 
     def __init__(self, enc):
         self.enc = enc
+        self.rank, self.world = enc.params.shard_rank, max(1, enc.params.shard_count)
 
     def layout(self, n_rows_total):
         v = [C.c_uint64() for _ in range(5)]
@@ -57,32 +83,30 @@ class HipShardEngine:
 
     def commit_shard(self, local_coeffs, n_rows_total):
         rb, re, cb, ce, _ = self.layout(n_rows_total)
-        cvs = torch.empty((max(ce - cb, 0), self.enc.n_cols, 32), dtype=torch.uint8, device=local_coeffs.device)
+        n_nodes = len(aligned_nodes(cb, ce))
+        nodes = torch.empty((n_nodes, self.enc.n_cols, 32), dtype=torch.uint8, device=local_coeffs.device)
         st = torch.cuda.current_stream().cuda_stream
-        ptr = local_coeffs.data_ptr() if local_coeffs.numel() else 0
+        ptr = local_coeffs.data_ptr() if re > rb else None
+        # a rank that owns no chunk still passes a valid (unused) output pointer
+        out = nodes if nodes.numel() else torch.zeros(64, dtype=torch.uint8, device=local_coeffs.device)
         self.enc._check(_lib.lib().lcpc_commit_shard_device(self.enc._h, C.c_void_p(ptr), n_rows_total, C.c_void_p(st),
-                                                            C.c_void_p(cvs.data_ptr() if cvs.numel() else 0) if cvs.numel() else C.c_void_p(self._dummy().data_ptr())))
-        return cvs
+                                                            C.c_void_p(out.data_ptr())))
+        return nodes
 
-    def _dummy(self):
-        if not hasattr(self, "_d"):
-            self._d = torch.zeros(64, dtype=torch.uint8, device="cuda")
-        return self._d
-
-    def commit_finish(self, all_cvs, n_rows_total, want_root=True):
+    def commit_finish(self, gathered, n_rows_total, slots, want_root=True):
         st = torch.cuda.current_stream().cuda_stream
         root = (C.c_uint8 * 32)() if want_root else None
-        self.enc._check(_lib.lib().lcpc_commit_finish_device(self.enc._h, C.c_void_p(all_cvs.data_ptr()), n_rows_total,
+        self.enc._check(_lib.lib().lcpc_commit_finish_device(self.enc._h, C.c_void_p(gathered.data_ptr()), n_rows_total, slots,
                                                              C.c_void_p(st), root))
         return bytes(root) if want_root else None
 
 
 def sharded_commit(engine, local_coeffs, n_rows_total, group=None, want_root=True):
-    """one row-sharded commit step: local encode + chunk CVs, all-gather, finish.  Returns the root."""
+    """one row-sharded commit step: local encode + node CVs, all-gather, finish.  Returns the root."""
     _, _, _, _, n_chunks = engine.layout(n_rows_total)
-    cvs = engine.commit_shard(local_coeffs, n_rows_total)
+    nodes = engine.commit_shard(local_coeffs, n_rows_total)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        all_cvs = exchange_chunk_cvs(cvs, n_chunks, group)
+        gathered, slots = exchange_nodes(nodes, n_chunks, group)
     else:
-        all_cvs = cvs
-    return engine.commit_finish(all_cvs.contiguous(), n_rows_total, want_root)
+        gathered, slots = nodes.contiguous(), max(1, nodes.shape[0])
+    return engine.commit_finish(gathered, n_rows_total, slots, want_root)

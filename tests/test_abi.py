@@ -80,3 +80,18 @@ def test_transcript_matches_oracle(oracle):
         assert t1.challenge_bytes(b"ch", k) == t2.challenge_bytes(b"ch", k)
     t3 = t1.clone()
     assert t3.challenge_bytes(b"x", 16) == t1.challenge_bytes(b"x", 16)
+
+
+def test_shard_node_layout_matches_python():
+    """lcpc_shard_nodes (C) == lcpc_amd.distributed.aligned_nodes (Python): both sides of the exchange must agree."""
+    import ctypes as C
+    from lcpc_amd.distributed import aligned_nodes, chunk_split
+    L = _lib.lib()
+    for n_chunks in list(range(1, 40)) + [65, 129, 1000]:
+        for world in (1, 2, 3, 4, 8):
+            for rank, (b, e) in enumerate(chunk_split(n_chunks, world)):
+                n = C.c_uint32()
+                first = (C.c_uint64 * 64)()
+                lg = (C.c_uint32 * 64)()
+                assert L.lcpc_shard_nodes(n_chunks, world, rank, C.byref(n), first, lg) == 0
+                assert [(first[i], lg[i]) for i in range(n.value)] == aligned_nodes(b, e)

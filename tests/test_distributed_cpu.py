@@ -12,7 +12,10 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle_lib as O
-from lcpc_amd.distributed import chunk_split, sharded_commit
+import struct
+
+import pyref as P
+from lcpc_amd.distributed import aligned_nodes, chunk_split, sharded_commit, slots_per_rank
 
 
 class OracleShardEngine:
@@ -45,11 +48,56 @@ class OracleShardEngine:
             comm[r, :self.n_per_row] = rows[r]
             comm[r] = self.enc.encode(comm[r].copy()).reshape(self.n_cols, self.L)
         cvs = O.leaf_chunk_cvs(self.fid, comm, self.n_cols, rb, re - rb, n_rows, cb, ce)
-        return torch.from_numpy(cvs)
+        # pre-merge the chunk CVs into aligned subtree nodes (BLAKE3 parent rule, no ROOT), as the HIP engine does
+        nodes = []
+        for first, lg in aligned_nodes(cb, ce):
+            level = [[struct.unpack("<8I", cvs[first - cb + i, col].tobytes()) for i in range(1 << lg)] for col in range(self.n_cols)]
+            out = np.zeros((self.n_cols, 32), np.uint8)
+            for col in range(self.n_cols):
+                cur = level[col]
+                while len(cur) > 1:
+                    cur = [P.b3_parent(cur[2 * i], cur[2 * i + 1], False) for i in range(len(cur) // 2)]
+                out[col] = np.frombuffer(struct.pack("<8I", *cur[0]), np.uint8)
+            nodes.append(out)
+        arr = np.stack(nodes) if nodes else np.zeros((0, self.n_cols, 32), np.uint8)
+        return torch.from_numpy(arr)
 
-    def commit_finish(self, all_cvs, n_rows, want_root=True):
-        self.hashes = O.finish_from_cvs(all_cvs.numpy(), self.n_cols)
-        return self.hashes[-1].tobytes()
+    def commit_finish(self, gathered, n_rows, slots, want_root=True):
+        """fold the gathered nodes of every rank (in chunk order) with the BLAKE3 stack rule, then the Merkle tree"""
+        _, _, _, _, n_chunks = self.layout(n_rows)
+        g = gathered.numpy()
+        order = []
+        for r, (b, e) in enumerate(chunk_split(n_chunks, self.world)):
+            for k, (first, lg) in enumerate(aligned_nodes(b, e)):
+                order.append((r * slots + k, lg))
+        np2 = 1 << max(0, (self.n_cols - 1).bit_length())
+        hashes = np.zeros((2 * np2 - 1, 32), np.uint8)
+        for col in range(self.n_cols):
+            if n_chunks == 1:
+                hashes[col] = g[order[0][0], col]
+                continue
+            stack, total = [], 0
+            for j, (slot, lg) in enumerate(order):
+                cv = struct.unpack("<8I", g[slot, col].tobytes())
+                if j == len(order) - 1:
+                    break
+                total += 1 << lg
+                t = total >> lg
+                while t & 1 == 0:
+                    cv = P.b3_parent(stack.pop(), cv, False)
+                    t >>= 1
+                stack.append(cv)
+            while stack:
+                left = stack.pop()
+                cv = P.b3_parent(left, cv, len(stack) == 0)
+            hashes[col] = np.frombuffer(struct.pack("<8I", *cv), np.uint8)
+        width, ins, outs = np2, 0, np2
+        while width > 1:
+            for i in range(width // 2):
+                hashes[outs + i] = np.frombuffer(O.blake3(hashes[ins + 2 * i].tobytes() + hashes[ins + 2 * i + 1].tobytes()), np.uint8)
+            ins, outs, width = outs, outs + width // 2, width // 2
+        self.hashes = hashes
+        return hashes[-1].tobytes()
 
 
 def _free_port():
@@ -98,6 +146,21 @@ def test_sharded_commit_gloo(world, fid, n_rows, n_per_row, n_cols):
     for rank, root, hashes in res:
         assert root == oc.get_root(), "rank %d" % rank
         assert hashes == oc.hashes().tobytes()
+
+
+def test_aligned_nodes_cover_and_align():
+    for c0 in range(0, 40):
+        for c1 in range(c0, 70):
+            nodes = aligned_nodes(c0, c1)
+            pos = c0
+            for first, lg in nodes:
+                assert first == pos and first % (1 << lg) == 0
+                pos += 1 << lg
+            assert pos == c1
+    # the layouts the 8-GPU bench uses at 2^26 (17 chunks): 1,1,1,1,1,1,1,2 nodes; 2 GPUs: 1 + 2
+    assert [len(aligned_nodes(b, e)) for b, e in chunk_split(17, 8)] == [1, 1, 1, 1, 1, 1, 1, 2]
+    assert [len(aligned_nodes(b, e)) for b, e in chunk_split(17, 2)] == [1, 2]
+    assert slots_per_rank(17, 4) == 2 and slots_per_rank(33, 8) == 2
 
 
 def test_chunk_split_is_a_partition():

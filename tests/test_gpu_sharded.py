@@ -8,7 +8,7 @@ import torch
 
 import lcpc_amd
 from lcpc_amd import LcCommit, LigeroEncoding, SdigEncoding
-from lcpc_amd.distributed import HipShardEngine, chunk_split
+from lcpc_amd.distributed import HipShardEngine, aligned_nodes, chunk_split, slots_per_rank
 
 pytestmark = pytest.mark.gpu
 
@@ -16,15 +16,19 @@ pytestmark = pytest.mark.gpu
 def run_sharded(mk_enc, G, coeffs_rows, n_rows):
     """coeffs_rows: torch int64 cuda tensor [n_rows, n_per_row, L]"""
     engines = [HipShardEngine(mk_enc((g, G))) for g in range(G)]
-    cvs = []
+    nodes = []
     for g, eng in enumerate(engines):
         rb, re, cb, ce, nch = eng.layout(n_rows)
         local = coeffs_rows[rb:re].contiguous()
-        cvs.append(eng.commit_shard(local, n_rows))
+        nodes.append(eng.commit_shard(local, n_rows))
         assert (cb, ce) == chunk_split(nch, G)[g]
-        assert cvs[-1].shape[0] == ce - cb
-    all_cvs = torch.cat(cvs, dim=0).contiguous()
-    roots = [eng.commit_finish(all_cvs.clone(), n_rows) for eng in engines]
+        assert nodes[-1].shape[0] == len(aligned_nodes(cb, ce))
+    # emulate the all-gather: equal-sized padded blocks, rank g at rows [g*slots, (g+1)*slots)
+    slots = slots_per_rank(nch, G)
+    gathered = torch.zeros((G * slots, nodes[0].shape[1], 32), dtype=torch.uint8, device="cuda")
+    for g, nd in enumerate(nodes):
+        gathered[g * slots:g * slots + nd.shape[0]] = nd
+    roots = [eng.commit_finish(gathered.clone(), n_rows, slots) for eng in engines]
     return roots, engines
 
 
