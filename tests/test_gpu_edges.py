@@ -1,0 +1,172 @@
+"""Edge cases on the GPU path: smallest shapes, single rows, length-1 inputs, maximum sizes, and the error
+behaviour of the reference's Result enums / asserts (lcpc-2d/src/lib.rs:111-166, 630-632; ligero lib.rs:114-148)
+mirrored as lcpc_status codes."""
+import numpy as np
+import pytest
+
+import lcpc_amd
+from common import mk_transcript
+from lcpc_amd import LcCommit, LcEvalProof, LigeroEncoding, SdigEncoding, Transcript
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+@pytest.mark.parametrize("n_per_row,n_cols", [(1, 2), (1, 4), (3, 4), (7, 8), (2, 16)])
+def test_tiny_shapes(oracle, fid, n_per_row, n_cols):
+    """n_cols = 2..16 (log_n = 1 has a single, multiplication-free stage), 1..5 rows, ragged tails."""
+    O = oracle
+    for n in (1, n_per_row, n_per_row + 1, 5 * n_per_row - (1 if n_per_row > 1 else 0)):
+        coeffs = O.random_elems(fid, n, n + n_cols)
+        enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+        oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+        c = LcCommit.commit(coeffs, enc)
+        oc = O.Commit.commit(coeffs, oenc)
+        assert (c.n_rows, c.n_per_row, c.n_cols) == (oc.n_rows, oc.n_per_row, oc.n_cols)
+        assert (c.comm() == oc.comm()).all() and (c.coeffs() == oc.coeffs()).all()
+        assert (c.hashes() == oc.hashes()).all() and c.get_root() == oc.get_root()
+        t = O.random_elems(fid, c.n_rows, 3)
+        assert (c.eval_outer(t) == oc.collapse(t)).all()
+        # full prove/verify round trip on the tiny commitment (309 openings of a handful of columns)
+        root = c.get_root()
+        pf = c.prove(t, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+        opf, _ = oc.prove(t, oenc, mk_transcript(O.Transcript, root, enc.get_n_col_opens()))
+        assert pf.to_bytes() == opf
+        inner = O.random_elems(fid, c.n_per_row, 4)
+        ev = pf.verify(root, t, inner, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+        rc, oev = O.verify(oenc, root, t, inner, opf, mk_transcript(O.Transcript, root, enc.get_n_col_opens()))
+        assert rc == 0 and (ev == oev).all()
+
+
+def test_all_zero_and_extreme_values(oracle):
+    """coefficients 0, 1 and p-1 (Montgomery forms 0, R, p-R): carries / conditional subtractions at the borders."""
+    O = oracle
+    import pyref as P
+    for fid in (0, 3):
+        F = P.FIELDS[fid]
+        vals = [0, 1, F.p - 1, 2, F.p - 2, (F.p - 1) // 2, (F.p + 1) // 2] * 40
+        coeffs = O.to_mont(fid, vals)
+        for enc, oenc in ((LigeroEncoding.new_from_dims(fid, 32, 64), O.Encoding.ligero_from_dims(fid, 32, 64)),
+                          (LigeroEncoding.new_from_dims(fid, 2048, 4096), O.Encoding.ligero_from_dims(fid, 2048, 4096))):
+            c = LcCommit.commit(coeffs, enc)
+            oc = O.Commit.commit(coeffs, oenc)
+            assert (c.comm() == oc.comm()).all() and c.get_root() == oc.get_root()
+        z = np.zeros((300, O.limbs(fid)), np.uint64)
+        enc, oenc = LigeroEncoding.new_from_dims(fid, 32, 64), O.Encoding.ligero_from_dims(fid, 32, 64)
+        assert LcCommit.commit(z, enc).get_root() == O.Commit.commit(z, oenc).get_root()
+
+
+def test_single_row_many_columns(oracle):
+    """n_rows = 1: leaf message = 32 + F bytes, one BLAKE3 block; n_cols = 2^13 (two NTT passes for Ft255)."""
+    O = oracle
+    for fid, k in ((3, 13), (0, 14)):
+        n = 1 << (k - 1)
+        coeffs = O.random_elems(fid, n, 77)
+        enc, oenc = LigeroEncoding.new_from_dims(fid, n, 2 * n), O.Encoding.ligero_from_dims(fid, n, 2 * n)
+        c, oc = LcCommit.commit(coeffs, enc), O.Commit.commit(coeffs, oenc, n_threads=4)
+        assert c.n_rows == 1 and (c.hashes() == oc.hashes()).all()
+
+
+def test_constructor_errors():
+    E = lcpc_amd.LcpcError
+    with pytest.raises(E) as e:                                  # _dims_ok: n_per_row < n_cols (ligero lib.rs:114-118)
+        LigeroEncoding.new_from_dims(3, 64, 64)
+    assert e.value.code == lcpc_amd.ERR_DIMS
+    with pytest.raises(E) as e:                                  # n_cols must be a power of two
+        LigeroEncoding.new_from_dims(3, 10, 48)
+    assert e.value.code == lcpc_amd.ERR_DIMS
+    with pytest.raises(E) as e:                                  # rho_num < rho_den (ligero lib.rs:56)
+        LigeroEncoding.new(3, 1 << 12, rho=(2, 2))
+    assert e.value.code == lcpc_amd.ERR_ARG
+    with pytest.raises(E) as e:                                  # unknown field id
+        LigeroEncoding.new(9, 1 << 12)
+    assert e.value.code == lcpc_amd.ERR_ARG
+    with pytest.raises(E) as e:                                  # n_cols beyond the device path's 2^30 (and ft127's 2^40 cap upstream)
+        LigeroEncoding.new_from_dims(0, 1 << 30, 1 << 31)
+    assert e.value.code in (lcpc_amd.ERR_TOO_BIG, lcpc_amd.ERR_DIMS)
+    with pytest.raises(E) as e:                                  # new_from_dims with a codeword length that matgen does not produce
+        SdigEncoding.new_from_dims(3, 600, 1000, 0)
+    assert e.value.code == lcpc_amd.ERR_DIMS
+    with pytest.raises(E) as e:                                  # n <= baselen: matgen::get_dims assert (matgen.rs:62)
+        SdigEncoding.new_from_dims(3, 20, 40, 0)
+    assert e.value.code == lcpc_amd.ERR_DIMS
+    with pytest.raises(E) as e:                                  # invalid SDIG code
+        SdigEncoding.new(3, 1 << 12, 0, code=7)
+    assert e.value.code == lcpc_amd.ERR_ARG
+    with pytest.raises(E) as e:                                  # sharding a field whose elements straddle BLAKE3 chunks
+        LigeroEncoding.new_from_dims(2, 64, 128, shard=(0, 2))
+    assert e.value.code == lcpc_amd.ERR_ARG
+
+
+def test_state_and_argument_errors(oracle):
+    O = oracle
+    E = lcpc_amd.LcpcError
+    enc = LigeroEncoding.new_from_dims(0, 64, 128)
+    with pytest.raises(E) as e:                                  # no commitment yet
+        LcCommit(enc)
+    assert e.value.code == lcpc_amd.ERR_STATE
+    with pytest.raises(E) as e:                                  # empty input (the reference asserts n_rows >= 1, lib.rs:630-631)
+        LcCommit.commit(np.zeros((0, 1), np.uint64), enc)
+    assert e.value.code == lcpc_amd.ERR_ARG
+    c = LcCommit.commit(O.random_elems(0, 1000, 1), enc)
+    with pytest.raises(E) as e:                                  # ProverError::OuterTensor (lib.rs:1016-1018)
+        c.prove(O.random_elems(0, c.n_rows + 1, 2), enc, Transcript(b"t"))
+    assert e.value.code == lcpc_amd.ERR_OUTER_TENSOR
+    with pytest.raises(E) as e:                                  # ProverError::ColumnNumber (lib.rs:797-799)
+        c.open_columns([0, 5, 128])
+    assert e.value.code == lcpc_amd.ERR_COLUMN_NUMBER
+    with pytest.raises(E) as e:                                  # encode(): row length != n_cols
+        enc.encode(np.zeros((100, 1), np.uint64))
+    assert e.value.code == lcpc_amd.ERR_ENCODE
+    other = LigeroEncoding.new_from_dims(0, 64, 128)
+    with pytest.raises(E) as e:                                  # prove with an encoding that does not own the commitment (check_comm)
+        c.prove(O.random_elems(0, c.n_rows, 2), other, Transcript(b"t"))
+    assert e.value.code == lcpc_amd.ERR_COMMIT
+    # VerifierError::NumColOpens (lib.rs:845-848): truncate the columns vector of a valid proof
+    t = O.random_elems(0, c.n_rows, 2)
+    pf = c.prove(t, enc, Transcript(b"t"))
+    raw = bytearray(pf.to_bytes())
+    n_deg = enc.get_n_degree_tests()
+    off = 8 + (8 + 64 * 8) + 8 + n_deg * (8 + 64 * 8)           # offset of the `columns` length prefix
+    assert int.from_bytes(raw[off:off + 8], "little") == enc.get_n_col_opens()
+    per_col = 8 + c.n_rows * 8 + 8 + 7 * 40
+    cut = bytes(raw[:off]) + (enc.get_n_col_opens() - 1).to_bytes(8, "little") + bytes(raw[off + 8:len(raw) - per_col])
+    with pytest.raises(E) as e:
+        LcEvalProof.from_bytes(cut, 1).verify(c.get_root(), t, O.random_elems(0, 64, 3), enc, Transcript(b"t"))
+    assert e.value.code == lcpc_amd.VERR_NUM_COL_OPENS
+    # VerifierError::EncodingDims (lib.rs:858-860): verify against an encoding of a different shape
+    wrong = LigeroEncoding.new_from_dims(0, 32, 128)
+    with pytest.raises(E) as e:
+        pf.verify(c.get_root(), t, O.random_elems(0, 64, 3), wrong, Transcript(b"t"))
+    assert e.value.code == lcpc_amd.VERR_ENCODING_DIMS
+
+
+def test_rate_variants_2e20(oracle):
+    """the three rates the reference benchmarks (1/2 `hlf`, 1/4 default, 38/39 `isz`; ligero tests.rs:59-69) at 2^20
+    Ft255: sampled rows/columns against the oracle (non-power-of-two n_per_row for 38/39: 2^k * 38 / 39)."""
+    import random
+    O = oracle
+    rnd = random.Random(1)
+    n = 1 << 20
+    coeffs = O.random_elems(3, n, 8)
+    for rho in ((1, 2), (1, 4), (38, 39)):
+        enc, oenc = LigeroEncoding.new(3, n, rho), O.Encoding.ligero(3, n, rho)
+        assert enc.get_dims(n) == oenc.get_dims(n)
+        c = LcCommit.commit(coeffs, enc)
+        nr, npr, nc = enc.get_dims(n)
+        for r in (0, nr - 1, rnd.randrange(nr)):
+            row = np.zeros((nc, 4), np.uint64)
+            chunk = coeffs[r * npr:min(n, (r + 1) * npr)]
+            row[:chunk.shape[0]] = chunk
+            assert (c.comm(r, 1) == oenc.encode(row)).all(), (rho, r)
+        cols = [0, nc - 1] + [rnd.randrange(nc) for _ in range(10)]
+        vals, paths = c.open_columns(cols)
+        hashes, root = c.hashes(), c.get_root()
+        for k, col in enumerate(cols):
+            h = O.hash_column(3, vals[k])
+            assert h == bytes(hashes[col])
+            cn = col
+            for p in paths[k]:
+                h = O.blake3(h + bytes(p)) if cn % 2 == 0 else O.blake3(bytes(p) + h)
+                cn >>= 1
+            assert h == root
