@@ -44,11 +44,14 @@ hipError_t launch_merkle_tree(uint32_t* hashes, uint64_t np2, hipStream_t st);
 struct CollapseArgs {
   const uint32_t* coeffs;      // local rows x n_per_row
   const uint32_t* tensors;     // [n_tensors][n_rows_local]
+  const uint32_t* tensors29;   // Ft255: the same tensors as 9 x 29-bit limbs of t * 2^261 (12-word stride), or null
   uint32_t* out;               // n_splits == 1: polys [n_tensors][n_per_row]; else partial [n_splits][n_tensors][n_per_row]
   uint64_t n_rows, n_per_row;
   uint32_t n_tensors, n_splits;
 };
 hipError_t launch_collapse(int nl, const CollapseArgs& a, hipStream_t st);
+// Ft255 tensors (Montgomery) -> the 29-bit-limb / 2^261 form used by the lazy dot-product kernels
+hipError_t launch_to_r29(const uint32_t* in, uint64_t n, uint32_t* out, hipStream_t st);
 // out[e] = sum_p parts[p][e] mod p
 hipError_t launch_field_sum(int nl, const uint32_t* parts, uint32_t n_parts, uint64_t n_elems, uint32_t* out, hipStream_t st);
 

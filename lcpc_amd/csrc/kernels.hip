@@ -505,6 +505,68 @@ __global__ void __launch_bounds__(256) collapse_kernel(CollapseArgs a) {
 #pragma unroll
   for (int t = 0; t < NT; t++) fe_store<NL>(a.out + (((u64)z * NT + t) * a.n_per_row + j) * NL, acc[t]);
 }
+// Ft255: carry-free lazy dot products (lazy29_mac); the tensor entry is wave-uniform, so its nine 29-bit limbs
+// (pre-converted to the 2^261 form, a.tensors29) are scalar operands of the 81 v_mad_u64_u32 per term.
+template <int NT>
+__global__ void __launch_bounds__(256) collapse29_kernel(CollapseArgs a) {
+  const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.n_per_row) return;
+  const u32 z = blockIdx.y;
+  const u64 rows_per = (a.n_rows + a.n_splits - 1) / a.n_splits;
+  const u64 r0 = (u64)z * rows_per;
+  const u64 r1 = (r0 + rows_per < a.n_rows) ? r0 + rows_per : a.n_rows;
+  Fe<8> acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = fe_zero<8>();
+  for (u64 rb = r0; rb < r1; rb += 60) {
+    const u64 re = (rb + 60 < r1) ? rb + 60 : r1;
+    Lazy29 w[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) lazy29_zero(w[t]);
+    u32 since = 0;
+    Fe<8> c = fe_load<8>(a.coeffs + (rb * a.n_per_row + j) * 8);
+    for (u64 r = rb; r < re; r++) {
+      Fe<8> cn = c;
+      if (r + 1 < re) cn = fe_load<8>(a.coeffs + ((r + 1) * a.n_per_row + j) * 8);     // next row in flight
+      const Fe29 x = fe_to29(c);
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        Fe29 v;
+#pragma unroll
+        for (int i = 0; i < 9; i++) v.v[i] = __builtin_amdgcn_readfirstlane(a.tensors29[((u64)t * a.n_rows + r) * 12 + i]);
+        lazy29_mac(w[t], x, v);
+      }
+      if (++since == 6) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) lazy29_normalize(w[t]);
+        since = 0;
+      }
+      c = cn;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = fe_add<8>(acc[t], lazy29_reduce(w[t]));
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++) fe_store<8>(a.out + (((u64)z * NT + t) * a.n_per_row + j) * 8, acc[t]);
+}
+// tensors (Montgomery, R = 2^256) -> 9 x 29-bit limbs of t * 2^261 mod p, 12-word stride
+__global__ void __launch_bounds__(256) to_r29_kernel(const u32* in, u64 n, u32* out) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  Fe<8> t = fe_load<8>(in + i * 8);
+#pragma unroll
+  for (int d = 0; d < 5; d++) t = fe_add<8>(t, t);
+  const Fe29 x = fe_to29(t);
+#pragma unroll
+  for (int k = 0; k < 9; k++) out[i * 12 + k] = x.v[k];
+  out[i * 12 + 9] = out[i * 12 + 10] = out[i * 12 + 11] = 0;
+}
+hipError_t launch_to_r29(const u32* in, u64 n, u32* out, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(to_r29_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, out);
+  return hipGetLastError();
+}
+
 template <int NL>
 static hipError_t launch_collapse_t(const CollapseArgs& a, hipStream_t st) {
   dim3 grid((unsigned)((a.n_per_row + 255) / 256), a.n_splits);
@@ -516,6 +578,15 @@ static hipError_t launch_collapse_t(const CollapseArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t launch_collapse(int nl, const CollapseArgs& a, hipStream_t st) {
+  if (nl == 8 && a.tensors29 != nullptr) {
+    dim3 grid((unsigned)((a.n_per_row + 255) / 256), a.n_splits);
+    switch (a.n_tensors) {
+      case 1: hipLaunchKernelGGL(collapse29_kernel<1>, grid, dim3(256), 0, st, a); break;
+      case 2: hipLaunchKernelGGL(collapse29_kernel<2>, grid, dim3(256), 0, st, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (nl) {
     case 2: return launch_collapse_t<2>(a, st);
     case 4: return launch_collapse_t<4>(a, st);

@@ -85,6 +85,8 @@ struct lcpc_ctx {
   // scratch for prove / collapse / open
   uint32_t* d_scratch = nullptr;
   uint64_t scratch_cap = 0;
+  uint32_t* d_t29 = nullptr;       // collapse: tensors in the 29-bit-limb form
+  uint64_t t29_cap = 0;
   // timing
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -558,7 +560,7 @@ void lcpc_ctx_destroy(lcpc_ctx* c) {
   dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_r2); dev_free(c->d_tmp); dev_free(c->d_t);
   for (auto* v : {&c->d_pre, &c->d_post})
     for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); dev_free(d.vals29); }
-  dev_free(c->d_coeffs); dev_free(c->d_comm); dev_free(c->d_hashes); dev_free(c->d_cvs); dev_free(c->d_scratch); dev_free(c->d_node_tab);
+  dev_free(c->d_coeffs); dev_free(c->d_comm); dev_free(c->d_hashes); dev_free(c->d_cvs); dev_free(c->d_scratch); dev_free(c->d_node_tab); dev_free(c->d_t29);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   delete c;
 }
@@ -719,6 +721,17 @@ static int collapse_local(lcpc_ctx* c, const uint32_t* d_tensors, uint32_t n_ten
   CollapseArgs a{};
   a.coeffs = c->d_coeffs; a.tensors = d_tensors; a.n_rows = c->n_rows_local; a.n_per_row = c->n_per_row;
   a.n_tensors = n_tensors; a.n_splits = n_splits;
+  if (c->NL == 8) {
+    const uint64_t ne = (uint64_t)n_tensors * c->n_rows_local;
+    if (ne > c->t29_cap) {
+      dev_free(c->d_t29);
+      int rc = dev_alloc(c, &c->d_t29, (size_t)ne * 48);
+      if (rc) return rc;
+      c->t29_cap = ne;
+    }
+    HIPCHK(c, launch_to_r29(d_tensors, ne, c->d_t29, st));
+    a.tensors29 = c->d_t29;
+  }
   if (n_splits == 1) {
     a.out = d_out;
     HIPCHK(c, launch_collapse(c->NL, a, st));
