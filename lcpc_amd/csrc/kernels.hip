@@ -808,8 +808,9 @@ hipError_t launch_transpose_from_t(int nl, const u32* t, u64 n_pos, u64 n_rows, 
   return hipGetLastError();
 }
 
-constexpr int SPMM_OPW = 4;       // outputs per workgroup
-template <int NL>
+// OPW = outputs per workgroup: 4 for the wide levels, 1 for the narrow tail levels (a few hundred outputs: the
+// launch is latency-bound, so spread the outputs over as many workgroups as possible)
+template <int NL, int SPMM_OPW>
 __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a) {
   const u64 row = (u64)blockIdx.y * 128 + threadIdx.x;
   const bool live = row < a.n_rows;
@@ -867,8 +868,13 @@ __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a) {
 }
 hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st) {
   if (a.m == 0 || a.n_rows == 0) return hipSuccess;
-  dim3 grid((unsigned)((a.m + SPMM_OPW - 1) / SPMM_OPW), (unsigned)((a.n_rows + 127) / 128));
-  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(spmm_t_kernel<NLV>, grid, dim3(128), 0, st, a));
+  if (a.m >= 8192) {
+    dim3 grid((unsigned)((a.m + 3) / 4), (unsigned)((a.n_rows + 127) / 128));
+    LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_kernel<NLV, 4>), grid, dim3(128), 0, st, a));
+  } else {
+    dim3 grid((unsigned)a.m, (unsigned)((a.n_rows + 127) / 128));
+    LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_kernel<NLV, 1>), grid, dim3(128), 0, st, a));
+  }
   return hipGetLastError();
 }
 
