@@ -50,15 +50,16 @@ def check_sampled(O, fid, enc, oenc, c, coeffs_host_rows, rnd, n_row_samples=2, 
     assert bytes(hashes[-1]) == root
 
 
-@pytest.mark.parametrize("log_len", [24, 26])
+@pytest.mark.parametrize("log_len", [24, 26, 28])
 def test_ligero_ft255_fullsize(oracle, log_len):
-    """BASELINE configs[1] (2^24) and the headline / configs[4] (2^26): commit + prove at full size."""
+    """BASELINE configs[1] (2^24), the headline / configs[4] (2^26) and configs[3]'s commitment (2^28, here on ONE
+    GPU: 8 + 16 GiB, 33 BLAKE3 chunks per leaf, 64 KiB NTT tiles): commit + prove at full size."""
     O, fid = oracle, 3
     rnd = random.Random(log_len)
     n = 1 << log_len
     enc = LigeroEncoding.new(fid, n)
     nr, npr, nc = enc.get_dims(n)
-    assert (nr, npr, nc) == {24: (256, 65536, 131072), 26: (512, 131072, 262144)}[log_len]
+    assert (nr, npr, nc) == {24: (256, 65536, 131072), 26: (512, 131072, 262144), 28: (1024, 262144, 524288)}[log_len]
     coeffs = device_random_coeffs(fid, n, 5)
     c = LcCommit.commit_device(coeffs.data_ptr(), n, enc, torch.cuda.current_stream().cuda_stream)
     oenc = O.Encoding.ligero_from_dims(fid, npr, nc)
