@@ -90,6 +90,8 @@ struct lcpc_ctx {
   // timing
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t s_copy = nullptr, s_comp = nullptr;   // lcpc_commit (host pointer): H2D of row batch b+1 overlaps the NTTs of batch b
+  hipEvent_t ev_batch[16] = {nullptr};
   lcpc_timings last{};
   uint32_t launches[3] = {0, 0, 0};
   std::string err;
@@ -562,6 +564,9 @@ void lcpc_ctx_destroy(lcpc_ctx* c) {
     for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); dev_free(d.vals29); }
   dev_free(c->d_coeffs); dev_free(c->d_comm); dev_free(c->d_hashes); dev_free(c->d_cvs); dev_free(c->d_scratch); dev_free(c->d_node_tab); dev_free(c->d_t29);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->ev_batch) if (e) (void)hipEventDestroy(e);
+  if (c->s_copy) (void)hipStreamDestroy(c->s_copy);
+  if (c->s_comp) (void)hipStreamDestroy(c->s_comp);
   delete c;
 }
 
@@ -637,11 +642,47 @@ int lcpc_commit(lcpc_ctx* c, const uint64_t* coeffs, uint64_t n_coeffs, uint8_t*
   int rc = set_rows(c, n_coeffs);
   if (rc) return rc;
   const size_t eb = elem_bytes(c);
-  HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs, (size_t)n_coeffs * eb, hipMemcpyHostToDevice, nullptr));
   const uint64_t padded = c->n_rows * c->n_per_row;
+  const size_t total_bytes = (size_t)n_coeffs * eb;
+  // Small inputs, Brakedown (whole-matrix transposes) and timing runs: one copy, then the resident path.
+  if (c->prm.encoding != LCPC_ENC_LIGERO || total_bytes < ((size_t)64 << 20) || c->n_rows < 16 || c->timing) {
+    HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs, total_bytes, hipMemcpyHostToDevice, nullptr));
+    if (padded > n_coeffs)
+      HIPCHK(c, hipMemsetAsync(reinterpret_cast<uint8_t*>(c->d_coeffs) + total_bytes, 0, (size_t)(padded - n_coeffs) * eb, nullptr));
+    return commit_resident(c, nullptr, root);
+  }
+  // Large Ligero commit from host memory: rows are independent (lcpc-2d lib.rs:648-653), so the matrix is
+  // uploaded in row batches on a copy stream while the previous batch runs its NTT passes on a compute stream;
+  // column hashing starts once the last batch is encoded.  The end-to-end time tends to the PCIe time.
+  if (!c->s_copy) HIPCHK(c, hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
+  if (!c->s_comp) HIPCHK(c, hipStreamCreateWithFlags(&c->s_comp, hipStreamNonBlocking));
+  constexpr int NB = 16;
+  for (auto& e : c->ev_batch)
+    if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(c, hipDeviceSynchronize());                       // earlier work of this context (null stream) is done
   if (padded > n_coeffs)
-    HIPCHK(c, hipMemsetAsync(reinterpret_cast<uint8_t*>(c->d_coeffs) + (size_t)n_coeffs * eb, 0, (size_t)(padded - n_coeffs) * eb, nullptr));
-  return commit_resident(c, nullptr, root);
+    HIPCHK(c, hipMemsetAsync(reinterpret_cast<uint8_t*>(c->d_coeffs) + total_bytes, 0, (size_t)(padded - n_coeffs) * eb, c->s_copy));
+  c->launches[0] = c->launches[1] = c->launches[2] = 0;
+  const uint64_t rows_per = (c->n_rows + NB - 1) / NB;
+  for (int b = 0; b < NB; b++) {
+    const uint64_t r0 = (uint64_t)b * rows_per;
+    if (r0 >= c->n_rows) break;
+    const uint64_t r1 = r0 + rows_per < c->n_rows ? r0 + rows_per : c->n_rows;
+    const uint64_t e0 = r0 * c->n_per_row, e1 = r1 * c->n_per_row < n_coeffs ? r1 * c->n_per_row : n_coeffs;
+    if (e1 > e0)
+      HIPCHK(c, hipMemcpyAsync(reinterpret_cast<uint8_t*>(c->d_coeffs) + (size_t)e0 * eb, reinterpret_cast<const uint8_t*>(coeffs) + (size_t)e0 * eb,
+                               (size_t)(e1 - e0) * eb, hipMemcpyHostToDevice, c->s_copy));
+    HIPCHK(c, hipEventRecord(c->ev_batch[b], c->s_copy));
+    HIPCHK(c, hipStreamWaitEvent(c->s_comp, c->ev_batch[b], 0));
+    rc = encode_rows_device(c, c->d_coeffs + (size_t)r0 * c->n_per_row * c->NL, c->n_per_row, c->n_per_row,
+                            c->d_comm + (size_t)r0 * c->n_cols * c->NL, r1 - r0, c->s_comp);
+    if (rc) return rc;
+  }
+  if ((rc = merkleize_device(c, c->s_comp))) return rc;
+  c->committed = true;
+  if (root) HIPCHK(c, hipMemcpyAsync(root, c->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, c->s_comp));
+  HIPCHK(c, hipStreamSynchronize(c->s_comp));              // later calls use the null stream / caller streams
+  return 0;
 }
 
 int lcpc_commit_from_parts(lcpc_ctx* c, const uint64_t* comm, const uint64_t* coeffs, uint64_t n_rows, uint8_t* root) {

@@ -347,3 +347,21 @@ def test_brakedown_many_rows_vs_oracle(oracle, fid, n_per_row, n_rows, seed, cod
     assert c.n_rows == n_rows == oc.n_rows
     assert (c.comm() == oc.comm()).all()
     assert (c.hashes() == oc.hashes()).all() and c.get_root() == oc.get_root()
+
+
+def test_commit_host_pipelined_vs_oracle(oracle):
+    """lcpc_commit from host memory above 64 MiB uploads the matrix in row batches overlapped with the row NTTs
+    (copy stream / compute stream): ragged 2^22-ish Ft255 input, everything compared with the oracle."""
+    O = oracle
+    n = (1 << 22) - 5
+    coeffs = O.random_elems(3, n, 55)
+    enc, oenc = LigeroEncoding.new(3, n), O.Encoding.ligero(3, n)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=8)
+    assert c.get_root() == oc.get_root()
+    assert (c.hashes() == oc.hashes()).all()
+    assert (c.coeffs() == oc.coeffs()).all()
+    assert (c.comm() == oc.comm()).all()
+    # and again on the same context (stream/event reuse), different data
+    coeffs2 = O.random_elems(3, n, 56)
+    assert LcCommit.commit(coeffs2, enc).get_root() == O.Commit.commit(coeffs2, oenc, n_threads=8).get_root()
