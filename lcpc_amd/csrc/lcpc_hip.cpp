@@ -11,7 +11,9 @@
 #include <string.h>
 #include <chrono>
 #include <mutex>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "encoding.h"
 #include "host_crypto.h"
@@ -42,6 +44,27 @@ void to_r29(const FieldDesc& f, const uint64_t* in4, uint32_t* out12) {
     out12[k] = (uint32_t)(x & ((1u << 29) - 1));
   }
   out12[9] = out12[10] = out12[11] = 0;
+}
+
+// small fork-join helper for the host-side glue (the reference uses rayon at the same places: lib.rs:923-944)
+template <typename Fn> void parallel_for(uint64_t n, uint64_t grain, Fn fn) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 16) nt = 16;
+  if (nt <= 1 || n < 2 * grain) { fn((uint64_t)0, n); return; }
+  const uint64_t nchunks = (n + grain - 1) / grain;
+  if (nt > nchunks) nt = (unsigned)nchunks;
+  std::atomic<uint64_t> next{0};
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++)
+    th.emplace_back([&] {
+      for (;;) {
+        const uint64_t c = next.fetch_add(1);
+        if (c >= nchunks) return;
+        const uint64_t b = c * grain, e = b + grain < n ? b + grain : n;
+        fn(b, e);
+      }
+    });
+  for (auto& x : th) x.join();
 }
 
 const uint8_t LBL_DT[] = "$l//DT", LBL_PR[] = "$l//PR", LBL_PE[] = "$l//PE", LBL_CO[] = "$l//CO";  // macros.rs:31-34
@@ -882,11 +905,12 @@ void lcpc_transcript_free(lcpc_transcript* t) { delete t; }
 static void put_u64(std::vector<uint8_t>& w, uint64_t v) { const uint8_t* p = reinterpret_cast<const uint8_t*>(&v); w.insert(w.end(), p, p + 8); }
 static void put_bytes(std::vector<uint8_t>& w, const void* d, size_t n) { const uint8_t* p = static_cast<const uint8_t*>(d); w.insert(w.end(), p, p + n); }
 static void absorb_poly(Transcript& tr, const uint8_t* label, const FieldDesc& f, const uint64_t* poly, uint64_t n) {
-  uint64_t t[MAXL];
-  for (uint64_t i = 0; i < n; i++) {
-    h_canon(f, t, poly + i * f.L);                                            // to_repr, little-endian (lib.rs:47-57)
-    tr.append_message(label, 6, reinterpret_cast<const uint8_t*>(t), 8 * f.L);
-  }
+  // to_repr (Montgomery -> canonical little-endian, lib.rs:47-57) is independent per element: done in parallel;
+  // only the STROBE absorb itself is serial (lib.rs:1045-1047)
+  const int L = f.L;
+  std::vector<uint64_t> canon(n * L);
+  parallel_for(n, 4096, [&](uint64_t b, uint64_t e) { for (uint64_t i = b; i < e; i++) h_canon(f, &canon[i * L], poly + i * L); });
+  for (uint64_t i = 0; i < n; i++) tr.append_message(label, 6, reinterpret_cast<const uint8_t*>(&canon[i * L]), 8 * L);
 }
 
 int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t** proof, uint64_t* proof_len,
@@ -1062,31 +1086,37 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
   memcpy(&enc[n_deg * n_cols * L], p_eval.data(), n_per_row * F);
   int rc = lcpc_encode_rows(c, enc.data(), n_deg + 1);                         // the 1+n_deg row encodes run on the GPU
   if (rc) return rc == LCPC_ERR_ENCODE ? LCPC_VERR_ENCODE : rc;
-  // step 3: per-column checks (lib.rs:923-944)
-  for (uint64_t i = 0; i < n_columns; i++) {
-    const uint64_t cn = rng.uniform(n_cols);
-    bool rnd = true, evl = true;
-    for (uint64_t d = 0; d <= n_deg; d++) {
-      const uint64_t* tensor = d < n_deg ? rand_tensors[d].data() : outer;
-      uint64_t acc[MAXL] = {0, 0, 0, 0}, t[MAXL];
-      for (uint64_t k = 0; k < n_rows; k++) { h_mul(f, t, tensor + k * L, &cols[i][k * L]); h_add(f, acc, acc, t); }
-      const bool ok = h_eq(f, acc, &enc[(d * n_cols + cn) * L]);             // verify_column_value lib.rs:985-1000
-      if (d < n_deg) rnd = rnd && ok; else evl = ok;
+  // step 3: per-column checks (lib.rs:923-944), in parallel over columns like the reference's par_iter;
+  // the error reported is that of the first failing column, with the reference's precedence degree > eval > path
+  std::vector<uint64_t> cols_to_open(n_columns);
+  for (auto& x : cols_to_open) x = rng.uniform(n_cols);
+  std::vector<int> status(n_columns, 0);
+  parallel_for(n_columns, 4, [&](uint64_t b, uint64_t e) {
+    for (uint64_t i = b; i < e; i++) {
+      const uint64_t cn = cols_to_open[i];
+      bool rnd = true, evl = true;
+      for (uint64_t d = 0; d <= n_deg; d++) {
+        const uint64_t* tensor = d < n_deg ? rand_tensors[d].data() : outer;
+        uint64_t acc[MAXL] = {0, 0, 0, 0}, t[MAXL];
+        for (uint64_t k = 0; k < n_rows; k++) { h_mul(f, t, tensor + k * L, &cols[i][k * L]); h_add(f, acc, acc, t); }
+        const bool ok = h_eq(f, acc, &enc[(d * n_cols + cn) * L]);           // verify_column_value lib.rs:985-1000
+        if (d < n_deg) rnd = rnd && ok; else evl = ok;
+      }
+      uint8_t h[32], blk[64];                                                  // verify_column_path lib.rs:955-982
+      hash_column_host(f, cols[i].data(), n_rows, h);
+      uint64_t cc = cn;
+      for (uint64_t k = 0; k < paths[i].size() / 32; k++) {
+        const uint8_t* pk = &paths[i][k * 32];
+        if (cc % 2 == 0) { memcpy(blk, h, 32); memcpy(blk + 32, pk, 32); } else { memcpy(blk, pk, 32); memcpy(blk + 32, h, 32); }
+        blake3_host(blk, 64, h);
+        cc >>= 1;
+      }
+      const bool pth = memcmp(h, root, 32) == 0;
+      status[i] = !rnd ? LCPC_VERR_COLUMN_DEGREE : (!evl ? LCPC_VERR_COLUMN_EVAL : (!pth ? LCPC_VERR_COLUMN_PATH : 0));
     }
-    uint8_t h[32], blk[64];                                                    // verify_column_path lib.rs:955-982
-    hash_column_host(f, cols[i].data(), n_rows, h);
-    uint64_t cc = cn;
-    for (uint64_t k = 0; k < paths[i].size() / 32; k++) {
-      const uint8_t* pk = &paths[i][k * 32];
-      if (cc % 2 == 0) { memcpy(blk, h, 32); memcpy(blk + 32, pk, 32); } else { memcpy(blk, pk, 32); memcpy(blk + 32, h, 32); }
-      blake3_host(blk, 64, h);
-      cc >>= 1;
-    }
-    const bool pth = memcmp(h, root, 32) == 0;
-    if (!rnd) return LCPC_VERR_COLUMN_DEGREE;
-    if (!evl) return LCPC_VERR_COLUMN_EVAL;
-    if (!pth) return LCPC_VERR_COLUMN_PATH;
-  }
+  });
+  for (uint64_t i = 0; i < n_columns; i++)
+    if (status[i]) return status[i];
   uint64_t acc[MAXL] = {0, 0, 0, 0}, t[MAXL];                                  // lib.rs:947-951
   for (uint64_t k = 0; k < n_per_row; k++) { h_mul(f, t, inner + k * L, &p_eval[k * L]); h_add(f, acc, acc, t); }
   memcpy(eval_out, acc, F);
