@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--log-len", type=int, default=26)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log-len", type=int, default=24)
+    ap.add_argument("--cpu-sample-log-len", type=int, default=25)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (debug: ranks may share a GPU)")
     ap.add_argument("--force-device", type=int, default=None, help="debug: every rank uses this HIP device")
     ap.add_argument("--check", action="store_true", help="debug: compare the sharded root with an unsharded commit of the same data")
