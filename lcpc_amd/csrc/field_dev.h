@@ -74,46 +74,6 @@ template <int NL> LCPC_DEV void fe_store(u32* __restrict__ p, const Fe<NL>& a) {
 }
 
 
-// streaming (touch-once) variants: non-temporal hint keeps the L2 for the twiddle table
-typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
-typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
-template <int NL> LCPC_DEV Fe<NL> fe_load_nt(const u32* __restrict__ p) {
-  Fe<NL> r;
-  if constexpr (NL % 4 == 0) {
-    const u32x4_t* q = reinterpret_cast<const u32x4_t*>(p);
-#pragma unroll
-    for (int i = 0; i < NL / 4; i++) {
-      u32x4_t t = __builtin_nontemporal_load(q + i);
-      r.v[4 * i] = t.x; r.v[4 * i + 1] = t.y; r.v[4 * i + 2] = t.z; r.v[4 * i + 3] = t.w;
-    }
-  } else {
-    const u32x2_t* q = reinterpret_cast<const u32x2_t*>(p);
-#pragma unroll
-    for (int i = 0; i < NL / 2; i++) {
-      u32x2_t t = __builtin_nontemporal_load(q + i);
-      r.v[2 * i] = t.x; r.v[2 * i + 1] = t.y;
-    }
-  }
-  return r;
-}
-template <int NL> LCPC_DEV void fe_store_nt(u32* __restrict__ p, const Fe<NL>& a) {
-  if constexpr (NL % 4 == 0) {
-    u32x4_t* q = reinterpret_cast<u32x4_t*>(p);
-#pragma unroll
-    for (int i = 0; i < NL / 4; i++) {
-      u32x4_t t = {a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]};
-      __builtin_nontemporal_store(t, q + i);
-    }
-  } else {
-    u32x2_t* q = reinterpret_cast<u32x2_t*>(p);
-#pragma unroll
-    for (int i = 0; i < NL / 2; i++) {
-      u32x2_t t = {a.v[2 * i], a.v[2 * i + 1]};
-      __builtin_nontemporal_store(t, q + i);
-    }
-  }
-}
-
 // ---- add / sub --------------------------------------------------------------------------------
 // r = a + b mod p; 2p < 2^(32 NL) so the plain sum never carries out.
 template <int NL> LCPC_DEV Fe<NL> fe_add(const Fe<NL>& a, const Fe<NL>& b) {

@@ -36,8 +36,6 @@ hipError_t launch_leaf_finish(uint32_t* cvs, uint32_t n_chunks, uint64_t n_cols,
 // nullptr = identity / all zero); root = false only pre-merges (no ROOT flag) into one subtree CV per column
 hipError_t launch_leaf_finish_nodes(uint32_t* cvs, const uint32_t* node_slot, const uint32_t* node_log, uint32_t n_nodes,
                                     uint64_t n_cols, uint32_t* out, bool root, hipStream_t st);
-// one Merkle layer: out[i] = D(in[2i] || in[2i+1]), n_out parents
-hipError_t launch_merkle_layer(const uint32_t* in, uint32_t* out, uint64_t n_out, hipStream_t st);
 // whole tree above the leaf layer in as few launches as possible (hashes = LcCommit.hashes, np2 leaves)
 hipError_t launch_merkle_tree(uint32_t* hashes, uint64_t np2, hipStream_t st);
 

@@ -402,20 +402,6 @@ hipError_t launch_leaf_finish_nodes(u32* cvs, const u32* node_slot, const u32* n
 // workgroup (9 layers through LDS) and writes every intermediate layer to its slot of the
 // reference's flat `hashes` array (lib.rs:656-666, 747-760).
 // =================================================================================================
-__global__ void __launch_bounds__(256) merkle_layer_kernel(const u32* in, u32* out, u64 n_out) {
-  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_out) return;
-  u32 l[8], r[8], o[8];
-  ld8(l, in + 2 * i * 8);
-  ld8(r, in + (2 * i + 1) * 8);
-  b3_hash64(o, l, r, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
-  st8(out + i * 8, o);
-}
-hipError_t launch_merkle_layer(const u32* in, u32* out, u64 n_out, hipStream_t st) {
-  hipLaunchKernelGGL(merkle_layer_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, in, out, n_out);
-  return hipGetLastError();
-}
-
 // layers: `width` nodes at `hashes + in_off*8`; each WG reduces SUB = 2^lsub consecutive nodes down
 // `lsub` layers.  Layer j (1-based) of the subtree lands at hashes[layer_off_j + wg * (SUB >> j) + ...].
 __global__ void __launch_bounds__(256) merkle_subtree_kernel(u32* hashes, u64 in_off, u64 width, u32 lsub) {
