@@ -90,37 +90,6 @@ int ligero_get_dims(const FieldDesc& f, uint64_t len, uint32_t rn, uint32_t rd, 
   if (sz1 < sz2) { *nr = nr1; *np = np1; *nc = nc1; } else { *nr = nr2; *np = np2; *nc = nc2; }
   return 0;
 }
-void roots_table(const FieldDesc& f, unsigned log_n, std::vector<uint64_t>& out) {
-  const int L = f.L;
-  uint64_t w[MAXL];
-  memcpy(w, f.rou, 8 * L);
-  for (unsigned i = 0; i < f.S - log_n; i++) h_mul(f, w, w, w);
-  const size_t half = log_n == 0 ? 1 : ((size_t)1 << log_n) / 2;
-  out.assign(half * L, 0);
-  memcpy(out.data(), f.r, 8 * L);
-  // w^i by blocks so the table can be filled by several host threads: first the powers w^(j*B)
-  const size_t B = 4096;
-  const size_t nblk = (half + B - 1) / B;
-  if (nblk <= 1) {
-    for (size_t i = 1; i < half; i++) h_mul(f, &out[i * L], &out[(i - 1) * L], w);
-    return;
-  }
-  uint64_t wB[MAXL];
-  memcpy(wB, f.r, 8 * L);
-  for (size_t i = 0; i < B; i++) h_mul(f, wB, wB, w);
-  for (size_t b = 1; b < nblk; b++) h_mul(f, &out[b * B * L], &out[(b - 1) * B * L], wB);
-  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < nt; t++)
-    th.emplace_back([&, t] {
-      for (size_t b = t; b < nblk; b += nt) {
-        const size_t e = std::min(half, (b + 1) * B);
-        for (size_t i = b * B + 1; i < e; i++) h_mul(f, &out[i * L], &out[(i - 1) * L], w);
-      }
-    });
-  for (auto& x : th) x.join();
-}
-
 // ---- Brakedown / SDIG ----------------------------------------------------------------------------------
 static double ent(double z) { return -z * std::log2(z) - (1.0 - z) * std::log2(1.0 - z); }
 bool sdig_spec(int code, SdigSpec* s) {

@@ -18,8 +18,6 @@ uint64_t ligero_n_col_opens(uint32_t rho_num, uint32_t rho_den);        // liger
 // _get_dims (ligero lib.rs:70-112): 0 on success, <0 if n_cols would exceed 2^S
 int ligero_get_dims(const FieldDesc& f, uint64_t len, uint32_t rho_num, uint32_t rho_den, uint64_t* n_rows,
                     uint64_t* n_per_row, uint64_t* n_cols);
-// precomp_fft (fffft [3P]): roots[i] = w^i, i < n/2, w = ROOT_OF_UNITY^(2^(S - log_n)); Montgomery limbs
-void roots_table(const FieldDesc& f, unsigned log_n, std::vector<uint64_t>& out);
 
 // Brakedown / SDIG
 struct SdigSpec {

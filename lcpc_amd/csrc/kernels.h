@@ -20,6 +20,10 @@ struct NttPassArgs {
 };
 hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream_t st);
 
+// device-side precomp_fft: roots[i] = w^i (i < 2^log_half) from pw[j] = w^(2^j); roots29 (Ft255) may be null
+hipError_t launch_roots(int nl, const uint32_t* pw, uint32_t log_half, const uint32_t* one, uint32_t* roots, uint32_t* roots29,
+                        hipStream_t st);
+
 struct LeafArgs {
   const uint32_t* comm;        // local rows, row-major
   uint64_t row_stride;         // elements

@@ -885,6 +885,38 @@ hipError_t launch_sdig_rs_t(int nl, const u32* in_t, u32 n_in, u32* t, u64 out_o
   return hipGetLastError();
 }
 
+// =================================================================================================
+// precomp_fft on the device: roots[i] = w^i, i < n/2, from the host-supplied squares
+// pw[j] = w^(2^j) (Montgomery).  Thread i multiplies the squares selected by the bits of i (<= log n
+// products); for Ft255 it also emits the 29-bit-limb / 2^261 form used by fe_mul_r29.
+// =================================================================================================
+template <int NL>
+__global__ void __launch_bounds__(256) roots_kernel(const u32* pw, u32 log_half, const u32* one, u32* roots, u32* roots29) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ((u64)1 << log_half)) return;
+  Fe<NL> acc = fe_load<NL>(one);
+  for (u32 j = 0; j < log_half; j++)
+    if ((i >> j) & 1) acc = fe_mul<NL>(acc, fe_load<NL>(pw + (size_t)j * NL));
+  fe_store<NL>(roots + i * NL, acc);
+  if constexpr (NL == 8) {
+    if (roots29 != nullptr) {
+      Fe<8> t = acc;
+#pragma unroll
+      for (int d = 0; d < 5; d++) t = fe_add<8>(t, t);          // * 2^5: R = 2^256 -> 2^261
+      const Fe29 x = fe_to29(t);
+#pragma unroll
+      for (int k = 0; k < 9; k++) roots29[i * 12 + k] = x.v[k];
+      roots29[i * 12 + 9] = roots29[i * 12 + 10] = roots29[i * 12 + 11] = 0;
+    }
+  }
+}
+hipError_t launch_roots(int nl, const u32* pw, u32 log_half, const u32* one, u32* roots, u32* roots29, hipStream_t st) {
+  const u64 n = (u64)1 << log_half;
+  dim3 grid((unsigned)((n + 255) / 256));
+  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(roots_kernel<NLV>, grid, dim3(256), 0, st, pw, log_half, one, roots, roots29));
+  return hipGetLastError();
+}
+
 template <int NL>
 __global__ void __launch_bounds__(256) pad_rows_kernel(const u32* src, u64 src_stride, u32* dst, u64 dst_stride, u64 n_valid) {
   const u64 row = blockIdx.y;

@@ -519,17 +519,28 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
     if (!(np_ < nc) || (nc & (nc - 1)) || log2_ceil(nc) > f->S) { delete c; return LCPC_ERR_DIMS; }   // _dims_ok + precomp_fft
     if (log2_ceil(nc) > 30) { delete c; return LCPC_ERR_TOO_BIG; }      // device kernels index a row with 32 bits
     c->n_per_row = np_; c->n_cols = nc; c->log_n = (unsigned)log2_ceil(nc);
-    std::vector<uint64_t> roots;
-    roots_table(*f, c->log_n, roots);
-    if ((rc = dev_alloc(c, &c->d_roots, roots.size() * 8))) { lcpc_ctx_destroy(c); return rc; }
-    if (hipMemcpy(c->d_roots, roots.data(), roots.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
-    if (f->L == 4) {
-      // w*R (R = 2^256) -> w*2^261 mod p (five doublings), split into 9 limbs of 29 bits, 12-word stride
-      const size_t nroots = roots.size() / 4;
-      std::vector<uint32_t> r29(nroots * 12, 0);
-      for (size_t i = 0; i < nroots; i++) to_r29(*f, &roots[i * 4], &r29[i * 12]);
-      if ((rc = dev_alloc(c, &c->d_roots29, r29.size() * 4))) { lcpc_ctx_destroy(c); return rc; }
-      if (hipMemcpy(c->d_roots29, r29.data(), r29.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
+    {
+      // precomp_fft (fffft [3P]): w = ROOT_OF_UNITY^(2^(S - log_n)); the host only computes the log_n - 1 squares
+      // w^(2^j), the n/2-entry tables are filled on the device (kernels.hip roots_kernel)
+      const unsigned log_half = c->log_n ? c->log_n - 1 : 0;
+      const size_t n_roots = (size_t)1 << log_half;
+      std::vector<uint64_t> pw((size_t)(log_half + 1) * f->L);
+      uint64_t w[MAXL];
+      memcpy(w, f->rou, 8 * f->L);
+      for (unsigned i = 0; i < f->S - c->log_n; i++) h_mul(*f, w, w, w);
+      for (unsigned j = 0; j <= log_half; j++) { memcpy(&pw[(size_t)j * f->L], w, 8 * f->L); h_mul(*f, w, w, w); }
+      uint32_t *d_pw = nullptr, *d_one = nullptr;
+      if ((rc = dev_alloc(c, &d_pw, pw.size() * 8)) || (rc = dev_alloc(c, &d_one, 8 * f->L)) ||
+          (rc = dev_alloc(c, &c->d_roots, n_roots * 8 * f->L)) ||
+          (f->L == 4 && (rc = dev_alloc(c, &c->d_roots29, n_roots * 48)))) {
+        dev_free(d_pw); dev_free(d_one); lcpc_ctx_destroy(c); return rc;
+      }
+      hipError_t he = hipMemcpy(d_pw, pw.data(), pw.size() * 8, hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = hipMemcpy(d_one, f->r, 8 * f->L, hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = launch_roots(c->NL, d_pw, log_half, d_one, c->d_roots, c->d_roots29, nullptr);
+      if (he == hipSuccess) he = hipDeviceSynchronize();
+      dev_free(d_pw); dev_free(d_one);
+      if (he != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
     }
     plan_passes(c);
   } else if (p->encoding == LCPC_ENC_SDIG) {
