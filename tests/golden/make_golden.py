@@ -45,6 +45,7 @@ def commit_case(name, F, enc, enc_desc, n, kind, seed, with_proof=True):
                comm_sha256=hashlib.sha256(mont_bytes(F, c.comm)).hexdigest(),
                hashes_sha256=hashlib.sha256(b"".join(c.hashes)).hexdigest(),
                comm_head=[hex(F.to_mont(v)) for v in c.comm[:4]],
+               comm_row0_col1_repr=F.to_repr(c.comm[1]).hex(),
                leaf0=c.hashes[0].hex())
     if with_proof:
         x = 0x1234567 % F.p
@@ -56,6 +57,7 @@ def commit_case(name, F, enc, enc_desc, n, kind, seed, with_proof=True):
         ev = P.verify(F, c.get_root(), outer, inner, pf, enc, mk_tr(c.get_root(), enc.get_n_col_opens()))
         assert ev == sum(cf * pow(x, i, F.p) for i, cf in enumerate(coeffs)) % F.p
         out.update(eval_point=hex(x), proof_len=len(ser), proof_sha256=hashlib.sha256(ser).hexdigest(),
+                   proof_blake3=P.blake3(ser).hex(),
                    cols_opened_head=cols[:8], eval=hex(ev),
                    p_eval_head=[hex(F.to_mont(v)) for v in pf.p_eval[:2]])
     return out
