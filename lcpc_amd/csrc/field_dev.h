@@ -355,38 +355,17 @@ LCPC_DEV void fe_from29(u32 out[8], const u32 l[9]) {
     out[w] = x;
   }
 }
+#include "field_r29_gen.h"   // r29_columns(): the 153-mad Comba/Montgomery chain as generated asm blocks
+
 // r = a * b29 * 2^-261 mod p, fully reduced, packed.  a: packed element < p; b29: 9 limbs < 2^29.
 LCPC_DEV Fe<8> fe_mul_r29(const Fe<8>& a, const Fe29& b) {
   const Fe29 x = fe_to29(a);
   u32 m[9], r[9];
-  u64 acc = 0;
-#pragma unroll
-  for (int k = 0; k < 17; k++) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (j >= 0 && j < 9) acc += (u64)x.v[i] * b.v[j];
-    }
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (i < k && j >= 1 && j < 9) acc += (u64)m[i] * P29::limb(j);
-    }
-    if (k < 9) {
-      m[k] = (0u - (u32)acc) & P29::M;
-      acc += m[k];                    // + m_k * p_0, p_0 = 1: low 29 bits become zero
-      acc >>= 29;
-    } else {
-      r[k - 9] = (u32)acc & P29::M;
-      acc >>= 29;
-    }
-  }
-  r[8] = (u32)acc;
+  r29_columns(x.v, b.v, m, r);
   u32 t[8];
   fe_from29(t, r);
   return fe_reduce_once8(t);           // REDC output < 2p < 2^256
 }
-
 
 // Montgomery form (R = 2^256) -> canonical value for Ft255, reduction only: a * 2^-256 = REDC_261(a * 2^5).
 // The "product" a << 5 needs no multiplies; the 9-step reduction is 72 v_mad_u64_u32, carry-free.

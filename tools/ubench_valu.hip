@@ -76,6 +76,7 @@ int main(){
     run(k_mad_u64_u32,"v_mad_u64_u32",8,w,d); run(k_mad_addc,"mad_u64+addc (pairs)",4,w,d); run(k_mad_dep,"v_mad_u64_u32 dep",8,w,d);
     run(k_mul_lo_u32,"v_mul_lo_u32",8,w,d); run(k_mul_hi_u32,"v_mul_hi_u32",8,w,d);
     run(k_mul_u32_u24,"v_mul_u32_u24",8,w,d); run(k_mul_hi_u32_u24,"v_mul_hi_u32_u24",8,w,d); run(k_mad_u32_u24,"v_mad_u32_u24",8,w,d);
+    run(k_add_u32,"v_add_u32",8,w,d); run(k_xor_b32,"v_xor_b32",8,w,d); run(k_add3_u32,"v_add3_u32",8,w,d); run(k_alignbit,"v_alignbit_b32",8,w,d);
     run(k_lshl_add_u64,"v_lshl_add_u64",8,w,d); run(k_fma_f32,"v_fma_f32",8,w,d); run(k_fma_f64,"v_fma_f64",8,w,d);
   }
   return 0;
