@@ -11,6 +11,7 @@ struct NttPassArgs {
   uint32_t* dst;           // row-major, dst_stride elements per row (may alias src when strides match)
   const uint32_t* roots;   // roots[i] = w^i (Montgomery), i < n/2
   const uint32_t* roots29; // Ft255 only: w^i * 2^261 mod p as 9 x 29-bit limbs, 12-word stride (fe_mul_r29)
+  const uint32_t* qp29;    // Ft255 only: q*p (q < 32) as 9 x 29-bit limbs, 12-word stride; non-null selects the lazy-limb kernel
   uint64_t src_stride, dst_stride;
   uint64_t n_valid;        // elements >= n_valid of every src row read as zero (fused zero padding)
   uint64_t n_src_total;    // flat src elements >= n_src_total read as zero (ragged last row)

@@ -202,6 +202,169 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
   for (u32 e = tid; e < T; e += 256) fe_store<NL>(dst + (size_t)gindex(e) * NL, lds_get<NL, LT>(lds, e));
 }
 
+// -------------------------------------------------------------------------------------------------
+// Ft255 variant on lazy 9 x 29-bit limbs (field_dev.h, namespace l9): same tiling, rounds and twiddle indexing as
+// ntt_pass_kernel, but the tile lives in LDS in the multiplier's own limb format (36 B per element), add/sub are
+// plain limb operations and exact reduction + packing happen once, at the tile store.  Bounds: see l9.
+// -------------------------------------------------------------------------------------------------
+template <int LT> struct Lds9 {
+  static constexpr u32 T = 1u << LT;
+  static constexpr u32 WORDS = T * 9 + 32 * 12;              // tile + q*p table (32 entries, 12-word stride)
+};
+template <int LT> __device__ __forceinline__ L9 lds9_get(const u32* lds, u32 e) {
+  const uint4 a = *reinterpret_cast<const uint4*>(lds + (size_t)e * 4);
+  const uint4 b = *reinterpret_cast<const uint4*>(lds + ((size_t)Lds9<LT>::T + e) * 4);
+  L9 r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  r.v[8] = lds[(size_t)Lds9<LT>::T * 8 + e];
+  return r;
+}
+template <int LT> __device__ __forceinline__ void lds9_put(u32* lds, u32 e, const L9& x) {
+  *reinterpret_cast<uint4*>(lds + (size_t)e * 4) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+  *reinterpret_cast<uint4*>(lds + ((size_t)Lds9<LT>::T + e) * 4) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+  lds[(size_t)Lds9<LT>::T * 8 + e] = x.v[8];
+}
+
+template <int LT>
+__global__ void __launch_bounds__(256) ntt_pass_l9_kernel(NttPassArgs a) {
+  constexpr int NL = 8;
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  u32* qp = lds + (size_t)Lds9<LT>::T * 9;                   // q*p table copy
+  const u32 k = a.log_n, t0 = a.t0, s = a.s, ltj = a.log_tj;
+  const u32 lb = k - t0 - s;
+  const u32 lbt = lb < ltj ? lb : ltj;
+  const u32 T = 1u << (s + ltj);
+  const u32 tiles_per_row = 1u << (k - s - ltj);
+  u64 row;
+  u32 tile;
+  if (tiles_per_row >= 8) {                                  // XCD-aware order, as in ntt_pass_kernel
+    const u32 xcd = blockIdx.x & 7u;
+    const u64 q = blockIdx.x >> 3;
+    tile = (u32)(q / a.n_rows) * 8u + xcd;
+    row = q % a.n_rows;
+  } else {
+    row = blockIdx.x / tiles_per_row;
+    tile = blockIdx.x % tiles_per_row;
+  }
+  const u32 o0 = tile << ltj;
+  const u32 tid = threadIdx.x;
+  const u32 lp_mask = (1u << lbt) - 1, i_mask = (1u << s) - 1;
+  const u32 lo_mask = (1u << lb) - 1;
+  auto gindex = [&](u32 e) -> u32 {
+    const u32 lp = e & lp_mask, i = (e >> lbt) & i_mask, hp = e >> (lbt + s);
+    const u32 outer = o0 | (hp << lbt) | lp;
+    return ((outer >> lb) << (lb + s)) | (i << lb) | (outer & lo_mask);
+  };
+
+  for (u32 i = tid; i < 32 * 12; i += 256) qp[i] = a.qp29[i];
+  const u32* src = a.src + row * a.src_stride * NL;
+  for (u32 e = tid; e < T; e += 256) {
+    const u32 g = gindex(e);
+    const Fe<NL> v = (g < a.n_valid && row * a.src_stride + g < a.n_src_total) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
+    lds9_put<LT>(lds, e, l9::from_packed(v));
+    if (a.copy_dst != nullptr && g < a.n_valid) fe_store<NL>(a.copy_dst + (row * a.src_stride + g) * NL, v);
+  }
+  __syncthreads();
+
+  constexpr u32 B29 = 1u << 29, B30 = 1u << 30;
+  u32 u = 0;
+  for (; u + 1 < s; u += 2) {
+    const u32 t = t0 + u;
+    const u32 hb = s - u - 1;
+    const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
+    const bool last_two = (t + 2 == k);
+    for (u32 q = tid; q < T / 4; q += 256) {
+      const u32 lp = q & lp_mask;
+      const u32 j = (q >> lbt) & (i_mask >> 2);
+      const u32 hp = q >> (lbt + s - 2);
+      const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+      const u32 e0 = (((hp << s) | i0) << lbt) | lp;
+      const u32 dq = 1u << (hb - 1 + lbt);
+      const u32 g0 = gindex(e0), g1 = gindex(e0 + dq);
+      const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
+      const L9 x2 = lds9_get<LT>(lds, e0 + 2 * dq), x3 = lds9_get<LT>(lds, e0 + 3 * dq);   // I: limbs < 2^29, value < 4p
+      const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);                                 // limbs < 2^30, value < 8p
+      L9 c0 = l9::add(b0, b1);                                                             // limbs < 2^31, value < 16p
+      l9::normalize(c0);
+      if (last_two) {
+        // stages k-2, k-1: twiddles 1, w^(n/4), 1 -- outputs go straight to the store path (normalised, value < 32p)
+        const Tw<NL> wq = tw_load<NL>(a, 1u << (k - 2));
+        L9 c1 = l9::sub_bias<9, B30>(b0, b1);                                              // value < 17p
+        const L9 b2 = l9::sub_bias<5, B29>(x0, x2);                                        // limbs < 1.5*2^30, value < 9p
+        const L9 b3 = l9::mul(l9::sub_bias<5, B29>(x1, x3), wq.w);                         // normalised, < 2p
+        L9 c2 = l9::add(b2, b3);                                                           // value < 11p
+        L9 c3 = l9::sub_bias<3, B29>(b2, b3);                                              // value < 12p
+        l9::normalize(c1); l9::normalize(c2); l9::normalize(c3);
+        lds9_put<LT>(lds, e0, c0);
+        lds9_put<LT>(lds, e0 + dq, c1);
+        lds9_put<LT>(lds, e0 + 2 * dq, c2);
+        lds9_put<LT>(lds, e0 + 3 * dq, c3);
+      } else {
+        const Tw<NL> w0 = tw_load<NL>(a, (g0 & gm0) << t);
+        const Tw<NL> w1 = tw_load<NL>(a, (g1 & gm0) << t);
+        const Tw<NL> w2 = tw_load<NL>(a, (g0 & gm1) << (t + 1));
+        l9::clamp(c0, qp);                                                                 // < 2p
+        lds9_put<LT>(lds, e0, c0);
+        const L9 c1 = l9::mul(l9::sub_bias<9, B30>(b0, b1), w2.w);                         // in: limbs < 2.5*2^30, value < 17p
+        lds9_put<LT>(lds, e0 + dq, c1);                                                    // normalised, < 2p
+        const L9 b2 = l9::mul(l9::sub_bias<5, B29>(x0, x2), w0.w);                         // in: value < 9p; out < 2p
+        const L9 b3 = l9::mul(l9::sub_bias<5, B29>(x1, x3), w1.w);
+        L9 c2 = l9::add(b2, b3);                                                           // limbs < 2^30, value < 4p
+        l9::normalize(c2);
+        lds9_put<LT>(lds, e0 + 2 * dq, c2);
+        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub_bias<3, B29>(b2, b3), w2.w));
+      }
+    }
+    __syncthreads();
+  }
+  for (; u < s; u++) {                                        // radix-2 tail when s is odd
+    const u32 t = t0 + u;
+    const u32 hb = s - u - 1;
+    const u32 gm = (1u << (k - t - 1)) - 1;
+    for (u32 q = tid; q < T / 2; q += 256) {
+      const u32 lp = q & lp_mask;
+      const u32 j = (q >> lbt) & (i_mask >> 1);
+      const u32 hp = q >> (lbt + s - 1);
+      const u32 i = ((j >> hb) << (hb + 1)) | (j & ((1u << hb) - 1));
+      const u32 e1 = (((hp << s) | i) << lbt) | lp;
+      const u32 e2 = e1 + (1u << (hb + lbt));
+      const u32 widx = (gindex(e1) & gm) << t;
+      const L9 x = lds9_get<LT>(lds, e1), y = lds9_get<LT>(lds, e2);
+      L9 sum = l9::add(x, y);                                                              // value < 8p
+      l9::normalize(sum);
+      l9::clamp(sum, qp);                                                                  // < 2p
+      lds9_put<LT>(lds, e1, sum);
+      L9 d = l9::sub_bias<5, B29>(x, y);                                                   // value < 9p
+      if (t + 1 == k) {
+        l9::normalize(d);                                                                  // last stage: twiddle 1
+        lds9_put<LT>(lds, e2, d);
+      } else {
+        const Tw<NL> w = tw_load<NL>(a, widx);
+        lds9_put<LT>(lds, e2, l9::mul(d, w.w));
+      }
+    }
+    __syncthreads();
+  }
+
+  u32* dst = a.dst + row * a.dst_stride * NL;
+  for (u32 e = tid; e < T; e += 256) fe_store<NL>(dst + (size_t)gindex(e) * NL, l9::to_packed_reduced(lds9_get<LT>(lds, e), qp));
+}
+
+template <int LT>
+static hipError_t launch_ntt_pass_l9_t(const NttPassArgs& a, hipStream_t st) {
+  const u64 tiles = ((u64)1 << (a.log_n - a.s - a.log_tj)) * a.n_rows;
+  const size_t lds_bytes = (size_t)Lds9<LT>::WORDS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_l9_kernel<LT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ntt_pass_l9_kernel<LT>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
+}
+
 template <int NL, int LT>
 static hipError_t launch_ntt_pass_t(const NttPassArgs& a, hipStream_t st) {
   const u64 tiles = ((u64)1 << (a.log_n - a.s - a.log_tj)) * a.n_rows;
@@ -218,6 +381,11 @@ static hipError_t launch_ntt_pass_t(const NttPassArgs& a, hipStream_t st) {
 }
 hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream_t st) {
   if (a.s + a.log_tj > (uint32_t)log_tile) return hipErrorInvalidValue;
+  if (nl == 8 && a.qp29 != nullptr) {        // Ft255: lazy 9-limb pipeline
+    if (log_tile == 10) return launch_ntt_pass_l9_t<10>(a, st);
+    if (log_tile == 11) return launch_ntt_pass_l9_t<11>(a, st);
+    return hipErrorInvalidValue;
+  }
 #define NTT_CASE(NLV, LTV) if (nl == NLV && log_tile == LTV) return launch_ntt_pass_t<NLV, LTV>(a, st);
   NTT_CASE(2, 10) NTT_CASE(4, 10) NTT_CASE(6, 10) NTT_CASE(8, 10)
   NTT_CASE(2, 11) NTT_CASE(4, 11) NTT_CASE(6, 11) NTT_CASE(8, 11)

@@ -86,6 +86,7 @@ struct lcpc_ctx {
   unsigned log_n = 0;
   uint32_t* d_roots = nullptr;
   uint32_t* d_roots29 = nullptr;   // Ft255: twiddles in radix-2^29 / R'=2^261 Montgomery form (field_dev.h fe_mul_r29)
+  uint32_t* d_qp29 = nullptr;      // Ft255: q*p, q < 32, as 29-bit limbs (l9::clamp); null = packed-form NTT kernel
   std::vector<Pass> passes;
   // Brakedown
   SdigSpec spec{};
@@ -263,6 +264,7 @@ int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, ui
       a.dst = dst;
       a.roots = c->d_roots;
       a.roots29 = c->d_roots29;
+      a.qp29 = c->d_qp29;
       a.src_stride = first ? src_stride : c->n_cols;
       a.dst_stride = c->n_cols;
       a.n_valid = first ? n_valid : c->n_cols;
@@ -542,6 +544,23 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
       dev_free(d_pw); dev_free(d_one);
       if (he != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
     }
+    if (f->L == 4 && !getenv("LCPC_NTT_PACKED")) {
+      // q * p for q < 32 as canonical 29-bit limbs: the table behind l9::clamp (lazy-limb NTT kernel)
+      std::vector<uint32_t> tab(32 * 12, 0);
+      uint64_t acc[5] = {0, 0, 0, 0, 0};
+      for (int q = 0; q < 32; q++) {
+        for (int k = 0; k < 9; k++) {
+          const int b = 29 * k, w = b / 64, sh = b % 64;
+          uint64_t x = acc[w] >> sh;
+          if (sh > 35) x |= acc[w + 1] << (64 - sh);
+          tab[q * 12 + k] = (uint32_t)(x & ((1u << 29) - 1));
+        }
+        unsigned __int128 cy = 0;
+        for (int w = 0; w < 5; w++) { cy += (unsigned __int128)acc[w] + (w < 4 ? f->p[w] : 0); acc[w] = (uint64_t)cy; cy >>= 64; }
+      }
+      if ((rc = dev_alloc(c, &c->d_qp29, tab.size() * 4))) { lcpc_ctx_destroy(c); return rc; }
+      if (hipMemcpy(c->d_qp29, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
+    }
     plan_passes(c);
   } else if (p->encoding == LCPC_ENC_SDIG) {
     if (!sdig_spec((int)c->prm.sdig_code, &c->spec)) { delete c; return LCPC_ERR_ARG; }
@@ -593,7 +612,7 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
 void lcpc_ctx_destroy(lcpc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->prm.device);
-  dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_r2); dev_free(c->d_tmp); dev_free(c->d_t);
+  dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_qp29); dev_free(c->d_r2); dev_free(c->d_tmp); dev_free(c->d_t);
   for (auto* v : {&c->d_pre, &c->d_post})
     for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); dev_free(d.vals29); }
   dev_free(c->d_coeffs); dev_free(c->d_comm); dev_free(c->d_hashes); dev_free(c->d_cvs); dev_free(c->d_scratch); dev_free(c->d_node_tab); dev_free(c->d_t29);

@@ -170,3 +170,28 @@ def test_rate_variants_2e20(oracle):
                 h = O.blake3(h + bytes(p)) if cn % 2 == 0 else O.blake3(bytes(p) + h)
                 cn >>= 1
             assert h == root
+
+
+def test_lazy_limb_ntt_range_stress(oracle):
+    """The Ft255 NTT keeps elements loosely reduced (value < 4p, 29-bit limbs) between stages and relies on bias
+    constants / a quotient-estimate clamp (field_dev.h, namespace l9).  Inputs chosen to push every bound: rows of
+    all p-1, all (p-1)/2, alternating 0 / p-1, and limbs with all 29-bit fields saturated -- at n_cols = 2^12 (one
+    pass), 2^13 (two passes) and 2^18 (the headline row: 4+5 radix-4 rounds), rates 1/2 and 38/39 (n_per_row not a
+    power of two).  Bit-exact against the oracle."""
+    import pyref as P
+    O = oracle
+    F = P.FT255
+    sat = sum(((1 << 29) - 1) << (29 * k) for k in range(9)) % F.p
+    pats = [[F.p - 1], [(F.p - 1) // 2], [0, F.p - 1], [sat, F.p - 2, 1], [F.p - 1, F.p - 1, F.p - 1, 0]]
+    for log_n, n_per_row in ((12, 2048), (13, 4096), (13, 7983), (18, 131072)):
+        n = 1 << log_n
+        enc = LigeroEncoding.new_from_dims(3, n_per_row, n)
+        oenc = O.Encoding.ligero_from_dims(3, n_per_row, n)
+        rows = np.zeros((len(pats), n, 4), np.uint64)
+        for r, pat in enumerate(pats):
+            m = O.to_mont(3, pat)
+            reps = (n_per_row + len(pat) - 1) // len(pat)
+            rows[r, :n_per_row] = np.tile(m, (reps, 1))[:n_per_row]
+        got = enc.encode(rows).reshape(len(pats), n, 4)
+        for r in range(len(pats)):
+            assert (got[r] == oenc.encode(rows[r].copy())).all(), (log_n, n_per_row, r)
