@@ -174,11 +174,11 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
         pmc = json.load(open(pmc_path))
         for kname, v in pmc["kernels"].items():
-            if kname.startswith("ntt_pass_kernel<8"):
+            if kname.startswith("ntt_pass"):
                 traffic = round((2.0 * v["FETCH_KB"] + v["WRITE_KB"]) * 1024 / 1e9, 3)
                 traffic_src = "profiles/r01_pmc_latest.json (rocprofv3 --pmc; GB per launch = 2*FETCH_SIZE + WRITE_SIZE; " \
                               "2-pass NTT: each pass reads+writes the matrix, pass 1 also writes LcCommit.coeffs)"
-    roofline = {"bound": "hbm", "kernel": "ntt_pass_kernel<8,*> (row NTT, %d launches per commit)" % ntt_launches,
+    roofline = {"bound": "hbm", "kernel": "ntt_pass_l9_kernel (row NTT, Ft255 lazy-limb variant; %d launches per commit)" % ntt_launches,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_unit": "GB/launch", "traffic_source": traffic_src,
                 "algorithmic_GB_per_launch": round(enc_bytes / ntt_launches / 1e9, 3),

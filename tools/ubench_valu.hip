@@ -47,6 +47,23 @@ KERNEL(k_mad_u32_u24, DECL8, OP8_3("v_mad_u32_u24"), a0^a1^a2^a3^a4^a5^a6^a7)
 KERNEL(k_alignbit, DECL8, OP8_3("v_alignbit_b32"), a0^a1^a2^a3^a4^a5^a6^a7)
 KERNEL(k_add3_u32, DECL8, OP8_3("v_add3_u32"), a0^a1^a2^a3^a4^a5^a6^a7)
 KERNEL(k_fma_f32, DECL8, OP8_3("v_fma_f32"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_and_b32, DECL8, OP8("v_and_b32"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_lshrrev_b32, DECL8, asm volatile("v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 3, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3\n v_lshrrev_b32 %4, 3, %4\n v_lshrrev_b32 %5, 3, %5\n v_lshrrev_b32 %6, 3, %6\n v_lshrrev_b32 %7, 3, %7\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7)), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_bfe_u32, DECL8, asm volatile("v_bfe_u32 %0, %0, 3, 29\n v_bfe_u32 %1, %1, 3, 29\n v_bfe_u32 %2, %2, 3, 29\n v_bfe_u32 %3, %3, 3, 29\n v_bfe_u32 %4, %4, 3, 29\n v_bfe_u32 %5, %5, 3, 29\n v_bfe_u32 %6, %6, 3, 29\n v_bfe_u32 %7, %7, 3, 29\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7)), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_lshl_or_b32, DECL8, asm volatile("v_lshl_or_b32 %0, %0, 3, %8\n v_lshl_or_b32 %1, %1, 3, %8\n v_lshl_or_b32 %2, %2, 3, %8\n v_lshl_or_b32 %3, %3, 3, %8\n v_lshl_or_b32 %4, %4, 3, %8\n v_lshl_or_b32 %5, %5, 3, %8\n v_lshl_or_b32 %6, %6, 3, %8\n v_lshl_or_b32 %7, %7, 3, %8\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x)), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_cndmask, DECL8, asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x) : "vcc"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_cndmask_cmp, DECL8, asm volatile("v_cmp_gt_u32 vcc, %8, %0\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x) : "vcc"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_cndmask_e64, DECL8; u64 msk = 0x5555aaaa5555aaaaull, asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x), "s"(msk)), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_sel_arith, DECL8; u32 mk = y, asm volatile("v_xor_b32 %0, %0, %8\n v_and_b32 %0, %0, %9\n v_xor_b32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_and_b32 %1, %1, %9\n v_xor_b32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_and_b32 %2, %2, %9\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x), "v"(mk)), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_addc_chain, DECL8, asm volatile("v_add_co_u32 %0, vcc, %0, %8\n v_addc_co_u32 %1, vcc, %1, %8, vcc\n v_addc_co_u32 %2, vcc, %2, %8, vcc\n v_addc_co_u32 %3, vcc, %3, %8, vcc\n v_addc_co_u32 %4, vcc, %4, %8, vcc\n v_addc_co_u32 %5, vcc, %5, %8, vcc\n v_addc_co_u32 %6, vcc, %6, %8, vcc\n v_addc_co_u32 %7, vcc, %7, %8, vcc\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x) : "vcc"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_lshrrev_b64, u64 a0=x;u64 a1=y;u64 a2=x+1;u64 a3=y+1;u64 a4=x+2;u64 a5=y+2;u64 a6=x+3;u64 a7=y+3,
+  asm volatile("v_lshrrev_b64 %0, 1, %0\n v_lshrrev_b64 %1, 1, %1\n v_lshrrev_b64 %2, 1, %2\n v_lshrrev_b64 %3, 1, %3\n v_lshrrev_b64 %4, 1, %4\n v_lshrrev_b64 %5, 1, %5\n v_lshrrev_b64 %6, 1, %6\n v_lshrrev_b64 %7, 1, %7\n"
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7)),
+  (u32)(a0^a1^a2^a3^a4^a5^a6^a7))
+KERNEL(k_mad_snop, u64 a0=x;u64 a1=y;u64 a2=x+1;u64 a3=y+1,
+  asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n s_nop 0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n s_nop 0\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n s_nop 0\n v_mad_u64_u32 %3, vcc, %4, %5, %3\n s_nop 0\n"
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3) : "v"(x),"v"(y) : "vcc"),
+  (u32)(a0^a1^a2^a3))
 #define DECL8D double a0=x;double a1=y;double a2=x+1;double a3=y+1;double a4=x+2;double a5=y+2;double a6=x+3;double a7=y+3; double dx=1.0+1e-9*x; double dy=1e-9*y
 KERNEL(k_fma_f64, DECL8D,
   asm volatile("v_fma_f64 %0, %8, %0, %9\n v_fma_f64 %1, %8, %1, %9\n v_fma_f64 %2, %8, %2, %9\n v_fma_f64 %3, %8, %3, %9\n v_fma_f64 %4, %8, %4, %9\n v_fma_f64 %5, %8, %5, %9\n v_fma_f64 %6, %8, %6, %9\n v_fma_f64 %7, %8, %7, %9\n"
@@ -77,6 +94,8 @@ int main(){
     run(k_mul_lo_u32,"v_mul_lo_u32",8,w,d); run(k_mul_hi_u32,"v_mul_hi_u32",8,w,d);
     run(k_mul_u32_u24,"v_mul_u32_u24",8,w,d); run(k_mul_hi_u32_u24,"v_mul_hi_u32_u24",8,w,d); run(k_mad_u32_u24,"v_mad_u32_u24",8,w,d);
     run(k_add_u32,"v_add_u32",8,w,d); run(k_xor_b32,"v_xor_b32",8,w,d); run(k_add3_u32,"v_add3_u32",8,w,d); run(k_alignbit,"v_alignbit_b32",8,w,d);
+    run(k_and_b32,"v_and_b32",8,w,d); run(k_lshrrev_b32,"v_lshrrev_b32",8,w,d); run(k_bfe_u32,"v_bfe_u32",8,w,d); run(k_lshl_or_b32,"v_lshl_or_b32",8,w,d);
+    run(k_cndmask,"v_cndmask_b32 (vcc)",8,w,d); run(k_cndmask_cmp,"v_cmp + 8 cndmask(vcc)",9,w,d); run(k_cndmask_e64,"v_cndmask_b32_e64 sgpr",8,w,d); run(k_sel_arith,"xor/and/xor select",8,w,d); run(k_addc_chain,"v_addc_co_u32 chain",8,w,d); run(k_lshrrev_b64,"v_lshrrev_b64",8,w,d); run(k_mad_snop,"mad_u64 + s_nop 0",4,w,d);
     run(k_lshl_add_u64,"v_lshl_add_u64",8,w,d); run(k_fma_f32,"v_fma_f32",8,w,d); run(k_fma_f64,"v_fma_f64",8,w,d);
   }
   return 0;
