@@ -893,7 +893,8 @@ hipError_t launch_sdig_rs(int nl, const u32* in, u64 in_stride, u32 n_in, u32* m
 // n_rows * F byte run.  Two tiled transposes (in: message, out: whole codeword) bracket the level chain.
 // =================================================================================================
 template <int NL>
-__global__ void __launch_bounds__(256) transpose_to_t_kernel(const u32* src, u64 src_stride, u64 n_valid, u64 n_rows, u32* t) {
+__global__ void __launch_bounds__(256) transpose_to_t_kernel(const u32* src, u64 src_stride, u64 n_valid, u64 n_rows, u32* t,
+                                                            u64 n_src_total, u32* copy_dst) {
   // tile: 32 positions x 32 rows; LDS holds it row-major with a one-element pad
   __shared__ u32 tile[32 * 33 * NL];
   const u64 p0 = (u64)blockIdx.x * 32, r0 = (u64)blockIdx.y * 32;
@@ -901,7 +902,10 @@ __global__ void __launch_bounds__(256) transpose_to_t_kernel(const u32* src, u64
   for (u32 rr = ty; rr < 32; rr += 8) {
     const u64 r = r0 + rr, p = p0 + tx;
     if (r < n_rows && p < n_valid) {
-      const Fe<NL> v = fe_load<NL>(src + (r * src_stride + p) * NL);
+      // flat source elements >= n_src_total read as zero (ragged last row); the padded LcCommit.coeffs copy
+      // (lcpc-2d lib.rs:636-645) is written here, where every message element is loaded exactly once
+      const Fe<NL> v = (r * src_stride + p < n_src_total) ? fe_load<NL>(src + (r * src_stride + p) * NL) : fe_zero<NL>();
+      if (copy_dst != nullptr) fe_store<NL>(copy_dst + (r * src_stride + p) * NL, v);
 #pragma unroll
       for (int w = 0; w < NL; w++) tile[(rr * 33 + tx) * NL + w] = v.v[w];
     }
@@ -949,10 +953,12 @@ __global__ void __launch_bounds__(256) transpose_from_t_kernel(const u32* t, u64
     case 8: { constexpr int NLV = 8; CALL; } break; \
     default: return hipErrorInvalidValue;          \
   }
-hipError_t launch_transpose_to_t(int nl, const u32* src, u64 src_stride, u64 n_valid, u64 n_rows, u32* t, hipStream_t st) {
+hipError_t launch_transpose_to_t(int nl, const u32* src, u64 src_stride, u64 n_valid, u64 n_rows, u32* t, hipStream_t st,
+                                 u64 n_src_total, u32* copy_dst) {
   if (!n_valid || !n_rows) return hipSuccess;
   dim3 grid((unsigned)((n_valid + 31) / 32), (unsigned)((n_rows + 31) / 32));
-  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(transpose_to_t_kernel<NLV>, grid, dim3(256), 0, st, src, src_stride, n_valid, n_rows, t));
+  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(transpose_to_t_kernel<NLV>, grid, dim3(256), 0, st, src, src_stride, n_valid, n_rows, t,
+                                          n_src_total, copy_dst));
   return hipGetLastError();
 }
 hipError_t launch_transpose_from_t(int nl, const u32* t, u64 n_pos, u64 n_rows, u32* dst, u64 dst_stride, hipStream_t st) {

@@ -299,7 +299,7 @@ int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, ui
       if (rc) return rc;
       c->t_cap = need;
     }
-    HIPCHK(c, launch_transpose_to_t(c->NL, src, src_stride, n_valid, n_rows, c->d_t, st));
+    HIPCHK(c, launch_transpose_to_t(c->NL, src, src_stride, n_valid, n_rows, c->d_t, st, n_src_total, copy_dst));
     c->launches[0]++;
     uint64_t in_start = 0;
     SpmmTArgs a{};
@@ -675,9 +675,10 @@ int lcpc_commit_device(lcpc_ctx* c, const uint64_t* coeffs_dev, uint64_t n_coeff
   int rc = set_rows(c, n_coeffs);
   if (rc) return rc;
   const size_t eb = elem_bytes(c);
-  if (c->prm.encoding == LCPC_ENC_LIGERO) {
+  if (c->prm.encoding == LCPC_ENC_LIGERO || c->n_rows >= 16) {
     // the padded local copy of coeffs (lib.rs:636-645; LcCommit keeps it for prove) is written by the first
-    // NTT pass while it streams the caller's buffer: no separate D2D copy
+    // NTT pass (Ligero) / the input transpose (Brakedown, >= 16 rows) while it streams the caller's buffer:
+    // no separate D2D copy
     return commit_resident(c, st, root, reinterpret_cast<const uint32_t*>(coeffs_dev), n_coeffs);
   }
   HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs_dev, (size_t)n_coeffs * eb, hipMemcpyDeviceToDevice, st));

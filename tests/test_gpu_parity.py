@@ -365,3 +365,24 @@ def test_commit_host_pipelined_vs_oracle(oracle):
     # and again on the same context (stream/event reuse), different data
     coeffs2 = O.random_elems(3, n, 56)
     assert LcCommit.commit(coeffs2, enc).get_root() == O.Commit.commit(coeffs2, oenc, n_threads=8).get_root()
+
+
+def test_brakedown_commit_device_fused_copy(oracle):
+    """lcpc_commit_device on the position-major Brakedown path: the padded LcCommit.coeffs copy is written by the
+    input transpose straight from the caller's (ragged) device buffer."""
+    import torch
+    O = oracle
+    for fid, n_per_row, n_rows in ((3, 300, 40), (0, 500, 33)):
+        oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 7, 3)
+        _, _, n_cols = oenc.get_dims(n_per_row)
+        n = n_per_row * n_rows - 11
+        coeffs = O.random_elems(fid, n, 61)
+        enc = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 7, 3)
+        LcCommit.commit(O.random_elems(fid, n_per_row * (n_rows + 2), 62), enc)      # poison buffers with a longer commit
+        dev = torch.from_numpy(coeffs.view(np.int64)).cuda()
+        c = LcCommit.commit_device(dev.data_ptr(), n, enc, torch.cuda.current_stream().cuda_stream)
+        oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+        assert c.n_rows == n_rows
+        assert (c.coeffs() == oc.coeffs()).all() and (c.comm() == oc.comm()).all() and (c.hashes() == oc.hashes()).all()
+        t = O.random_elems(fid, n_rows, 63)
+        assert (c.eval_outer(t) == oc.collapse(t)).all()
