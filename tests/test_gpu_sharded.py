@@ -66,3 +66,26 @@ def test_sharding_rejects_straddling_field():
     with pytest.raises(lcpc_amd.LcpcError) as e:
         LigeroEncoding.new_from_dims(2, 64, 128, shard=(0, 2))
     assert e.value.code == lcpc_amd.ERR_ARG
+
+
+@pytest.mark.parametrize("fid,n_per_row,n_rows,G", [(3, 300, 70, 2), (3, 300, 70, 4), (0, 400, 300, 2), (3, 257, 40, 8)])
+def test_sharded_brakedown_equals_unsharded(oracle, fid, n_per_row, n_rows, G):
+    """Brakedown shards the same way (rows independent, matrices replicated on every rank): shards with
+    >= 16 local rows take the position-major SpMM path, smaller ones the row-major one."""
+    O = oracle
+    L = O.limbs(fid)
+    oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 11, 3)
+    _, _, n_cols = oenc.get_dims(n_per_row)
+    coeffs = O.random_elems(fid, n_rows * n_per_row, 23)
+    dev = torch.from_numpy(coeffs.view(np.int64)).cuda().reshape(n_rows, n_per_row, L)
+    roots, engines = run_sharded(lambda sh: SdigEncoding(fid, None, 11, 3, 0, sh, _dims=(n_per_row, n_cols)), G, dev, n_rows)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+    for r in roots:
+        assert r == oc.get_root()
+    for eng in engines:
+        c = LcCommit(eng.enc)
+        assert (c.hashes() == oc.hashes()).all()
+        rb, re, _, _, _ = eng.layout(n_rows)
+        if re > rb:
+            assert (c.comm(rb, re - rb) == oc.comm().reshape(n_rows, -1)[rb:re].reshape(-1, L)).all()
+            assert (c.coeffs(rb, re - rb) == oc.coeffs().reshape(n_rows, -1)[rb:re].reshape(-1, L)).all()
