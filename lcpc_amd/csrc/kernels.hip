@@ -1,11 +1,13 @@
 // lcpc_amd/csrc/kernels.hip -- gfx950 (MI355X) kernels of the lcpc-2d commit / prove path.
 //
-//   K1  ntt_pass_kernel      LcEncoding::encode for Ligero = fffft fft_io_pc   (ligero lib.rs:162-164)
-//   K2  spmv / sdig_rs       LcEncoding::encode for Brakedown                  (brakedown encode.rs:36-110)
-//   K3  leaf_chunk/finish    hash_columns                                       (lcpc-2d lib.rs:706-745)
-//   K4  merkle_*             merkle_tree / merkle_layer                         (lib.rs:747-785)
-//   K5  collapse / field_sum collapse_columns                                   (lib.rs:1095-1123)
-//   K6  gather_*             open_column                                        (lib.rs:788-825)
+//   K1  ntt_pass_kernel / ntt_pass_l9_kernel (Ft255), roots_kernel
+//                               LcEncoding::encode for Ligero = fffft fft_io_pc, precomp_fft (ligero lib.rs:140, 162-164)
+//   K2  transpose_to/from_t, spmm_t, sdig_rs_t (>= 16 rows); spmv, sdig_rs (few rows)
+//                               LcEncoding::encode for Brakedown                   (brakedown encode.rs:36-110)
+//   K3  leaf_chunk / leaf_finish hash_columns (+ subtree pre-merge for sharding)    (lcpc-2d lib.rs:706-745)
+//   K4  merkle_subtree           merkle_tree / merkle_layer                         (lib.rs:747-785)
+//   K5  collapse / collapse29 / field_sum / to_r29   collapse_columns               (lib.rs:1095-1123)
+//   K6  gather_columns / gather_paths                open_column                    (lib.rs:788-825)
 //
 // All arithmetic is exact modular integer arithmetic, so any evaluation order gives bit-identical,
 // fully-reduced results; the kernels are free to re-associate (multi-pass NTT, split sums).
@@ -16,7 +18,7 @@
 namespace lcpc {
 
 // =================================================================================================
-// K1: batched multi-pass radix-2 DIF NTT, LDS-staged.
+// K1: batched multi-pass DIF NTT (radix-4 rounds inside a pass), LDS-staged.
 //
 // One pass executes stages [t0, t0+s) of the n = 2^k point transform of every row.  A stage-t
 // butterfly pairs x[e] and x[e + gap], gap = 2^(k-t-1), twiddle w^(2^t * (e mod gap)).  The elements
