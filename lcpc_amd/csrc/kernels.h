@@ -12,6 +12,10 @@ struct NttPassArgs {
   const uint32_t* roots;   // roots[i] = w^i (Montgomery), i < n/2
   const uint32_t* roots29; // Ft255 only: w^i * 2^261 mod p as 9 x 29-bit limbs, 12-word stride (fe_mul_r29)
   const uint32_t* qp29;    // Ft255 only: q*p (q < 32) as 9 x 29-bit limbs, 12-word stride; non-null selects the lazy-limb kernel
+  const uint32_t* roots29c;// lazy-limb kernel only, may be null: w^i * 2^5 mod p, same layout.  Non-null = "canonical output":
+                           // src is in Montgomery form, dst of the final pass holds canonical values (see ntt_pass_l9_kernel)
+  uint32_t mont_prefix;    // canonical output, final pass: elements [0, mont_prefix) of a row never met a multiplier and are
+                           // converted at the store
   uint64_t src_stride, dst_stride;
   uint64_t n_valid;        // elements >= n_valid of every src row read as zero (fused zero padding)
   uint64_t n_src_total;    // flat src elements >= n_src_total read as zero (ragged last row)
@@ -23,7 +27,7 @@ hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream
 
 // device-side precomp_fft: roots[i] = w^i (i < 2^log_half) from pw[j] = w^(2^j); roots29 (Ft255) may be null
 hipError_t launch_roots(int nl, const uint32_t* pw, uint32_t log_half, const uint32_t* one, uint32_t* roots, uint32_t* roots29,
-                        hipStream_t st);
+                        uint32_t* roots29c, hipStream_t st);
 
 struct LeafArgs {
   const uint32_t* comm;        // local rows, row-major
@@ -33,6 +37,7 @@ struct LeafArgs {
   uint64_t n_rows_total;
   uint32_t chunk_begin, n_chunks_local, n_chunks_total;
   uint32_t* out;               // n_chunks_total == 1: digests [n_cols][8]; else CVs [n_chunks_local][n_cols][8]
+  uint32_t canon_in;           // comm already holds canonical values (Ft255 Ligero commit): no Montgomery reduction here
 };
 hipError_t launch_leaf_chunks(int nl, const LeafArgs& a, hipStream_t st);
 // cvs [n_chunks][n_cols][8] (clobbered: used as the BLAKE3 CV stack) -> digests [n_cols][8]
@@ -58,9 +63,14 @@ hipError_t launch_to_r29(const uint32_t* in, uint64_t n, uint32_t* out, hipStrea
 // out[e] = sum_p parts[p][e] mod p
 hipError_t launch_field_sum(int nl, const uint32_t* parts, uint32_t n_parts, uint64_t n_elems, uint32_t* out, hipStream_t st);
 
-// open_column: vals[k][r] = comm[r][cols[k]]; paths[k][lvl] = sibling digest
+// open_column: vals[k][r] = comm[r][cols[k]]; paths[k][lvl] = sibling digest.  r2 non-null: comm holds canonical
+// values, multiply by R^2 on the way out so that vals are Montgomery-form elements like everything else at the ABI
 hipError_t launch_gather_columns(int nl, const uint32_t* comm, uint64_t n_rows, uint64_t n_cols, const uint64_t* cols,
-                                 uint32_t n, uint32_t* vals, hipStream_t st);
+                                 uint32_t n, uint32_t* vals, const uint32_t* r2, hipStream_t st);
+// elementwise representation change of n elements (in may equal out): to_mont = x * R (r2 = R^2 mod p, Montgomery
+// multiply), to_canon = x * R^-1 (Montgomery reduction = PrimeField::to_repr without the byte dump)
+hipError_t launch_to_mont(int nl, const uint32_t* in, uint64_t n, const uint32_t* r2, uint32_t* out, hipStream_t st);
+hipError_t launch_to_canon(int nl, const uint32_t* in, uint64_t n, uint32_t* out, hipStream_t st);
 hipError_t launch_gather_paths(const uint32_t* hashes, uint64_t np2, uint32_t path_len, const uint64_t* cols, uint32_t n,
                                uint32_t* paths, hipStream_t st);
 

@@ -14,8 +14,19 @@
 #include "kernels.h"
 #include "field_dev.h"
 #include "blake3_dev.h"
+#include <algorithm>
 
 namespace lcpc {
+
+// limb count (runtime) -> template parameter
+#define LCPC_DISPATCH_NL(nl, CALL)                 \
+  switch (nl) {                                    \
+    case 2: { constexpr int NLV = 2; CALL; } break; \
+    case 4: { constexpr int NLV = 4; CALL; } break; \
+    case 6: { constexpr int NLV = 6; CALL; } break; \
+    case 8: { constexpr int NLV = 8; CALL; } break; \
+    default: return hipErrorInvalidValue;          \
+  }
 
 // =================================================================================================
 // K1: batched multi-pass DIF NTT (radix-4 rounds inside a pass), LDS-staged.
@@ -83,6 +94,15 @@ __device__ __forceinline__ Tw<NL> tw_load(const NttPassArgs& a, u32 widx) {
   } else {
     t.w = fe_load<NL>(a.roots + (size_t)widx * NL);
   }
+  return t;
+}
+__device__ __forceinline__ Tw<8> tw_load29(const u32* tab, u32 widx) {
+  Tw<8> t;
+  const uint4* wp = reinterpret_cast<const uint4*>(tab + (size_t)widx * 12);
+  const uint4 w0 = wp[0], w1 = wp[1];
+  const u32 w8 = tab[(size_t)widx * 12 + 8];
+  t.w.v[0] = w0.x; t.w.v[1] = w0.y; t.w.v[2] = w0.z; t.w.v[3] = w0.w;
+  t.w.v[4] = w1.x; t.w.v[5] = w1.y; t.w.v[6] = w1.z; t.w.v[7] = w1.w; t.w.v[8] = w8;
   return t;
 }
 template <int NL>
@@ -208,6 +228,17 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
 // Ft255 variant on lazy 9 x 29-bit limbs (field_dev.h, namespace l9): same tiling, rounds and twiddle indexing as
 // ntt_pass_kernel, but the tile lives in LDS in the multiplier's own limb format (36 B per element), add/sub are
 // plain limb operations and exact reduction + packing happen once, at the tile store.  Bounds: see l9.
+//
+// Canonical output (a.roots29c != null; the Ligero commit): hash_columns needs to_repr(x) = x * R^-1 of every
+// codeword element, one Montgomery reduction each (2^27 of them at the headline, 0.7 ms inside the hash kernel).
+// The transform is linear and a twiddle multiply keeps whatever representation its input has, so the
+// conversion can ride on multiplications the NTT performs anyway: after t stages exactly the elements
+// [0, n / 2^t) of a row have never been multiplied ("block 0" of stage t: pure sums).  A butterfly in block 0
+// multiplies its difference by the twiddle from the second table, w^i * 2^5 = (w^i * 2^261) * 2^-256, which
+// converts it on the fly; every other butterfly sees canonical inputs and uses the normal table.  What is left
+// in Montgomery form at the end is the prefix the trivial last stages cover (a.mont_prefix = 4 or 2 elements
+// per row), reduced explicitly at the store.  comm then holds canonical values (LcCommit.coeffs, copied from the
+// loads, stays in Montgomery form); the hash kernel reads them as they are.
 // -------------------------------------------------------------------------------------------------
 template <int LT> struct Lds9 {
   static constexpr u32 T = 1u << LT;
@@ -228,7 +259,7 @@ template <int LT> __device__ __forceinline__ void lds9_put(u32* lds, u32 e, cons
 }
 
 template <int LT>
-__global__ void __launch_bounds__(256) ntt_pass_l9_kernel(NttPassArgs a) {
+__global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
   constexpr int NL = 8;
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* qp = lds + (size_t)Lds9<LT>::T * 9;                   // q*p table copy
@@ -258,6 +289,7 @@ __global__ void __launch_bounds__(256) ntt_pass_l9_kernel(NttPassArgs a) {
     return ((outer >> lb) << (lb + s)) | (i << lb) | (outer & lo_mask);
   };
 
+  const bool canon = a.roots29c != nullptr;
   for (u32 i = tid; i < 32 * 12; i += 256) qp[i] = a.qp29[i];
   const u32* src = a.src + row * a.src_stride * NL;
   for (u32 e = tid; e < T; e += 256) {
@@ -275,6 +307,8 @@ __global__ void __launch_bounds__(256) ntt_pass_l9_kernel(NttPassArgs a) {
     const u32 hb = s - u - 1;
     const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
     const bool last_two = (t + 2 == k);
+    // first round of a zero-padded row (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x * w)
+    const bool zero_hi = (t == 0) && !last_two && a.n_valid <= (1ull << (k - 1));
     for (u32 q = tid; q < T / 4; q += 256) {
       const u32 lp = q & lp_mask;
       const u32 j = (q >> lbt) & (i_mask >> 2);
@@ -283,6 +317,26 @@ __global__ void __launch_bounds__(256) ntt_pass_l9_kernel(NttPassArgs a) {
       const u32 e0 = (((hp << s) | i0) << lbt) | lp;
       const u32 dq = 1u << (hb - 1 + lbt);
       const u32 g0 = gindex(e0), g1 = gindex(e0 + dq);
+      if (zero_hi) {
+        // inputs straight from the loads: value < p.  Everything is block 0 here, so with canonical output the
+        // multiplies out of block 0 (w0, w1, and w2 for c1) take the converting table
+        const u32* tc = canon ? a.roots29c : a.roots29;
+        const Tw<NL> w0 = tw_load29(tc, g0 & gm0);
+        const Tw<NL> w1 = tw_load29(tc, g1 & gm0);
+        const Tw<NL> w2c = tw_load29(tc, (g0 & gm1) << 1);
+        const Tw<NL> w2 = tw_load<NL>(a, (g0 & gm1) << 1);
+        const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
+        L9 c0 = l9::add(x0, x1);                                                           // value < 2p
+        l9::normalize(c0);
+        lds9_put<LT>(lds, e0, c0);
+        lds9_put<LT>(lds, e0 + dq, l9::mul(l9::sub_bias<5, B29>(x0, x1), w2c.w));
+        const L9 b2 = l9::mul(x0, w0.w), b3 = l9::mul(x1, w1.w);                           // < 2p
+        L9 c2 = l9::add(b2, b3);
+        l9::normalize(c2);
+        lds9_put<LT>(lds, e0 + 2 * dq, c2);
+        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub_bias<3, B29>(b2, b3), w2.w));
+        continue;
+      }
       const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
       const L9 x2 = lds9_get<LT>(lds, e0 + 2 * dq), x3 = lds9_get<LT>(lds, e0 + 3 * dq);   // I: limbs < 2^29, value < 4p
       const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);                                 // limbs < 2^30, value < 8p
@@ -302,12 +356,19 @@ __global__ void __launch_bounds__(256) ntt_pass_l9_kernel(NttPassArgs a) {
         lds9_put<LT>(lds, e0 + 2 * dq, c2);
         lds9_put<LT>(lds, e0 + 3 * dq, c3);
       } else {
-        const Tw<NL> w0 = tw_load<NL>(a, (g0 & gm0) << t);
-        const Tw<NL> w1 = tw_load<NL>(a, (g1 & gm0) << t);
+        // block 0 of stages t, t+1 with canonical output (inputs still in Montgomery form): the three multiplies that
+        // leave block 0 take the converting table; c0 stays a pure sum; c3's inputs b2, b3 are already canonical
+        const bool blk0c = canon && g0 <= gm1;
+        const u32* t01 = blk0c ? a.roots29c : a.roots29;
+        const Tw<NL> w0 = tw_load29(t01, (g0 & gm0) << t);
+        const Tw<NL> w1 = tw_load29(t01, (g1 & gm0) << t);
         const Tw<NL> w2 = tw_load<NL>(a, (g0 & gm1) << (t + 1));
         l9::clamp(c0, qp);                                                                 // < 2p
         lds9_put<LT>(lds, e0, c0);
-        const L9 c1 = l9::mul(l9::sub_bias<9, B30>(b0, b1), w2.w);                         // in: limbs < 2.5*2^30, value < 17p
+        const L9 d1 = l9::sub_bias<9, B30>(b0, b1);                                        // limbs < 2.5*2^30, value < 17p
+        L9 c1;
+        if (blk0c) c1 = l9::mul(d1, tw_load29(a.roots29c, (g0 & gm1) << (t + 1)).w);
+        else c1 = l9::mul(d1, w2.w);
         lds9_put<LT>(lds, e0 + dq, c1);                                                    // normalised, < 2p
         const L9 b2 = l9::mul(l9::sub_bias<5, B29>(x0, x2), w0.w);                         // in: value < 9p; out < 2p
         const L9 b3 = l9::mul(l9::sub_bias<5, B29>(x1, x3), w1.w);
@@ -330,7 +391,8 @@ __global__ void __launch_bounds__(256) ntt_pass_l9_kernel(NttPassArgs a) {
       const u32 i = ((j >> hb) << (hb + 1)) | (j & ((1u << hb) - 1));
       const u32 e1 = (((hp << s) | i) << lbt) | lp;
       const u32 e2 = e1 + (1u << (hb + lbt));
-      const u32 widx = (gindex(e1) & gm) << t;
+      const u32 g1 = gindex(e1);
+      const u32 widx = (g1 & gm) << t;
       const L9 x = lds9_get<LT>(lds, e1), y = lds9_get<LT>(lds, e2);
       L9 sum = l9::add(x, y);                                                              // value < 8p
       l9::normalize(sum);
@@ -341,7 +403,7 @@ __global__ void __launch_bounds__(256) ntt_pass_l9_kernel(NttPassArgs a) {
         l9::normalize(d);                                                                  // last stage: twiddle 1
         lds9_put<LT>(lds, e2, d);
       } else {
-        const Tw<NL> w = tw_load<NL>(a, widx);
+        const Tw<NL> w = tw_load29((canon && g1 <= gm) ? a.roots29c : a.roots29, widx);   // block 0 of stage t converts
         lds9_put<LT>(lds, e2, l9::mul(d, w.w));
       }
     }
@@ -349,7 +411,12 @@ __global__ void __launch_bounds__(256) ntt_pass_l9_kernel(NttPassArgs a) {
   }
 
   u32* dst = a.dst + row * a.dst_stride * NL;
-  for (u32 e = tid; e < T; e += 256) fe_store<NL>(dst + (size_t)gindex(e) * NL, l9::to_packed_reduced(lds9_get<LT>(lds, e), qp));
+  for (u32 e = tid; e < T; e += 256) {
+    const u32 g = gindex(e);
+    Fe<NL> v = l9::to_packed_reduced(lds9_get<LT>(lds, e), qp);
+    if (g < a.mont_prefix) v = fe_canon_r29(v);              // canonical output, final pass: the never-multiplied prefix
+    fe_store<NL>(dst + (size_t)g * NL, v);
+  }
 }
 
 template <int LT>
@@ -419,12 +486,13 @@ __device__ __forceinline__ void leaf_load_raw(LeafRaw<NL, PH>& r, const LeafArgs
   }
 }
 // Montgomery -> canonical little-endian words (PrimeField::to_repr), laid out as the block's 16 message words
-template <int NL, int PH>
+template <int NL, int PH, bool CANON = false>
 __device__ __forceinline__ void leaf_build_block(u32 m[16], const LeafRaw<NL, PH>& r) {
   Fe<NL> c[LeafRaw<NL, PH>::NEL];
 #pragma unroll
   for (int x = 0; x < LeafRaw<NL, PH>::NEL; x++) {
-    if constexpr (NL == 8) c[x] = fe_canon_r29(r.el[x]);
+    if constexpr (CANON) c[x] = r.el[x];                    // comm already canonical (LeafArgs::canon_in)
+    else if constexpr (NL == 8) c[x] = fe_canon_r29(r.el[x]);
     else c[x] = fe_canon<NL>(r.el[x]);
   }
 #pragma unroll
@@ -437,7 +505,7 @@ __device__ __forceinline__ void leaf_fill_block(u32 m[16], const LeafArgs& a, u6
   leaf_build_block<NL, PH>(m, r);
 }
 
-template <int NL>
+template <int NL, bool CANON = false>
 __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
   const u64 col = (u64)blockIdx.x * 256 + threadIdx.x;
   if (col >= a.n_cols) return;
@@ -463,7 +531,7 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
     for (u32 b = 0; b < nblocks; b++) {
       if (b + 1 < nblocks) leaf_load_raw<NL, 0>(nxt, a, col, block_row0(b + 1, ph));
       u32 m[16];
-      leaf_build_block<NL, 0>(m, cur);
+      leaf_build_block<NL, 0, CANON>(m, cur);
       const u32 rem = chunk_len - 64 * b;
       const u32 blen = rem < 64 ? rem : 64;
       u32 flags = (b == 0 ? B3_CHUNK_START : 0u);
@@ -493,6 +561,11 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
 hipError_t launch_leaf_chunks(int nl, const LeafArgs& a, hipStream_t st) {
   if (a.n_chunks_local == 0 || a.n_cols == 0) return hipSuccess;
   dim3 grid((unsigned)((a.n_cols + 255) / 256), a.n_chunks_local);
+  if (a.canon_in) {
+    if (nl != 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((leaf_chunk_kernel<8, true>), grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   switch (nl) {
     case 2: hipLaunchKernelGGL(leaf_chunk_kernel<2>, grid, dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL(leaf_chunk_kernel<4>, grid, dim3(256), 0, st, a); break;
@@ -777,23 +850,49 @@ hipError_t launch_field_sum(int nl, const u32* parts, u32 n_parts, u64 n_elems, 
 // =================================================================================================
 template <int NL>
 __global__ void __launch_bounds__(256) gather_columns_kernel(const u32* comm, u64 n_rows, u64 n_cols, const u64* cols,
-                                                            u32* vals) {
+                                                            u32* vals, const u32* r2) {
   const u32 k = blockIdx.y;
   const u64 c = cols[k];
-  for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (u64)gridDim.x * 256)
-    fe_store<NL>(vals + ((u64)k * n_rows + r) * NL, fe_load<NL>(comm + (r * n_cols + c) * NL));
+  for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (u64)gridDim.x * 256) {
+    Fe<NL> v = fe_load<NL>(comm + (r * n_cols + c) * NL);
+    if (r2 != nullptr) v = fe_mul<NL>(v, fe_load<NL>(r2));  // canonical comm -> Montgomery form
+    fe_store<NL>(vals + ((u64)k * n_rows + r) * NL, v);
+  }
+}
+template <int NL>
+__global__ void __launch_bounds__(256) to_mont_kernel(const u32* in, u64 n, const u32* r2, u32* out) {
+  const Fe<NL> rr = fe_load<NL>(r2);
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    fe_store<NL>(out + i * NL, fe_mul<NL>(fe_load<NL>(in + i * NL), rr));
+}
+template <int NL>
+__global__ void __launch_bounds__(256) to_canon_kernel(const u32* in, u64 n, u32* out) {
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256)
+    fe_store<NL>(out + i * NL, fe_canon<NL>(fe_load<NL>(in + i * NL)));
+}
+hipError_t launch_to_mont(int nl, const u32* in, u64 n, const u32* r2, u32* out, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const unsigned gx = (unsigned)std::min<u64>((n + 255) / 256, 65536);
+  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(to_mont_kernel<NLV>, dim3(gx), dim3(256), 0, st, in, n, r2, out));
+  return hipGetLastError();
+}
+hipError_t launch_to_canon(int nl, const u32* in, u64 n, u32* out, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const unsigned gx = (unsigned)std::min<u64>((n + 255) / 256, 65536);
+  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(to_canon_kernel<NLV>, dim3(gx), dim3(256), 0, st, in, n, out));
+  return hipGetLastError();
 }
 hipError_t launch_gather_columns(int nl, const u32* comm, u64 n_rows, u64 n_cols, const u64* cols, u32 n, u32* vals,
-                                 hipStream_t st) {
+                                 const u32* r2, hipStream_t st) {
   if (n == 0) return hipSuccess;
   unsigned gx = (unsigned)((n_rows + 255) / 256);
   if (gx > 64) gx = 64;
   dim3 grid(gx, n);
   switch (nl) {
-    case 2: hipLaunchKernelGGL(gather_columns_kernel<2>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals); break;
-    case 4: hipLaunchKernelGGL(gather_columns_kernel<4>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals); break;
-    case 6: hipLaunchKernelGGL(gather_columns_kernel<6>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals); break;
-    case 8: hipLaunchKernelGGL(gather_columns_kernel<8>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals); break;
+    case 2: hipLaunchKernelGGL(gather_columns_kernel<2>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals, r2); break;
+    case 4: hipLaunchKernelGGL(gather_columns_kernel<4>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals, r2); break;
+    case 6: hipLaunchKernelGGL(gather_columns_kernel<6>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals, r2); break;
+    case 8: hipLaunchKernelGGL(gather_columns_kernel<8>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals, r2); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -947,14 +1046,6 @@ __global__ void __launch_bounds__(256) transpose_from_t_kernel(const u32* t, u64
     }
   }
 }
-#define LCPC_DISPATCH_NL(nl, CALL)                 \
-  switch (nl) {                                    \
-    case 2: { constexpr int NLV = 2; CALL; } break; \
-    case 4: { constexpr int NLV = 4; CALL; } break; \
-    case 6: { constexpr int NLV = 6; CALL; } break; \
-    case 8: { constexpr int NLV = 8; CALL; } break; \
-    default: return hipErrorInvalidValue;          \
-  }
 hipError_t launch_transpose_to_t(int nl, const u32* src, u64 src_stride, u64 n_valid, u64 n_rows, u32* t, hipStream_t st,
                                  u64 n_src_total, u32* copy_dst) {
   if (!n_valid || !n_rows) return hipSuccess;
@@ -1067,7 +1158,8 @@ hipError_t launch_sdig_rs_t(int nl, const u32* in_t, u32 n_in, u32* t, u64 out_o
 // products); for Ft255 it also emits the 29-bit-limb / 2^261 form used by fe_mul_r29.
 // =================================================================================================
 template <int NL>
-__global__ void __launch_bounds__(256) roots_kernel(const u32* pw, u32 log_half, const u32* one, u32* roots, u32* roots29) {
+__global__ void __launch_bounds__(256) roots_kernel(const u32* pw, u32 log_half, const u32* one, u32* roots, u32* roots29,
+                                                   u32* roots29c) {
   const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
   if (i >= ((u64)1 << log_half)) return;
   Fe<NL> acc = fe_load<NL>(one);
@@ -1084,12 +1176,22 @@ __global__ void __launch_bounds__(256) roots_kernel(const u32* pw, u32 log_half,
       for (int k = 0; k < 9; k++) roots29[i * 12 + k] = x.v[k];
       roots29[i * 12 + 9] = roots29[i * 12 + 10] = roots29[i * 12 + 11] = 0;
     }
+    if (roots29c != nullptr) {                                   // w^i * 2^5: the converting table of ntt_pass_l9_kernel
+      Fe<8> t = fe_canon<8>(acc);
+#pragma unroll
+      for (int d = 0; d < 5; d++) t = fe_add<8>(t, t);
+      const Fe29 x = fe_to29(t);
+#pragma unroll
+      for (int k = 0; k < 9; k++) roots29c[i * 12 + k] = x.v[k];
+      roots29c[i * 12 + 9] = roots29c[i * 12 + 10] = roots29c[i * 12 + 11] = 0;
+    }
   }
 }
-hipError_t launch_roots(int nl, const u32* pw, u32 log_half, const u32* one, u32* roots, u32* roots29, hipStream_t st) {
+hipError_t launch_roots(int nl, const u32* pw, u32 log_half, const u32* one, u32* roots, u32* roots29, u32* roots29c,
+                        hipStream_t st) {
   const u64 n = (u64)1 << log_half;
   dim3 grid((unsigned)((n + 255) / 256));
-  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(roots_kernel<NLV>, grid, dim3(256), 0, st, pw, log_half, one, roots, roots29));
+  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(roots_kernel<NLV>, grid, dim3(256), 0, st, pw, log_half, one, roots, roots29, roots29c));
   return hipGetLastError();
 }
 

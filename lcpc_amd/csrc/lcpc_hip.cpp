@@ -87,6 +87,9 @@ struct lcpc_ctx {
   uint32_t* d_roots = nullptr;
   uint32_t* d_roots29 = nullptr;   // Ft255: twiddles in radix-2^29 / R'=2^261 Montgomery form (field_dev.h fe_mul_r29)
   uint32_t* d_qp29 = nullptr;      // Ft255: q*p, q < 32, as 29-bit limbs (l9::clamp); null = packed-form NTT kernel
+  uint32_t* d_roots29c = nullptr;  // Ft255 lazy-limb kernel: w^i * 2^5, the table that converts to canonical on the fly
+  bool comm_canon = false;         // d_comm of a commit holds canonical values (x * R^-1), not Montgomery form: the column
+                                   // hash reads them as they are; every read-out (get_comm, open_columns) converts back
   std::vector<Pass> passes;
   // Brakedown
   SdigSpec spec{};
@@ -253,13 +256,19 @@ int shard_nodes(uint64_t c0, uint64_t c1, uint64_t* first, uint32_t* lg) {
 }
 
 // ---- encode all local rows: coeffs -> comm ----------------------------------------------------------
+// canon_out: dst receives canonical values instead of Montgomery form (commit paths of a comm_canon context only)
 int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, uint64_t n_valid, uint32_t* dst,
-                       uint64_t n_rows, hipStream_t st, uint64_t n_src_total = ~(uint64_t)0, uint32_t* copy_dst = nullptr) {
+                       uint64_t n_rows, hipStream_t st, uint64_t n_src_total = ~(uint64_t)0, uint32_t* copy_dst = nullptr,
+                       bool canon_out = false) {
   if (n_rows == 0) return 0;
   if (c->prm.encoding == LCPC_ENC_LIGERO) {
     bool first = true;
     for (const Pass& p : c->passes) {
       NttPassArgs a;
+      a.roots29c = canon_out ? c->d_roots29c : nullptr;
+      // the trailing stages multiply by 1 only: a final radix-4 round leaves 4 elements per row unconverted, a final
+      // radix-2 stage 2 (ntt_pass_l9_kernel)
+      a.mont_prefix = (canon_out && p.t0 + p.s == c->log_n) ? (c->log_n == 0 ? 1u : (p.s % 2 == 0 ? 4u : 2u)) : 0u;
       a.src = first ? src : dst;
       a.dst = dst;
       a.roots = c->d_roots;
@@ -375,7 +384,7 @@ int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, ui
 int merkleize_device(lcpc_ctx* c, hipStream_t st) {
   const uint64_t n_chunks = leaf_chunks(c, c->n_rows);
   LeafArgs la{};
-  la.comm = c->d_comm; la.row_stride = c->n_cols; la.n_cols = c->n_cols; la.row_base = 0;
+  la.comm = c->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.n_cols = c->n_cols; la.row_base = 0;
   la.n_rows_total = c->n_rows; la.chunk_begin = 0; la.n_chunks_local = (uint32_t)n_chunks; la.n_chunks_total = (uint32_t)n_chunks;
   if (n_chunks == 1) {
     la.out = c->d_hashes;
@@ -417,8 +426,10 @@ int finish_timing(lcpc_ctx* c, hipStream_t st) {
 int commit_resident(lcpc_ctx* c, hipStream_t st, uint8_t* root, const uint32_t* ext_src = nullptr, uint64_t n_ext = 0) {
   c->launches[0] = c->launches[1] = c->launches[2] = 0;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
-  int rc = ext_src ? encode_rows_device(c, ext_src, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st, n_ext, c->d_coeffs)
-                   : encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st);
+  int rc = ext_src ? encode_rows_device(c, ext_src, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st, n_ext, c->d_coeffs,
+                                        c->comm_canon)
+                   : encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st, ~(uint64_t)0,
+                                        nullptr, c->comm_canon);
   if (rc) return rc;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], st));
   if ((rc = merkleize_device(c, st))) return rc;
@@ -534,12 +545,13 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
       uint32_t *d_pw = nullptr, *d_one = nullptr;
       if ((rc = dev_alloc(c, &d_pw, pw.size() * 8)) || (rc = dev_alloc(c, &d_one, 8 * f->L)) ||
           (rc = dev_alloc(c, &c->d_roots, n_roots * 8 * f->L)) ||
-          (f->L == 4 && (rc = dev_alloc(c, &c->d_roots29, n_roots * 48)))) {
+          (f->L == 4 && (rc = dev_alloc(c, &c->d_roots29, n_roots * 48))) ||
+          (f->L == 4 && (rc = dev_alloc(c, &c->d_roots29c, n_roots * 48)))) {
         dev_free(d_pw); dev_free(d_one); lcpc_ctx_destroy(c); return rc;
       }
       hipError_t he = hipMemcpy(d_pw, pw.data(), pw.size() * 8, hipMemcpyHostToDevice);
       if (he == hipSuccess) he = hipMemcpy(d_one, f->r, 8 * f->L, hipMemcpyHostToDevice);
-      if (he == hipSuccess) he = launch_roots(c->NL, d_pw, log_half, d_one, c->d_roots, c->d_roots29, nullptr);
+      if (he == hipSuccess) he = launch_roots(c->NL, d_pw, log_half, d_one, c->d_roots, c->d_roots29, c->d_roots29c, nullptr);
       if (he == hipSuccess) he = hipDeviceSynchronize();
       dev_free(d_pw); dev_free(d_one);
       if (he != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
@@ -560,6 +572,9 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
       }
       if ((rc = dev_alloc(c, &c->d_qp29, tab.size() * 4))) { lcpc_ctx_destroy(c); return rc; }
       if (hipMemcpy(c->d_qp29, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
+      c->comm_canon = !getenv("LCPC_COMM_MONT");
+      if ((rc = dev_alloc(c, &c->d_r2, 8 * f->L))) { lcpc_ctx_destroy(c); return rc; }
+      if (hipMemcpy(c->d_r2, f->r2, 8 * f->L, hipMemcpyHostToDevice) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
     }
     plan_passes(c);
   } else if (p->encoding == LCPC_ENC_SDIG) {
@@ -612,7 +627,7 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
 void lcpc_ctx_destroy(lcpc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->prm.device);
-  dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_qp29); dev_free(c->d_r2); dev_free(c->d_tmp); dev_free(c->d_t);
+  dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2); dev_free(c->d_tmp); dev_free(c->d_t);
   for (auto* v : {&c->d_pre, &c->d_post})
     for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); dev_free(d.vals29); }
   dev_free(c->d_coeffs); dev_free(c->d_comm); dev_free(c->d_hashes); dev_free(c->d_cvs); dev_free(c->d_scratch); dev_free(c->d_node_tab); dev_free(c->d_t29);
@@ -729,7 +744,7 @@ int lcpc_commit(lcpc_ctx* c, const uint64_t* coeffs, uint64_t n_coeffs, uint8_t*
     HIPCHK(c, hipEventRecord(c->ev_batch[b], c->s_copy));
     HIPCHK(c, hipStreamWaitEvent(c->s_comp, c->ev_batch[b], 0));
     rc = encode_rows_device(c, c->d_coeffs + (size_t)r0 * c->n_per_row * c->NL, c->n_per_row, c->n_per_row,
-                            c->d_comm + (size_t)r0 * c->n_cols * c->NL, r1 - r0, c->s_comp);
+                            c->d_comm + (size_t)r0 * c->n_cols * c->NL, r1 - r0, c->s_comp, ~(uint64_t)0, nullptr, c->comm_canon);
     if (rc) return rc;
   }
   if ((rc = merkleize_device(c, c->s_comp))) return rc;
@@ -748,6 +763,7 @@ int lcpc_commit_from_parts(lcpc_ctx* c, const uint64_t* comm, const uint64_t* co
   if (rc) return rc;
   const size_t eb = elem_bytes(c);
   HIPCHK(c, hipMemcpy(c->d_comm, comm, (size_t)n_rows * c->n_cols * eb, hipMemcpyHostToDevice));
+  if (c->comm_canon) HIPCHK(c, launch_to_canon(c->NL, c->d_comm, n_rows * c->n_cols, c->d_comm, nullptr));
   if (coeffs) HIPCHK(c, hipMemcpy(c->d_coeffs, coeffs, (size_t)n_rows * c->n_per_row * eb, hipMemcpyHostToDevice));
   else HIPCHK(c, hipMemset(c->d_coeffs, 0, (size_t)n_rows * c->n_per_row * eb));
   c->launches[0] = c->launches[1] = c->launches[2] = 0;
@@ -788,8 +804,24 @@ int lcpc_get_comm(lcpc_ctx* c, uint64_t row0, uint64_t n, uint64_t* out) {
   if (row0 < c->row_begin || row0 + n > c->row_begin + c->n_rows_local) return LCPC_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->prm.device));
   const size_t eb = elem_bytes(c);
-  HIPCHK(c, hipMemcpy(out, reinterpret_cast<uint8_t*>(c->d_comm) + (size_t)(row0 - c->row_begin) * c->n_cols * eb,
-                      (size_t)n * c->n_cols * eb, hipMemcpyDeviceToHost));
+  const uint32_t* src = c->d_comm + (size_t)(row0 - c->row_begin) * c->n_cols * c->NL;
+  if (!c->comm_canon) {
+    HIPCHK(c, hipMemcpy(out, src, (size_t)n * c->n_cols * eb, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  // canonical on the device, Montgomery form (as ff_derive stores elements) at the ABI: convert a row batch at a time
+  const uint64_t batch = std::max<uint64_t>(1, ((uint64_t)64 << 20) / (c->n_cols * eb));
+  uint32_t* tmp = nullptr;
+  int rc = dev_alloc(c, &tmp, (size_t)std::min(batch, n ? n : 1) * c->n_cols * eb);
+  if (rc) return rc;
+  for (uint64_t r = 0; r < n; r += batch) {
+    const uint64_t nb = std::min(batch, n - r);
+    hipError_t he = launch_to_mont(c->NL, src + (size_t)r * c->n_cols * c->NL, nb * c->n_cols, c->d_r2, tmp, nullptr);
+    if (he == hipSuccess)
+      he = hipMemcpy(reinterpret_cast<uint8_t*>(out) + (size_t)r * c->n_cols * eb, tmp, (size_t)nb * c->n_cols * eb, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) { dev_free(tmp); return fail_hip(c, he, "lcpc_get_comm"); }
+  }
+  dev_free(tmp);
   return 0;
 }
 int lcpc_get_coeffs(lcpc_ctx* c, uint64_t row0, uint64_t n, uint64_t* out) {
@@ -911,7 +943,7 @@ int lcpc_open_columns(lcpc_ctx* c, const uint64_t* cols, uint32_t n, uint64_t* c
   uint32_t* d_paths = reinterpret_cast<uint32_t*>(base + ((cb + 31) & ~(size_t)31) + ((vb + 31) & ~(size_t)31));
   HIPCHK(c, hipMemcpy(d_cols, cols, cb, hipMemcpyHostToDevice));
   if (col_vals) {
-    HIPCHK(c, launch_gather_columns(c->NL, c->d_comm, c->n_rows_local, c->n_cols, d_cols, n, d_vals, nullptr));
+    HIPCHK(c, launch_gather_columns(c->NL, c->d_comm, c->n_rows_local, c->n_cols, d_cols, n, d_vals, c->comm_canon ? c->d_r2 : nullptr, nullptr));
     HIPCHK(c, hipMemcpy(col_vals, d_vals, vb, hipMemcpyDeviceToHost));
   }
   if (paths && c->path_len) {
@@ -1199,7 +1231,7 @@ int lcpc_commit_shard_device(lcpc_ctx* c, const uint64_t* coeffs_local, uint64_t
     if (!coeffs_local) return LCPC_ERR_ARG;
     if (c->prm.encoding == LCPC_ENC_LIGERO) {
       rc = encode_rows_device(c, reinterpret_cast<const uint32_t*>(coeffs_local), c->n_per_row, c->n_per_row, c->d_comm,
-                              c->n_rows_local, st, ~(uint64_t)0, c->d_coeffs);        // coeffs copy fused into pass 1
+                              c->n_rows_local, st, ~(uint64_t)0, c->d_coeffs, c->comm_canon);   // coeffs copy fused into pass 1
     } else {
       HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs_local, (size_t)c->n_rows_local * c->n_per_row * elem_bytes(c), hipMemcpyDeviceToDevice, st));
       rc = encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st);
@@ -1214,7 +1246,7 @@ int lcpc_commit_shard_device(lcpc_ctx* c, const uint64_t* coeffs_local, uint64_t
     bool all_single = true;
     for (int k = 0; k < n_nodes; k++) all_single = all_single && lg[k] == 0;
     LeafArgs la{};
-    la.comm = c->d_comm; la.row_stride = c->n_cols; la.n_cols = c->n_cols; la.row_base = (int64_t)rb;
+    la.comm = c->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.n_cols = c->n_cols; la.row_base = (int64_t)rb;
     la.n_rows_total = n_rows_total; la.chunk_begin = (uint32_t)cb; la.n_chunks_local = (uint32_t)(ce - cb);
     la.n_chunks_total = (uint32_t)nch;
     if (all_single) {                       // nothing to pre-merge: chunk CVs are the nodes
