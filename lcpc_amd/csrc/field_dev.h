@@ -464,9 +464,8 @@ LCPC_DEV void clamp(L9& a, const u32* qp) {
 // (a * w) * 2^-261 mod p, loosely: a value < 64p with limbs < 2^31.3, w normalised < p (2^261-Montgomery form).
 // Result: normalised limbs, value < 2p.
 LCPC_DEV L9 mul(const L9& a, const Fe29& w) {
-  u32 m[9];
   L9 r;
-  r29_columns(a.v, w.v, m, r.v);
+  r29_mul1(a.v, w.v, r.v);        // the whole column chain as one asm statement (field_r29_gen.h)
   return r;
 }
 // exact: normalised value < 32p -> packed, fully reduced
