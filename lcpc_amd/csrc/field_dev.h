@@ -375,102 +375,82 @@ LCPC_DEV Fe<8> fe_mul_r29(const Fe<8>& a, const Fe29& b) {
 // wave64 instruction, but v_addc/v_subb (carry chains), v_alignbit, v_add3, 64-bit adds AND v_mad_u64_u32 all
 // ~4.3-4.5.  In the packed 8x32 representation a butterfly spends ~25 % of its cycles on carry-chain add/sub and
 // on packed<->29-bit conversions around the multiply.  Here an element stays in the multiplier's own format
-// between stages: 9 limbs, each < 2^29 in LDS ("normalised"), value only *loosely* reduced:
-//     invariant I:  limbs < 2^29,  value < 4p,  value == true value (mod p).
-// add = 9 plain adds; sub = a - b + K with K a multiple of p written with limbs >= the subtrahend's limb bound
-// (so no limb goes negative: no borrows); the Montgomery multiply (fe_mul_r29's column chain) accepts any value
-// < 64p with limbs < 2^31.3 and returns a normalised value < 2p; a "clamp" (quotient estimate from the top limb,
-// subtract q*p from a table) brings the only growing path (sums of sums) back under 2p.  Exact reduction to
-// [0,p) and packing happen once per element per pass, at the tile store.  Bounds are stated at every step below.
+// between stages: 9 limbs, SIGNED (two's complement) and only loosely reduced:
+//     invariant I ("normalised"):  limbs 0..7 in [0, 2^29), limb 8 signed;  |value| < 4p;  value == true value (mod p).
+// add and sub are 9 plain limb operations each (differences simply go negative: no bias constants, no borrows);
+// the Montgomery multiply (r29_mul1s: v_mad_i64_i32 column chain with negative quotient digits) accepts limbs in
+// (-2^30, 2^30), |value| < 16p, and returns a normalised value in (-1.2p, 0.2p]; a "clamp" (quotient estimate from
+// the signed top limb, subtract q*p from a table) brings the only growing path (sums of sums) back into [0, 1.01p).
+// Exact reduction to [0,p) and packing happen once per element per pass, at the tile store.  Bounds are stated at
+// every step below and in the kernel; tests/test_gpu_edges.py::test_lazy_limb_ntt_range_stress pushes them.
 // =================================================================================================
 struct L9 {
-  u32 v[9];
+  u32 v[9];       // two's complement; limb 8 (and un-normalised intermediates) may be negative
 };
 
 namespace l9 {
 constexpr u32 M = P29::M;
+constexpr int QOFF = 24;          // clamp table: entry i = (i - QOFF) * p, i in [0, 64)
+constexpr int QBIAS = 40;         // subtracted from the top limb before the quotient estimate (keeps remainders >= 0)
 
-// kappa * p as 9 canonical 29-bit limbs (constexpr big-int), kappa small
-struct Limbs9 {
-  u32 v[9];
-};
-constexpr Limbs9 kp_limbs(u32 kappa) {
-  Limbs9 r{};
-  u64 carry = 0;
-  for (int k = 0; k < 9; k++) {
-    const u64 t = (u64)P29::limb(k) * kappa + carry;
-    r.v[k] = (u32)(t & M);
-    carry = t >> 29;
-  }
-  return r;       // kappa * p < 2^261 for kappa <= 64
-}
-// bias for "a - b + K": K = kappa*p re-written so that limb j (j < 8) is >= LB - 1 where LB (a power of two,
-// 2^29 or 2^30) bounds the limbs of b; the top limb only has to dominate b's top limb (kappa > value bound of b).
-template <u32 KAPPA, u32 LB> struct Bias {
-  static constexpr u32 limb(int k) {
-    constexpr Limbs9 c = kp_limbs(KAPPA);
-    const u32 borrow = LB >> 29;                     // what one unit of limb k+1 is worth in units of LB ... 2^29*borrow = LB
-    if (k == 0) return c.v[0] + LB;
-    if (k < 8) return c.v[k] + LB - borrow;
-    return c.v[8] - borrow;
-  }
-};
-
-LCPC_DEV L9 from_packed(const Fe<8>& a) {           // value < p, limbs < 2^29
+LCPC_DEV L9 from_packed(const Fe<8>& a) {           // value in [0, p), normalised
   const Fe29 t = fe_to29(a);
   L9 r;
 #pragma unroll
   for (int k = 0; k < 9; k++) r.v[k] = t.v[k];
   return r;
 }
-LCPC_DEV L9 add(const L9& a, const L9& b) {         // limbs add, no carries
+LCPC_DEV L9 add(const L9& a, const L9& b) {         // limb-wise, no carries
   L9 r;
 #pragma unroll
   for (int k = 0; k < 9; k++) r.v[k] = a.v[k] + b.v[k];
   return r;
 }
-// a - b + KAPPA*p; requires limbs(b) < LB (j < 8) and value(b) < (KAPPA - 1) p.  Result limbs < limbs(a) + LB + 2^29.
-template <u32 KAPPA, u32 LB> LCPC_DEV L9 sub_bias(const L9& a, const L9& b) {
+LCPC_DEV L9 sub(const L9& a, const L9& b) {         // limb-wise, limbs may go negative
   L9 r;
 #pragma unroll
-  for (int k = 0; k < 9; k++) r.v[k] = a.v[k] + Bias<KAPPA, LB>::limb(k) - b.v[k];
+  for (int k = 0; k < 9; k++) r.v[k] = a.v[k] - b.v[k];
   return r;
 }
-// carry-propagate: limbs (< 2^32) -> limbs < 2^29 (top limb takes what is left; value < 2^261 keeps it < 2^29)
+// carry-propagate signed limbs (|limb| < 2^31): limbs 0..7 -> [0, 2^29), limb 8 takes what is left (signed)
 LCPC_DEV void normalize(L9& a) {
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    a.v[k + 1] += a.v[k] >> 29;
+    a.v[k + 1] += (u32)((int32_t)a.v[k] >> 29);     // floor division: arithmetic shift
     a.v[k] &= M;
   }
 }
-// a: normalised, value < 32p  ->  normalised, value < 2p (== a mod p).  qp[q] = q*p as 9 limbs (12-word stride).
-// q = floor(top / (ptop + 1)) never overshoots: q*p <= a; the remainder is < p + (q + 2) * 2^232 < 2p.
+// a: normalised, |value| < 16p  ->  normalised, value in [0, p + 2^239) (== a mod p).  qp[i] = (i - QOFF) * p as
+// normalised signed limbs (12-word stride).  With t the signed top limb, V = t * 2^232 + low, 0 <= low < 2^232, and
+// q = floor((t - QBIAS) / (ptop + 1)), ptop = floor(p / 2^232):  t - QBIAS = q (ptop + 1) + rem, so
+// V - q p = q (2^232 - plow) + (rem + QBIAS) 2^232 + low  with plow = p mod 2^232:  >= (QBIAS - |q|) 2^232 >= 0 for
+// |q| <= 17 + 1 and < (ptop + 1 + QBIAS + |q| + 1) 2^232 < p + 2^239.
 LCPC_DEV void clamp(L9& a, const u32* qp) {
   constexpr u32 PTOP1 = (u32)(P29::limb(8)) + 1;                         // floor(p / 2^232) + 1 (23 bits)
   constexpr u64 MAGIC = (((u64)1 << 52) + PTOP1 - 1) / PTOP1;            // ceil(2^52 / PTOP1) < 2^30
-  const u32 q = (u32)(((u64)a.v[8] * MAGIC) >> 52);                      // exact floor for a.v[8] < 2^29
+  const u32 n = a.v[8] + (u32)(QOFF * PTOP1 - QBIAS);                    // in [0, 2^29) for |value| < 16p
+  const u32 q = (u32)(((u64)n * MAGIC) >> 52);                           // exact floor(n / PTOP1) for n < 2^29
   const u32* t = qp + q * 12;
   int32_t d[9];
 #pragma unroll
   for (int k = 0; k < 9; k++) d[k] = (int32_t)(a.v[k] - t[k]);
 #pragma unroll
-  for (int k = 0; k < 8; k++) {                                         // borrow-propagate (value stays >= 0)
+  for (int k = 0; k < 8; k++) {                                         // borrow-propagate
     d[k + 1] += d[k] >> 31;                                             // -1 if limb k went negative
     a.v[k] = (u32)d[k] & M;                                             // + 2^29 in that case
   }
   a.v[8] = (u32)d[8];
 }
-// (a * w) * 2^-261 mod p, loosely: a value < 64p with limbs < 2^31.3, w normalised < p (2^261-Montgomery form).
-// Result: normalised limbs, value < 2p.
+// (a * w) * 2^-261 mod p, loosely: a limbs in (-2^30, 2^30), |value| < 16p; w normalised, in [0, p) (2^261-Montgomery
+// form).  Column sums stay inside i64: 9 * 2^59 + 8 * 2^58 + 2^34 < 2^63.  Result: normalised, in (-1.2p, 0.2p].
 LCPC_DEV L9 mul(const L9& a, const Fe29& w) {
   L9 r;
-  r29_mul1(a.v, w.v, r.v);        // the whole column chain as one asm statement (field_r29_gen.h)
+  r29_mul1s(a.v, w.v, r.v);       // one asm statement (field_r29_gen.h)
   return r;
 }
-// exact: normalised value < 32p -> packed, fully reduced
+// exact: normalised |value| < 16p -> packed, fully reduced
 LCPC_DEV Fe<8> to_packed_reduced(L9 a, const u32* qp) {
-  clamp(a, qp);                   // < 2p < 2^256
+  clamp(a, qp);                   // [0, p + 2^239) < 2^256
   u32 t[8];
   fe_from29(t, a.v);
   return fe_reduce_once8(t);

@@ -225,8 +225,8 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Ft255 variant on lazy 9 x 29-bit limbs (field_dev.h, namespace l9): same tiling, rounds and twiddle indexing as
-// ntt_pass_kernel, but the tile lives in LDS in the multiplier's own limb format (36 B per element), add/sub are
+// Ft255 variant on lazy signed 9 x 29-bit limbs (field_dev.h, namespace l9): same tiling, rounds and twiddle indexing
+// as ntt_pass_kernel, but the tile lives in LDS in the multiplier's own limb format (36 B per element), add/sub are
 // plain limb operations and exact reduction + packing happen once, at the tile store.  Bounds: see l9.
 //
 // Canonical output (a.roots29c != null; the Ligero commit): hash_columns needs to_repr(x) = x * R^-1 of every
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
 // -------------------------------------------------------------------------------------------------
 template <int LT> struct Lds9 {
   static constexpr u32 T = 1u << LT;
-  static constexpr u32 WORDS = T * 9 + 32 * 12;              // tile + q*p table (32 entries, 12-word stride)
+  static constexpr u32 WORDS = T * 9 + 64 * 12;              // tile + q*p table (64 entries, 12-word stride)
 };
 template <int LT> __device__ __forceinline__ L9 lds9_get(const u32* lds, u32 e) {
   const uint4 a = *reinterpret_cast<const uint4*>(lds + (size_t)e * 4);
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
   };
 
   const bool canon = a.roots29c != nullptr;
-  for (u32 i = tid; i < 32 * 12; i += 256) qp[i] = a.qp29[i];
+  for (u32 i = tid; i < 64 * 12; i += 256) qp[i] = a.qp29[i];
   const u32* src = a.src + row * a.src_stride * NL;
   for (u32 e = tid; e < T; e += 256) {
     const u32 g = gindex(e);
@@ -300,7 +300,6 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
   }
   __syncthreads();
 
-  constexpr u32 B29 = 1u << 29, B30 = 1u << 30;
   u32 u = 0;
   for (; u + 1 < s; u += 2) {
     const u32 t = t0 + u;
@@ -326,30 +325,30 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
         const Tw<NL> w2c = tw_load29(tc, (g0 & gm1) << 1);
         const Tw<NL> w2 = tw_load<NL>(a, (g0 & gm1) << 1);
         const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
-        L9 c0 = l9::add(x0, x1);                                                           // value < 2p
+        L9 c0 = l9::add(x0, x1);                                                           // [0, 2p)
         l9::normalize(c0);
         lds9_put<LT>(lds, e0, c0);
-        lds9_put<LT>(lds, e0 + dq, l9::mul(l9::sub_bias<5, B29>(x0, x1), w2c.w));
-        const L9 b2 = l9::mul(x0, w0.w), b3 = l9::mul(x1, w1.w);                           // < 2p
+        lds9_put<LT>(lds, e0 + dq, l9::mul(l9::sub(x0, x1), w2c.w));
+        const L9 b2 = l9::mul(x0, w0.w), b3 = l9::mul(x1, w1.w);                           // (-1.2p, 0.2p]
         L9 c2 = l9::add(b2, b3);
         l9::normalize(c2);
         lds9_put<LT>(lds, e0 + 2 * dq, c2);
-        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub_bias<3, B29>(b2, b3), w2.w));
+        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2.w));
         continue;
       }
       const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
-      const L9 x2 = lds9_get<LT>(lds, e0 + 2 * dq), x3 = lds9_get<LT>(lds, e0 + 3 * dq);   // I: limbs < 2^29, value < 4p
-      const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);                                 // limbs < 2^30, value < 8p
-      L9 c0 = l9::add(b0, b1);                                                             // limbs < 2^31, value < 16p
+      const L9 x2 = lds9_get<LT>(lds, e0 + 2 * dq), x3 = lds9_get<LT>(lds, e0 + 3 * dq);   // I: normalised, |value| < 4p
+      const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);                                 // limbs [0, 2^30), |value| < 8p
+      L9 c0 = l9::add(b0, b1);                                                             // limbs [0, 2^31), |value| < 16p
       l9::normalize(c0);
       if (last_two) {
-        // stages k-2, k-1: twiddles 1, w^(n/4), 1 -- outputs go straight to the store path (normalised, value < 32p)
+        // stages k-2, k-1: twiddles 1, w^(n/4), 1 -- outputs go straight to the store path (normalised, |value| < 16p)
         const Tw<NL> wq = tw_load<NL>(a, 1u << (k - 2));
-        L9 c1 = l9::sub_bias<9, B30>(b0, b1);                                              // value < 17p
-        const L9 b2 = l9::sub_bias<5, B29>(x0, x2);                                        // limbs < 1.5*2^30, value < 9p
-        const L9 b3 = l9::mul(l9::sub_bias<5, B29>(x1, x3), wq.w);                         // normalised, < 2p
-        L9 c2 = l9::add(b2, b3);                                                           // value < 11p
-        L9 c3 = l9::sub_bias<3, B29>(b2, b3);                                              // value < 12p
+        L9 c1 = l9::sub(b0, b1);                                                           // |value| < 16p
+        const L9 b2 = l9::sub(x0, x2);                                                     // limbs (-2^29, 2^29), |value| < 8p
+        const L9 b3 = l9::mul(l9::sub(x1, x3), wq.w);                                      // normalised, (-1.2p, 0.2p]
+        L9 c2 = l9::add(b2, b3);                                                           // |value| < 9.2p
+        L9 c3 = l9::sub(b2, b3);                                                           // |value| < 9.2p
         l9::normalize(c1); l9::normalize(c2); l9::normalize(c3);
         lds9_put<LT>(lds, e0, c0);
         lds9_put<LT>(lds, e0 + dq, c1);
@@ -363,19 +362,19 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
         const Tw<NL> w0 = tw_load29(t01, (g0 & gm0) << t);
         const Tw<NL> w1 = tw_load29(t01, (g1 & gm0) << t);
         const Tw<NL> w2 = tw_load<NL>(a, (g0 & gm1) << (t + 1));
-        l9::clamp(c0, qp);                                                                 // < 2p
+        l9::clamp(c0, qp);                                                                 // [0, 1.01p)
         lds9_put<LT>(lds, e0, c0);
-        const L9 d1 = l9::sub_bias<9, B30>(b0, b1);                                        // limbs < 2.5*2^30, value < 17p
+        const L9 d1 = l9::sub(b0, b1);                                                     // limbs (-2^30, 2^30), |value| < 16p
         L9 c1;
         if (blk0c) c1 = l9::mul(d1, tw_load29(a.roots29c, (g0 & gm1) << (t + 1)).w);
         else c1 = l9::mul(d1, w2.w);
-        lds9_put<LT>(lds, e0 + dq, c1);                                                    // normalised, < 2p
-        const L9 b2 = l9::mul(l9::sub_bias<5, B29>(x0, x2), w0.w);                         // in: value < 9p; out < 2p
-        const L9 b3 = l9::mul(l9::sub_bias<5, B29>(x1, x3), w1.w);
-        L9 c2 = l9::add(b2, b3);                                                           // limbs < 2^30, value < 4p
+        lds9_put<LT>(lds, e0 + dq, c1);                                                    // normalised, (-1.2p, 0.2p]
+        const L9 b2 = l9::mul(l9::sub(x0, x2), w0.w);                                      // in: |value| < 8p
+        const L9 b3 = l9::mul(l9::sub(x1, x3), w1.w);
+        L9 c2 = l9::add(b2, b3);                                                           // (-2.4p, 0.4p]
         l9::normalize(c2);
         lds9_put<LT>(lds, e0 + 2 * dq, c2);
-        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub_bias<3, B29>(b2, b3), w2.w));
+        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2.w));
       }
     }
     __syncthreads();
@@ -394,11 +393,11 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
       const u32 g1 = gindex(e1);
       const u32 widx = (g1 & gm) << t;
       const L9 x = lds9_get<LT>(lds, e1), y = lds9_get<LT>(lds, e2);
-      L9 sum = l9::add(x, y);                                                              // value < 8p
+      L9 sum = l9::add(x, y);                                                              // |value| < 8p
       l9::normalize(sum);
-      l9::clamp(sum, qp);                                                                  // < 2p
+      l9::clamp(sum, qp);                                                                  // [0, 1.01p)
       lds9_put<LT>(lds, e1, sum);
-      L9 d = l9::sub_bias<5, B29>(x, y);                                                   // value < 9p
+      L9 d = l9::sub(x, y);                                                                // |value| < 8p
       if (t + 1 == k) {
         l9::normalize(d);                                                                  // last stage: twiddle 1
         lds9_put<LT>(lds, e2, d);

@@ -557,18 +557,24 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
       if (he != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
     }
     if (f->L == 4 && !getenv("LCPC_NTT_PACKED")) {
-      // q * p for q < 32 as canonical 29-bit limbs: the table behind l9::clamp (lazy-limb NTT kernel)
-      std::vector<uint32_t> tab(32 * 12, 0);
-      uint64_t acc[5] = {0, 0, 0, 0, 0};
-      for (int q = 0; q < 32; q++) {
+      // (i - 24) * p for i < 64 as normalised signed 29-bit limbs (limbs 0..7 in [0, 2^29), limb 8 two's complement):
+      // the table behind l9::clamp (lazy-limb NTT kernel; QOFF in field_dev.h)
+      std::vector<uint32_t> tab(64 * 12, 0);
+      for (int i = 0; i < 64; i++) {
+        const int q = i - 24;
+        uint64_t mag[5] = {0, 0, 0, 0, 0};                      // |q| * p
+        unsigned __int128 cy = 0;
+        for (int w = 0; w < 5; w++) { cy += (unsigned __int128)(w < 4 ? f->p[w] : 0) * (uint64_t)(q < 0 ? -q : q); mag[w] = (uint64_t)cy; cy >>= 64; }
+        if (q < 0) {                                            // two's complement over 320 bits
+          unsigned __int128 c2 = 1;
+          for (int w = 0; w < 5; w++) { c2 += (unsigned __int128)(~mag[w]); mag[w] = (uint64_t)c2; c2 >>= 64; }
+        }
         for (int k = 0; k < 9; k++) {
           const int b = 29 * k, w = b / 64, sh = b % 64;
-          uint64_t x = acc[w] >> sh;
-          if (sh > 35) x |= acc[w + 1] << (64 - sh);
-          tab[q * 12 + k] = (uint32_t)(x & ((1u << 29) - 1));
+          uint64_t x = mag[w] >> sh;
+          if (sh > 35) x |= mag[w + 1] << (64 - sh);
+          tab[i * 12 + k] = k < 8 ? (uint32_t)(x & ((1u << 29) - 1)) : (uint32_t)x;      // limb 8: bits 232..263, sign-extended
         }
-        unsigned __int128 cy = 0;
-        for (int w = 0; w < 5; w++) { cy += (unsigned __int128)acc[w] + (w < 4 ? f->p[w] : 0); acc[w] = (uint64_t)cy; cy >>= 64; }
       }
       if ((rc = dev_alloc(c, &c->d_qp29, tab.size() * 4))) { lcpc_ctx_destroy(c); return rc; }
       if (hipMemcpy(c->d_qp29, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { lcpc_ctx_destroy(c); return LCPC_ERR_HIP; }
