@@ -178,12 +178,13 @@ def main():
                 traffic = round((2.0 * v["FETCH_KB"] + v["WRITE_KB"]) * 1024 / 1e9, 3)
                 traffic_src = "profiles/r01_pmc_latest.json (rocprofv3 --pmc; GB per launch = 2*FETCH_SIZE + WRITE_SIZE; " \
                               "2-pass NTT: each pass reads+writes the matrix, pass 1 also writes LcCommit.coeffs)"
-    roofline = {"bound": "hbm", "kernel": "ntt_pass_l9_kernel (row NTT, Ft255 lazy-limb variant; %d launches per commit)" % ntt_launches,
+    roofline = {"bound": "hbm", "kernel": "ntt_pass_l9_kernel (row NTT, Ft255 signed lazy-limb variant; %d launches per commit)" % ntt_launches,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_unit": "GB/launch", "traffic_source": traffic_src,
                 "algorithmic_GB_per_launch": round(enc_bytes / ntt_launches / 1e9, 3),
                 "avg_launch_ms": round(ntt_ms, 4),
-                "note": "255-bit modular multiply makes this kernel integer-VALU-bound, not HBM-bound (DESIGN.md)",
+                "note": "255-bit modular multiply: integer-VALU work at the board power limit (~1.33 kW, sclk ~2.1 GHz: "
+                        "profiles/r01e_clock_power.txt), not HBM-bound (DESIGN.md section 6)",
                 "commit_GBps": round(commit_bytes / (tm.total_ms * 1e-3) / 1e9, 1) if tm.total_ms > 0 else None,
                 "group_ms": {"encode": round(tm.encode_ms, 3), "hash": round(tm.hash_ms, 3), "merkle": round(tm.merkle_ms, 3),
                              "total": round(tm.total_ms, 3)}}

@@ -122,7 +122,8 @@ int  lcpc_get_root(lcpc_ctx *ctx, uint8_t root[32]);                /* get_root 
 int  lcpc_commit_dims(const lcpc_ctx *ctx, uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols,
                       uint64_t *n_hashes);                           /* get_n_rows/.. lib.rs:283-296 */
 int  lcpc_get_hashes(lcpc_ctx *ctx, uint8_t *hashes);               /* LcCommit.hashes: (2*np2-1)*32 bytes */
-int  lcpc_get_comm(lcpc_ctx *ctx, uint64_t row0, uint64_t n_rows, uint64_t *out);    /* LcCommit.comm rows */
+int  lcpc_get_comm(lcpc_ctx *ctx, uint64_t row0, uint64_t n_rows, uint64_t *out);    /* LcCommit.comm rows (Montgomery form,
+                                                                                         whatever the device keeps) */
 int  lcpc_get_coeffs(lcpc_ctx *ctx, uint64_t row0, uint64_t n_rows, uint64_t *out);  /* LcCommit.coeffs rows */
 
 /* collapse_columns (lib.rs:1095-1123; test alias eval_outer lib.rs:1176-1202) for n_tensors tensors

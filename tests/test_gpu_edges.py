@@ -195,3 +195,43 @@ def test_lazy_limb_ntt_range_stress(oracle):
         got = enc.encode(rows).reshape(len(pats), n, 4)
         for r in range(len(pats)):
             assert (got[r] == oenc.encode(rows[r].copy())).all(), (log_n, n_per_row, r)
+
+
+@pytest.mark.parametrize("log_n,n_per_row,n_rows", [(1, 1, 3), (2, 2, 5), (3, 4, 2), (5, 16, 33), (10, 512, 4), (11, 1024, 3), (11, 2047, 2),
+                                                    (12, 1024, 3), (13, 4096, 2), (13, 7983, 2), (17, 65536, 2)])
+def test_canonical_comm_commit_stress(oracle, log_n, n_per_row, n_rows):
+    """The Ft255 Ligero commit keeps comm in canonical form on the device: the conversion rides on the NTT's twiddle
+    multiplies (second table for "block 0" butterflies, an explicit reduction for the 2 or 4 elements per row that
+    only ever meet trivial twiddles) and the column hash reads the result as it is.  Shapes cover: one stage only,
+    a single radix-4 round, odd stage counts (radix-2 tail), one and two passes, rates 1/2 (zero upper half in the
+    first round), 1/4 and ~1 (generic block-0 path).  Inputs push the signed lazy-limb bounds (all p-1, saturated
+    29-bit fields, alternating 0 / p-1).  comm read back through the ABI is Montgomery form again, columns opened
+    by prove() too."""
+    import pyref as P
+    O = oracle
+    F = P.FT255
+    n = 1 << log_n
+    sat = sum(((1 << 29) - 1) << (29 * k) for k in range(9)) % F.p
+    pats = [[F.p - 1], [0, F.p - 1], [sat, F.p - 2, 1], [(F.p - 1) // 2, F.p - 1, F.p - 1, 0, 3]]
+    enc = LigeroEncoding.new_from_dims(3, n_per_row, n)
+    oenc = O.Encoding.ligero_from_dims(3, n_per_row, n)
+    for pi, pat in enumerate(pats):
+        n_coeffs = n_rows * n_per_row - (pi % 2)                    # ragged last row every other time
+        reps = (n_coeffs + len(pat) - 1) // len(pat)
+        coeffs = np.tile(O.to_mont(3, pat), (reps, 1))[:n_coeffs]
+        c = LcCommit.commit(coeffs, enc)
+        oc = O.Commit.commit(coeffs, oenc)
+        assert (c.comm() == oc.comm()).all(), (log_n, pi)
+        assert (c.coeffs() == oc.coeffs()).all()
+        assert (c.hashes() == oc.hashes()).all() and c.get_root() == oc.get_root()
+        if c.n_rows > 1:
+            assert (c.comm(1, 1) == oc.comm()[n:2 * n]).all()       # partial read-out converts the right rows
+    coeffs = O.random_elems(3, n_rows * n_per_row, 5 + log_n)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc)
+    root = c.get_root()
+    assert root == oc.get_root()
+    t = O.random_elems(3, c.n_rows, 9)
+    pf = c.prove(t, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+    opf, _ = oc.prove(t, oenc, mk_transcript(O.Transcript, root, enc.get_n_col_opens()))
+    assert pf.to_bytes() == opf

@@ -1,0 +1,44 @@
+#!/bin/bash
+# tools/profile_round.sh TAG -- everything profiles/ holds for one state of the code, as text, under gpurun_out/prof_TAG/:
+#   bench_line.json           python bench.py (un-profiled, with the CPU baseline)
+#   bench_kernel_stats.txt    rocprofv3 --kernel-trace --stats of the same command (no CPU baseline)
+#   bench_pmc_{fetch,write,sq}.txt + pmc.json     separate --pmc passes (never combined with traces)
+#   clock_power.txt           rocm-smi sclk / socket power sampled while the bench loops
+#   configs.jsonl, c3_kernel_stats.txt, c5_kernel_stats.txt   the other BASELINE.json configs
+# Run on the MI355X box:  gpurun -- 'bash tools/profile_round.sh r01e'
+TAG=${1:-latest}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof_$TAG
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+python $R/bench.py > $O/bench_line.json 2> $O/bench_stderr.log
+db() { find $1 -name '*.db' | head -1; }
+rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- $BENCH > $O/kt.log 2>&1
+python $R/tools/rocpd_summary.py $(db $O/kt) > $O/bench_kernel_stats.txt
+rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
+python $R/tools/rocpd_summary.py $(db $O/fetch) --pmc > $O/bench_pmc_fetch.txt
+rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
+python $R/tools/rocpd_summary.py $(db $O/write) --pmc > $O/bench_pmc_write.txt
+python $R/tools/pmc_to_json.py $(db $O/fetch) $(db $O/write) $O/pmc.json > /dev/null
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
+  -d $O/sq -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/sq.log 2>&1
+python $R/tools/rocpd_summary.py $(db $O/sq) --pmc > $O/bench_pmc_sq.txt
+# clocks / power while the bench loops
+python $R/bench.py --steps 1200 --warmup 2 --no-cpu-baseline > $O/clk_bench.log 2>&1 &
+BP=$!
+echo "# rocm-smi samples every 0.5 s during: python bench.py --steps 1200 (idle samples dropped): sclk, socket power (W)" > $O/clock_power.txt
+while kill -0 $BP 2>/dev/null; do
+  rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Socket" | sed -e 's/.*sclk clock level: //' -e 's/.*Power (W)://' | tr '\n' ' '
+  echo
+  sleep 0.5
+done | grep -v "([0-9][0-9]Mhz)\|([0-9][0-9][0-9]Mhz)" >> $O/clock_power.txt
+tail -1 $O/clk_bench.log | cut -c1-220 >> $O/clock_power.txt
+# the other configs
+python $R/tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.log
+rocprofv3 --kernel-trace --stats -d $O/c3 -o c3 -- python $R/tools/bench_configs.py c3 > $O/c3.log 2>&1
+python $R/tools/rocpd_summary.py $(db $O/c3) > $O/c3_kernel_stats.txt
+rocprofv3 --kernel-trace --stats -d $O/c5 -o c5 -- python $R/tools/bench_configs.py c5 > $O/c5.log 2>&1
+python $R/tools/rocpd_summary.py $(db $O/c5) > $O/c5_kernel_stats.txt
+rm -rf $O/kt $O/fetch $O/write $O/sq $O/c3 $O/c5     # raw .db files stay out of the merge-back
+ls -la $O
