@@ -52,6 +52,7 @@ typedef enum {
   LCPC_ERR_HIP = -16,
   LCPC_ERR_NOMEM = -17,
   LCPC_ERR_NO_DEVICE = -18,
+  LCPC_ERR_XCHG = -19,      /* the caller's all-gather callback of a sharded prove failed */
   /* VerifierError, lib.rs:137-166 */
   LCPC_VERR_NUM_COL_OPENS = -32,
   LCPC_VERR_COLUMN_PATH = -33,
@@ -181,6 +182,21 @@ int  lcpc_collapse_device(lcpc_ctx *ctx, const uint64_t *tensors_dev, uint32_t n
                           uint64_t *polys_dev);
 int  lcpc_field_sum_device(lcpc_ctx *ctx, const uint64_t *parts_dev, uint32_t n_parts, uint64_t n_elems,
                            void *stream, uint64_t *out_dev);
+/* LcCommit::prove (lib.rs:1004-1093) on a row-sharded commitment (after lcpc_commit_shard_device +
+ * lcpc_commit_finish_device on every rank).  collapse_columns splits by rows: each rank sums its rows, the partial
+ * polynomials are all-gathered and added mod p; open_column gathers each rank's rows of the requested columns and
+ * all-gathers them; transcript, challenges and bincode are computed identically on every rank, so every rank returns
+ * the same proof bytes (== the unsharded proof).  The exchange is the caller's: `allgather(user, bytes)` must
+ * all-gather the first `bytes` bytes of send_dev from every rank into recv_dev (rank g's block at g * bytes) -- e.g.
+ * ncclAllGather on RCCL, torch.distributed.all_gather_into_tensor -- and return 0 once recv_dev is complete and
+ * visible to the null stream.  All ranks must call with the same outer_tensor (all n_rows_total entries) and the
+ * same transcript state.  send_dev: max_bytes, recv_dev: shard_count * max_bytes device bytes,
+ * max_bytes >= lcpc_prove_sharded_bytes().  3 exchanges for n_degree_tests = 1. */
+typedef int (*lcpc_allgather_fn)(void *user, uint64_t bytes);
+uint64_t lcpc_prove_sharded_bytes(const lcpc_ctx *ctx, uint64_t n_rows_total);
+int  lcpc_prove_sharded(lcpc_ctx *ctx, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
+                        uint8_t *send_dev, uint8_t *recv_dev, uint64_t max_bytes, lcpc_allgather_fn allgather, void *user,
+                        uint8_t **proof, uint64_t *proof_len, uint64_t *cols_opened);
 
 /* ---- measurement hooks (bench.py): HIP-event time of each kernel group of the last commit, ms ---- */
 typedef struct {

@@ -25,6 +25,8 @@ class LcpcTimings(C.Structure):
 
 # every symbol include/lcpc_hip.h declares: name -> (restype, argtypes)
 _vp, _u64, _u32, _i32, _sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_size_t
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)      # lcpc_allgather_fn (include/lcpc_hip.h)
+
 SYMBOLS = {
     "lcpc_abi_version": (_i32, []),
     "lcpc_ctx_create": (_i32, [C.POINTER(LcpcParams), C.POINTER(_vp)]),
@@ -63,6 +65,8 @@ SYMBOLS = {
     "lcpc_commit_finish_device": (_i32, [_vp, _vp, _u64, _u32, _vp, _vp]),
     "lcpc_collapse_device": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "lcpc_field_sum_device": (_i32, [_vp, _vp, _u32, _u64, _vp, _vp]),
+    "lcpc_prove_sharded_bytes": (_u64, [_vp, _u64]),
+    "lcpc_prove_sharded": (_i32, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, ALLGATHER_FN, _vp, _vp, _vp, _vp]),
     "lcpc_set_timing": (_i32, [_vp, _i32]),
     "lcpc_get_timings": (_i32, [_vp, C.POINTER(LcpcTimings)]),
 }

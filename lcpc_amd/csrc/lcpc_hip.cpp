@@ -226,9 +226,10 @@ int ensure_scratch(lcpc_ctx* c, uint64_t bytes) {
 uint64_t leaf_chunks(const lcpc_ctx* c, uint64_t n_rows) { return (32 + elem_bytes(c) * n_rows + 1023) / 1024; }
 
 // rows / chunks of shard `rank` (DESIGN.md "multi-GPU"): chunk-aligned row blocks
-void shard_layout(const lcpc_ctx* c, uint64_t n_rows, uint64_t* rb, uint64_t* re, uint64_t* cb, uint64_t* ce, uint64_t* nch) {
+void shard_layout_of(const lcpc_ctx* c, uint64_t g, uint64_t n_rows, uint64_t* rb, uint64_t* re, uint64_t* cb, uint64_t* ce, uint64_t* nch) {
   const uint64_t n_chunks = leaf_chunks(c, n_rows);
-  const uint64_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1, g = G > 1 ? c->prm.shard_rank : 0;
+  const uint64_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
+  if (G == 1) g = 0;
   const uint64_t c0 = n_chunks * g / G, c1 = n_chunks * (g + 1) / G;
   const uint64_t F = elem_bytes(c);
   auto first_row = [&](uint64_t chunk) -> uint64_t {   // first row whose bytes start in or after this chunk
@@ -241,6 +242,9 @@ void shard_layout(const lcpc_ctx* c, uint64_t n_rows, uint64_t* rb, uint64_t* re
   *rb = first_row(c0);
   *re = c1 >= n_chunks ? n_rows : first_row(c1);
   if (c0 == c1) *re = *rb;
+}
+void shard_layout(const lcpc_ctx* c, uint64_t n_rows, uint64_t* rb, uint64_t* re, uint64_t* cb, uint64_t* ce, uint64_t* nch) {
+  shard_layout_of(c, c->prm.shard_rank, n_rows, rb, re, cb, ce, nch);
 }
 
 // aligned power-of-two decomposition of the chunk range [c0, c1): the subtree nodes a shard exchanges
@@ -473,6 +477,7 @@ const char* lcpc_strerror(int s) {
     case LCPC_ERR_HIP: return "HIP runtime error";
     case LCPC_ERR_NOMEM: return "out of device memory";
     case LCPC_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case LCPC_ERR_XCHG: return "all-gather callback of the sharded prove failed";
     case LCPC_VERR_NUM_COL_OPENS: return "wrong number of column openings in proof";
     case LCPC_VERR_COLUMN_PATH: return "column verification: merkle path failed";
     case LCPC_VERR_COLUMN_EVAL: return "column verification: eval dot product failed";
@@ -982,11 +987,93 @@ static void absorb_poly(Transcript& tr, const uint8_t* label, const FieldDesc& f
   for (uint64_t i = 0; i < n; i++) tr.append_message(label, 6, reinterpret_cast<const uint8_t*>(&canon[i * L]), 8 * L);
 }
 
-int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t** proof, uint64_t* proof_len,
-               uint64_t* cols_opened) {
+// The exchange of a row-sharded prove: every rank contributes `bytes` from send_dev, receives all
+// ranks' blocks in rank order in recv_dev.
+namespace {
+struct ShardXchg {
+  uint8_t *send_dev, *recv_dev;
+  uint64_t max_bytes;
+  lcpc_allgather_fn fn;
+  void* user;
+};
+// collapse over ALL rows of a sharded commitment: local partial sums, all-gather, sum mod p (lib.rs:1095-1123 split by rows)
+int collapse_sharded(lcpc_ctx* c, const ShardXchg& x, const uint64_t* tensors_full, uint32_t nt, uint64_t* polys) {
+  const size_t eb = elem_bytes(c);
+  const int L = c->L;
+  const uint64_t bytes = (uint64_t)nt * c->n_per_row * eb;
+  if (bytes > x.max_bytes) return LCPC_ERR_ARG;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    if (c->n_rows_local == 0) {
+      HIPCHK(c, hipMemsetAsync(x.send_dev, 0, bytes, nullptr));
+    } else {
+      std::vector<uint64_t> loc((size_t)nt * c->n_rows_local * L);
+      for (uint32_t t = 0; t < nt; t++)
+        memcpy(&loc[(size_t)t * c->n_rows_local * L], tensors_full + ((size_t)t * c->n_rows + c->row_begin) * L, c->n_rows_local * eb);
+      const size_t tb = (loc.size() * 8 + 255) & ~(size_t)255;
+      int rc = ensure_scratch(c, tb + collapse_scratch_bytes(c, 2) + 256);
+      if (rc) return rc;
+      uint32_t* d_t = c->d_scratch;
+      HIPCHK(c, hipMemcpyAsync(d_t, loc.data(), loc.size() * 8, hipMemcpyHostToDevice, nullptr));
+      if ((rc = collapse_run(c, d_t, nt, nullptr, reinterpret_cast<uint32_t*>(x.send_dev)))) return rc;
+    }
+    HIPCHK(c, hipStreamSynchronize(nullptr));
+  }
+  if (x.fn(x.user, bytes) != 0) return LCPC_ERR_XCHG;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  HIPCHK(c, launch_field_sum(c->NL, reinterpret_cast<const uint32_t*>(x.recv_dev), c->prm.shard_count, (uint64_t)nt * c->n_per_row,
+                             reinterpret_cast<uint32_t*>(x.send_dev), nullptr));
+  HIPCHK(c, hipMemcpy(polys, x.send_dev, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+// open_column for n columns of a sharded commitment: every rank gathers its rows, one all-gather, columns assembled in
+// row order on the host; the Merkle paths come from the (replicated) tree
+int open_sharded(lcpc_ctx* c, const ShardXchg& x, const uint64_t* cols, uint32_t n, uint64_t* vals, uint8_t* paths) {
+  const size_t eb = elem_bytes(c);
+  const uint32_t G = c->prm.shard_count;
+  std::vector<uint64_t> rb(G), re(G);
+  uint64_t max_rows = 0;
+  for (uint32_t g = 0; g < G; g++) {
+    uint64_t cb, ce, nch;
+    shard_layout_of(c, g, c->n_rows, &rb[g], &re[g], &cb, &ce, &nch);
+    max_rows = std::max(max_rows, re[g] - rb[g]);
+  }
+  const uint64_t bytes = (uint64_t)n * max_rows * eb;
+  if (bytes > x.max_bytes) return LCPC_ERR_ARG;
+  std::vector<uint64_t> loc((size_t)n * std::max<uint64_t>(c->n_rows_local, 1) * c->L);
+  int rc = lcpc_open_columns(c, cols, n, c->n_rows_local ? loc.data() : nullptr, paths);      // local rows + paths
+  if (rc) return rc;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    if (c->n_rows_local) HIPCHK(c, hipMemcpy(x.send_dev, loc.data(), (size_t)n * c->n_rows_local * eb, hipMemcpyHostToDevice));
+  }
+  if (x.fn(x.user, bytes) != 0) return LCPC_ERR_XCHG;
+  std::vector<uint8_t> all((size_t)G * bytes);
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    HIPCHK(c, hipMemcpy(all.data(), x.recv_dev, all.size(), hipMemcpyDeviceToHost));
+  }
+  for (uint32_t g = 0; g < G; g++) {
+    const uint64_t nr_g = re[g] - rb[g];
+    for (uint32_t k = 0; k < n && nr_g; k++)       // rank g's block: [k][its rows], contiguous
+      memcpy(reinterpret_cast<uint8_t*>(vals) + ((size_t)k * c->n_rows + rb[g]) * eb, &all[(size_t)g * bytes + (size_t)k * nr_g * eb], nr_g * eb);
+  }
+  return 0;
+}
+}  // namespace
+
+static int prove_impl(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t** proof, uint64_t* proof_len,
+                      uint64_t* cols_opened, const ShardXchg* xchg) {
   if (!c || !outer || !trw || !proof || !proof_len) return LCPC_ERR_ARG;
   if (!c->committed) return LCPC_ERR_STATE;
-  if (c->prm.shard_count > 1) return LCPC_ERR_STATE;     // sharded prove is driven by the caller (collapse_device + all_gather)
+  if ((c->prm.shard_count > 1) != (xchg != nullptr)) return LCPC_ERR_STATE;   // sharded contexts prove through lcpc_prove_sharded
+  auto collapse = [&](const uint64_t* tensors, uint32_t nt, uint64_t* polys) -> int {
+    return xchg ? collapse_sharded(c, *xchg, tensors, nt, polys) : lcpc_collapse(c, tensors, nt, polys);
+  };
   if (!lcpc_dims_ok(c, c->n_per_row, c->n_cols)) return LCPC_ERR_COMMIT;      // check_comm lib.rs:1015
   if (n_outer != c->n_rows) return LCPC_ERR_OUTER_TENSOR;                     // lib.rs:1016-1018
   const FieldDesc& f = *c->f;
@@ -1012,7 +1099,7 @@ int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transc
       nt = 2;
     }
     double t0 = now();
-    int rc = lcpc_collapse(c, tensors.data(), nt, polys.data());
+    int rc = collapse(tensors.data(), nt, polys.data());
     if (rc) return rc;
     t_collapse += now() - t0;
     p_random[i].assign(polys.begin(), polys.begin() + np * L);
@@ -1022,7 +1109,7 @@ int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transc
     t_absorb += now() - t0;
   }
   if (!have_eval) {                                                           // lib.rs:1053-1064
-    int rc = lcpc_collapse(c, outer, 1, p_eval.data());
+    int rc = collapse(outer, 1, p_eval.data());
     if (rc) return rc;
   }
   tp[1] = now();
@@ -1037,7 +1124,8 @@ int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transc
   std::vector<uint64_t> vals((size_t)n_open * nr * L);
   std::vector<uint8_t> paths((size_t)n_open * c->path_len * 32 + 32);
   tp[3] = now();
-  int rc = lcpc_open_columns(c, cols.data(), (uint32_t)n_open, vals.data(), paths.data());   // lib.rs:1081-1084
+  int rc = xchg ? open_sharded(c, *xchg, cols.data(), (uint32_t)n_open, vals.data(), paths.data())
+                : lcpc_open_columns(c, cols.data(), (uint32_t)n_open, vals.data(), paths.data());   // lib.rs:1081-1084
   if (rc) return rc;
   tp[4] = now();
   // bincode 1.3 of WrappedLcEvalProof (lib.rs:550-560): n_cols, p_eval, p_random_vec, columns
@@ -1061,6 +1149,34 @@ int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transc
     fprintf(stderr, "[lcpc_prove] collapse %.2f ms, absorb p_random %.2f, absorb p_eval %.2f, challenges+alloc %.2f, open %.2f, bincode %.2f, total %.2f\n",
             t_collapse, t_absorb, tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], now() - tp[4], now() - tp[0]);
   return 0;
+}
+
+int lcpc_prove(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t** proof, uint64_t* proof_len,
+               uint64_t* cols_opened) {
+  return prove_impl(c, outer, n_outer, trw, proof, proof_len, cols_opened, nullptr);
+}
+
+uint64_t lcpc_prove_sharded_bytes(const lcpc_ctx* c, uint64_t n_rows_total) {
+  if (!c || n_rows_total == 0) return 0;
+  const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
+  uint64_t max_rows = 0;
+  for (uint32_t g = 0; g < G; g++) {
+    uint64_t rb, re, cb, ce, nch;
+    shard_layout_of(c, g, n_rows_total, &rb, &re, &cb, &ce, &nch);
+    max_rows = std::max(max_rows, re - rb);
+  }
+  const uint64_t eb = elem_bytes(c);
+  return std::max<uint64_t>(2 * c->n_per_row * eb, lcpc_get_n_col_opens(c) * max_rows * eb);
+}
+
+int lcpc_prove_sharded(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t* send_dev, uint8_t* recv_dev,
+                       uint64_t max_bytes, lcpc_allgather_fn fn, void* user, uint8_t** proof, uint64_t* proof_len,
+                       uint64_t* cols_opened) {
+  if (!c || !send_dev || !recv_dev || !fn) return LCPC_ERR_ARG;
+  if (c->prm.shard_count <= 1) return LCPC_ERR_STATE;
+  if (c->committed && max_bytes < lcpc_prove_sharded_bytes(c, c->n_rows)) return LCPC_ERR_ARG;
+  const ShardXchg x{send_dev, recv_dev, max_bytes, fn, user};
+  return prove_impl(c, outer, n_outer, trw, proof, proof_len, cols_opened, &x);
 }
 
 // ---- verify (lib.rs:832-1000) ----------------------------------------------------------------------------

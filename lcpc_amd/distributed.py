@@ -9,7 +9,9 @@ subtree of the BLAKE3 tree), so it sends 1-2 CVs per column instead of one per c
 step of the path is ONE all-gather of those node CVs (n_cols x 32 B per node, equal-sized padded blocks);
 every rank then folds the nodes into leaf digests straight out of the gather buffer (node table, no
 re-packing copy) and builds the Merkle tree redundantly (~1 % of the work).  No other collective exists on the
-commit path.
+commit path.  `sharded_prove` is the prover on such a commitment: collapse_columns splits by rows
+(partial sums per rank, all-gather, sum mod p), open_column gathers each rank's rows of the opened columns
+(one more all-gather); the transcript runs identically on every rank, so every rank ends with the same proof.
 
 The compute is delegated to an `engine`, so that the exchange logic here can be exercised on CPU (gloo,
 world_size 2/3) with a stand-in engine from the tests while the product engine is HIP:
@@ -99,6 +101,58 @@ class HipShardEngine:
         self.enc._check(_lib.lib().lcpc_commit_finish_device(self.enc._h, C.c_void_p(gathered.data_ptr()), n_rows_total, slots,
                                                              C.c_void_p(st), root))
         return bytes(root) if want_root else None
+
+
+def allgather_bytes(send, recv, nbytes, group=None):
+    """all-gather the first nbytes of the uint8 device tensor `send` into `recv` (rank g at [g*nbytes, (g+1)*nbytes))."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        recv[:nbytes].copy_(send[:nbytes])
+    elif dist.get_backend(group) == "gloo" and send.is_cuda:       # debugging path, see exchange_nodes
+        host = torch.empty(world * nbytes, dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, send[:nbytes].cpu(), group=group)
+        recv[:world * nbytes].copy_(host)
+    else:
+        dist.all_gather_into_tensor(recv[:world * nbytes], send[:nbytes], group=group)
+    if send.is_cuda:
+        torch.cuda.synchronize()
+
+
+def sharded_prove(enc, outer_tensor, tr, group=None, allgather=None):
+    """LcCommit::prove on the row-sharded commitment held by `enc`'s context (lcpc_prove_sharded).  Collective: every
+    rank calls it with the same outer_tensor (n_rows_total x L) and an identical transcript; returns (proof bytes,
+    opened columns), identical on every rank.  `allgather(send, recv, nbytes)` defaults to torch.distributed."""
+    import numpy as np
+    lib = _lib.lib()
+    t = np.ascontiguousarray(outer_tensor, np.uint64).reshape(-1, enc.L)
+    world = max(1, enc.params.shard_count)
+    nb = int(lib.lcpc_prove_sharded_bytes(enc._h, t.shape[0]))
+    dev = torch.device("cuda", enc.params.device)
+    send = torch.empty(max(nb, 64), dtype=torch.uint8, device=dev)
+    recv = torch.empty(max(nb, 64) * world, dtype=torch.uint8, device=dev)
+    ag = allgather or (lambda s, r, n: allgather_bytes(s, r, n, group))
+    err = []
+
+    def cb(_user, nbytes):
+        try:
+            ag(send, recv, int(nbytes))
+            return 0
+        except Exception as e:      # never unwind through the C frame
+            err.append(e)
+            return 1
+
+    fn = _lib.ALLGATHER_FN(cb)
+    pp, plen = C.c_void_p(), C.c_uint64()
+    cols = np.zeros(enc.get_n_col_opens(), np.uint64)
+    rc = lib.lcpc_prove_sharded(enc._h, t.ctypes.data_as(C.c_void_p), t.shape[0], tr._h, C.c_void_p(send.data_ptr()),
+                                C.c_void_p(recv.data_ptr()), send.numel(), fn, None, C.byref(pp), C.byref(plen),
+                                cols.ctypes.data_as(C.c_void_p))
+    if err:
+        raise err[0]
+    enc._check(rc)
+    data = C.string_at(pp, plen.value)
+    lib.lcpc_free(pp)
+    return data, cols
 
 
 def sharded_commit(engine, local_coeffs, n_rows_total, group=None, want_root=True):

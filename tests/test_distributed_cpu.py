@@ -170,3 +170,35 @@ def test_chunk_split_is_a_partition():
             assert sp[0][0] == 0 and sp[-1][1] == n
             assert all(sp[i][1] == sp[i + 1][0] for i in range(w - 1))
             assert max(e - b for b, e in sp) - min(e - b for b, e in sp) <= 1
+
+
+def _ag_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lcpc_amd.distributed import allgather_bytes
+        send = torch.full((100,), rank + 1, dtype=torch.uint8)
+        send[40:] = 99                                   # beyond nbytes: must not travel
+        recv = torch.zeros(100 * world, dtype=torch.uint8)
+        allgather_bytes(send, recv, 40)
+        q.put((rank, recv.numpy().tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_bytes_gloo():
+    """the exchange primitive of sharded_prove (lcpc_prove_sharded's callback): rank g's first nbytes land at g*nbytes."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ag_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = bytes([1] * 40 + [2] * 40 + [3] * 40) + bytes(300 - 120)
+    for _, got in res:
+        assert got == want

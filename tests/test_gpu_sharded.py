@@ -89,3 +89,79 @@ def test_sharded_brakedown_equals_unsharded(oracle, fid, n_per_row, n_rows, G):
         if re > rb:
             assert (c.comm(rb, re - rb) == oc.comm().reshape(n_rows, -1)[rb:re].reshape(-1, L)).all()
             assert (c.coeffs(rb, re - rb) == oc.coeffs().reshape(n_rows, -1)[rb:re].reshape(-1, L)).all()
+
+
+class ThreadAllGather:
+    """all-gather between G threads of one process (one per shard context): stands in for RCCL in lcpc_prove_sharded."""
+
+    def __init__(self, G):
+        import threading
+        self.G, self.bar, self.slots = G, threading.Barrier(G), [None] * G
+
+    def make(self, g):
+        def ag(send, recv, nbytes):
+            torch.cuda.synchronize()
+            self.slots[g] = send[:nbytes]
+            self.bar.wait()
+            for h in range(self.G):
+                recv[h * nbytes:(h + 1) * nbytes].copy_(self.slots[h])
+            torch.cuda.synchronize()
+            self.bar.wait()
+        return ag
+
+
+@pytest.mark.parametrize("kind,fid,n_rows,n_per_row,n_cols,G", [
+    ("ligero", 3, 512, 256, 512, 8),     # headline row count
+    ("ligero", 3, 70, 64, 128, 4),       # one rank owns no rows
+    ("ligero", 0, 300, 128, 256, 2),
+    ("ligero", 3, 20, 64, 128, 2),       # single chunk: rank 1 owns nothing
+    ("sdig", 3, 70, 300, 0, 4),
+])
+def test_sharded_prove_equals_unsharded(oracle, kind, fid, n_rows, n_per_row, n_cols, G):
+    """lcpc_prove_sharded on G shard contexts (threads + an in-process all-gather): every rank returns the proof of the
+    unsharded prover == the oracle's proof, byte for byte; the oracle verifier accepts it."""
+    import threading
+    from common import mk_transcript
+    from lcpc_amd import Transcript
+    from lcpc_amd.distributed import sharded_prove
+    O = oracle
+    L = O.limbs(fid)
+    coeffs = O.random_elems(fid, n_rows * n_per_row, 23)
+    dev = torch.from_numpy(coeffs.view(np.int64)).cuda().reshape(n_rows, n_per_row, L)
+    if kind == "ligero":
+        mk = lambda sh: LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=sh)
+        oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+    else:
+        oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 11, 3)
+        _, _, nc = oenc.get_dims(n_per_row)
+        mk = lambda sh: SdigEncoding(fid, None, 11, 3, 0, sh, _dims=(n_per_row, nc))
+    roots, engines = run_sharded(mk, G, dev, n_rows)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+    root = oc.get_root()
+    assert all(r == root for r in roots)
+    outer = O.random_elems(fid, n_rows, 29)
+    n_open = engines[0].enc.get_n_col_opens()
+    opf, ocols = oc.prove(outer, oenc, mk_transcript(O.Transcript, root, n_open))
+    tag = ThreadAllGather(G)
+    out = [None] * G
+
+    def work(g):
+        try:
+            out[g] = sharded_prove(engines[g].enc, outer, mk_transcript(Transcript, root, n_open), allgather=tag.make(g))
+        except Exception as e:                     # do not leave the other threads stuck at the barrier
+            out[g] = e
+            tag.bar.abort()
+
+    th = [threading.Thread(target=work, args=(g,)) for g in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    for g in range(G):
+        assert not isinstance(out[g], Exception), out[g]
+        data, cols = out[g]
+        assert data == opf, g
+        assert (cols == np.asarray(ocols, np.uint64)).all()
+    inner = O.random_elems(fid, n_per_row, 31)
+    rc, _ = O.verify(oenc, root, outer, inner, out[0][0], mk_transcript(O.Transcript, root, n_open))
+    assert rc == 0
