@@ -104,6 +104,10 @@ uint64_t lcpc_get_n_degree_tests(const lcpc_ctx *ctx);    /* ligero lib.rs:183-1
 uint32_t lcpc_field_limbs(const lcpc_ctx *ctx);           /* L */
 /* static `_get_dims(len)` without a context (ligero lib.rs:70-112; brakedown lib.rs:69-110) */
 int  lcpc_static_get_dims(const lcpc_params *params, uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols);
+/* new_ml(n_vars) (ligero lib.rs:128-135; brakedown lib.rs:114-123): the dims the reference picks for a multilinear
+ * polynomial with 2^n_vars monomials; build the context with new_from_dims semantics (n_per_row, n_cols) from them,
+ * as the reference does.  LCPC_ERR_DIMS where the reference's assert!s fire (ligero: non-power-of-two split). */
+int  lcpc_static_get_dims_ml(const lcpc_params *params, uint32_t n_vars, uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols);
 /* encode (ligero lib.rs:162-164, brakedown lib.rs:150-153), batched: `rows` holds n_rows rows of
  * n_cols elements each, first n_per_row = message, rest zero on entry; encoded in place. */
 int  lcpc_encode_rows(lcpc_ctx *ctx, uint64_t *rows_host, uint64_t n_rows);

@@ -145,6 +145,17 @@ def static_get_dims(field, encoding, length, rho=(1, 2), code=3):
     return a.value, b.value, c.value
 
 
+def static_get_dims_ml(field, encoding, n_vars, rho=(1, 2), code=3):
+    """the dims new_ml(n_vars) picks (ligero lib.rs:128-135, brakedown lib.rs:114-123); LcpcError(ERR_DIMS) where the
+    reference's assert!s fire."""
+    p = _params(field, encoding, 0, n_coeffs=1, rho=rho, code=code)
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = _lib.lib().lcpc_static_get_dims_ml(C.byref(p), n_vars, C.byref(a), C.byref(b), C.byref(c))
+    if rc:
+        raise LcpcError(rc)
+    return a.value, b.value, c.value
+
+
 class LigeroEncoding(_Encoding):
     """LigeroEncodingRho<Ft, Rn, Rd> (lcpc-ligero-pc/src/lib.rs:31-186); default rate 1/2 (lib.rs:189)."""
 
@@ -159,6 +170,12 @@ class LigeroEncoding(_Encoding):
     @classmethod
     def new(cls, field, length, rho=(1, 2), device=0, shard=(0, 1)):
         return cls(field, length, rho, device, shard)
+
+    @classmethod
+    def new_ml(cls, field, n_vars, rho=(1, 2), device=0):
+        """LigeroEncodingRho::new_ml (lib.rs:128-135)."""
+        _, n_per_row, n_cols = static_get_dims_ml(field, ENC_LIGERO, n_vars, rho)
+        return cls.new_from_dims(field, n_per_row, n_cols, rho, device)
 
     @classmethod
     def new_from_dims(cls, field, n_per_row, n_cols, rho=(1, 2), device=0, shard=(0, 1)):
@@ -179,6 +196,12 @@ class SdigEncoding(_Encoding):
     @classmethod
     def new(cls, field, length, seed, code=3, device=0):
         return cls(field, length, seed, code, device)
+
+    @classmethod
+    def new_ml(cls, field, n_vars, seed, code=3, device=0):
+        """SdigEncodingS::new_ml (lib.rs:114-123)."""
+        _, n_per_row, n_cols = static_get_dims_ml(field, ENC_SDIG, n_vars, code=code)
+        return cls.new_from_dims(field, n_per_row, n_cols, seed, code, device)
 
     @classmethod
     def new_from_dims(cls, field, n_per_row, n_cols, seed, code=3, device=0):

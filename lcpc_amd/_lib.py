@@ -39,6 +39,7 @@ SYMBOLS = {
     "lcpc_get_n_degree_tests": (_u64, [_vp]),
     "lcpc_field_limbs": (_u32, [_vp]),
     "lcpc_static_get_dims": (_i32, [C.POINTER(LcpcParams), _vp, _vp, _vp]),
+    "lcpc_static_get_dims_ml": (_i32, [_vp, _u32, _vp, _vp, _vp]),
     "lcpc_encode_rows": (_i32, [_vp, _vp, _u64]),
     "lcpc_commit": (_i32, [_vp, _vp, _u64, _vp]),
     "lcpc_commit_device": (_i32, [_vp, _vp, _u64, _vp, _vp]),

@@ -147,12 +147,15 @@ uint64_t sdig_codeword_length(const std::vector<LevelDims>& pre, const std::vect
   for (auto& d : post) c += d.m;
   return c;
 }
-bool sdig_n_per_row(const FieldDesc& f, uint64_t len, int code, uint64_t* out) {
+// new (lib.rs:103-110) and, with ml = true, new_ml (lib.rs:114-123: the first candidate is rounded up to a power of
+// two), both through _new_from_np1 (lib.rs:69-87)
+bool sdig_n_per_row(const FieldDesc& f, uint64_t len, int code, uint64_t* out, bool ml) {
   const uint64_t flog2 = f.flog2(), n_col_opens = sdig_n_col_opens(code);
   if (!n_col_opens || !len) return false;
   const double lncf = (double)(n_col_opens * len);
   const double ndt = (double)n_degree_tests(128, (uint64_t)std::ceil(std::sqrt(lncf)) * 2, flog2);
   uint64_t np1 = (uint64_t)std::ceil(std::sqrt(lncf / ndt));
+  if (ml) { uint64_t q = 1; while (q < np1) q <<= 1; np1 = q; }       // checked_next_power_of_two
   if (np1 > len) np1 = len;
   const uint64_t nr1 = (len + np1 - 1) / np1, nd1 = n_degree_tests(128, np1 * 2, flog2);
   const uint64_t np2 = np1 / 2;

@@ -31,7 +31,7 @@ struct LevelDims { uint64_t n, m, d; };                                  // (inp
 bool sdig_level_dims(const SdigSpec& s, uint64_t n, double log2p, std::vector<LevelDims>& pre, std::vector<LevelDims>& post);
 uint64_t sdig_codeword_length(const std::vector<LevelDims>& pre, const std::vector<LevelDims>& post);  // encode.rs:18-33
 // SdigEncoding::new's choice of n_per_row (brakedown lib.rs:103-110 -> 69-87)
-bool sdig_n_per_row(const FieldDesc& f, uint64_t len, int code, uint64_t* n_per_row);
+bool sdig_n_per_row(const FieldDesc& f, uint64_t len, int code, uint64_t* n_per_row, bool ml = false);
 
 // one expander matrix, CSR by *output* (the transpose view of the reference's CSC-by-input)
 struct CsrMatrix {

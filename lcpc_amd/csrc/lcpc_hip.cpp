@@ -512,6 +512,33 @@ int lcpc_static_get_dims(const lcpc_params* p, uint64_t* nr, uint64_t* np, uint6
   return LCPC_ERR_ARG;
 }
 
+// new_ml (ligero lib.rs:128-135, brakedown lib.rs:114-123): dims for a multilinear polynomial in n_vars variables
+int lcpc_static_get_dims_ml(const lcpc_params* p, uint32_t n_vars, uint64_t* nr, uint64_t* np, uint64_t* nc) {
+  if (!p || !nr || !np || !nc || n_vars >= 63) return LCPC_ERR_ARG;
+  const FieldDesc* f = field_desc((int)p->field);
+  if (!f) return LCPC_ERR_ARG;
+  const uint64_t n = (uint64_t)1 << n_vars;
+  if (p->encoding == LCPC_ENC_LIGERO) {
+    lcpc_params q = *p;
+    q.n_coeffs = n;
+    int rc = lcpc_static_get_dims(&q, nr, np, nc);
+    if (rc) return rc;
+    // the reference's assert!s (lib.rs:131-133)
+    if ((*nr & (*nr - 1)) || (*np & (*np - 1)) || *nr * *np != n) return LCPC_ERR_DIMS;
+    return 0;
+  } else if (p->encoding == LCPC_ENC_SDIG) {
+    SdigSpec s;
+    const int code = p->sdig_code ? (int)p->sdig_code : 3;
+    uint64_t npr;
+    if (!sdig_spec(code, &s) || !sdig_n_per_row(*f, n, code, &npr, true)) return LCPC_ERR_ARG;
+    std::vector<LevelDims> pre, post;
+    if (!sdig_level_dims(s, npr, (double)f->flog2(), pre, post)) return LCPC_ERR_DIMS;
+    *nr = (n + npr - 1) / npr; *np = npr; *nc = sdig_codeword_length(pre, post);
+    return 0;
+  }
+  return LCPC_ERR_ARG;
+}
+
 int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
   if (!p || !out) return LCPC_ERR_ARG;
   *out = nullptr;

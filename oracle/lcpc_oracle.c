@@ -685,11 +685,13 @@ static u64 sdig_n_col_opens(int code) { /* brakedown lib.rs:57-61 */
   sdig_spec_get(code, &s);
   return (u64)ceil(-128.0 / log2(1.0 - s.dist / 3.0));
 }
-static int sdig_n_per_row(const fld_t *f, u64 len, int code, u64 *out) { /* lib.rs:103-110, 69-87 */
+/* new (lib.rs:103-110) or, with ml != 0, new_ml (lib.rs:114-123), then _new_from_np1 (lib.rs:69-87) */
+static int sdig_n_per_row_x(const fld_t *f, u64 len, int code, int ml, u64 *out) {
   u64 flog2 = f->num_bits - 1, n_col_opens = sdig_n_col_opens(code);
   double lncf = (double)(n_col_opens * len);
   double ndt = (double)n_degree_tests(128, (u64)ceil(sqrt(lncf)) * 2, flog2);
   u64 np1 = (u64)ceil(sqrt(lncf / ndt));
+  if (ml) np1 = np2(np1);                               /* checked_next_power_of_two (lib.rs:119-121) */
   if (np1 > len) np1 = len;
   u64 nr1 = (len + np1 - 1) / np1, nd1 = n_degree_tests(128, np1 * 2, flog2);
   u64 np2_ = np1 / 2;
@@ -699,12 +701,13 @@ static int sdig_n_per_row(const fld_t *f, u64 len, int code, u64 *out) { /* lib.
   *out = sz1 < sz2 ? np1 : np2_;
   return 0;
 }
-int lo_sdig_get_dims(int fid, u64 len, int code, u64 *nr, u64 *np, u64 *nc) {
+static int sdig_n_per_row(const fld_t *f, u64 len, int code, u64 *out) { return sdig_n_per_row_x(f, len, code, 0, out); }
+static int sdig_dims_x(int fid, u64 len, int code, int ml, u64 *nr, u64 *np, u64 *nc) {
   const fld_t *f = getf(fid);
   sdig_spec s;
   if (!f || sdig_spec_get(code, &s)) return LO_ERR_ARG;
   u64 npr;
-  if (sdig_n_per_row(f, len, code, &npr)) return LO_ERR_ARG;
+  if (sdig_n_per_row_x(f, len, code, ml, &npr)) return LO_ERR_ARG;
   u64 pre[MAXLEV][3], post[MAXLEV][3];
   int t = sdig_get_dims(&s, npr, (double)(f->num_bits - 1), pre, post);
   if (t < 1) return LO_ERR_ARG;
@@ -712,6 +715,21 @@ int lo_sdig_get_dims(int fid, u64 len, int code, u64 *nr, u64 *np, u64 *nc) {
   for (int i = 0; i + 1 < t; i++) c += pre[i][1];
   for (int i = 0; i < t; i++) c += post[i][1];
   *nr = (len + npr - 1) / npr; *np = npr; *nc = c;
+  return 0;
+}
+int lo_sdig_get_dims(int fid, u64 len, int code, u64 *nr, u64 *np, u64 *nc) { return sdig_dims_x(fid, len, code, 0, nr, np, nc); }
+/* SdigEncodingS::new_ml (lib.rs:114-123): dims for 2^n_vars monomials */
+int lo_sdig_get_dims_ml(int fid, unsigned n_vars, int code, u64 *nr, u64 *np, u64 *nc) {
+  if (n_vars >= 63) return LO_ERR_ARG;
+  return sdig_dims_x(fid, (u64)1 << n_vars, code, 1, nr, np, nc);
+}
+/* LigeroEncodingRho::new_ml (ligero lib.rs:128-135): _get_dims + the three assert!s (LO_ERR_ARG when they fire) */
+int lo_ligero_get_dims_ml(int fid, unsigned n_vars, unsigned rn, unsigned rd, u64 *nr, u64 *np, u64 *nc) {
+  if (n_vars >= 63) return LO_ERR_ARG;
+  u64 n = (u64)1 << n_vars;
+  int rc = lo_ligero_get_dims(fid, n, rn, rd, nr, np, nc);
+  if (rc) return rc;
+  if ((*nr & (*nr - 1)) || (*np & (*np - 1)) || *nr * *np != n) return LO_ERR_ARG;
   return 0;
 }
 lo_enc *lo_sdig_new_from_dims(int fid, u64 n_per_row, u64 n_cols, u64 seed, int code) { /* lib.rs:126-137 + matgen.rs:28-52 */

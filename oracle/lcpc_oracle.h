@@ -76,6 +76,10 @@ lo_enc *lo_ligero_new(int fid, uint64_t len, unsigned rho_num, unsigned rho_den)
 lo_enc *lo_ligero_new_from_dims(int fid, uint64_t n_per_row, uint64_t n_cols, unsigned rho_num, unsigned rho_den);
 int     lo_sdig_get_dims(int fid, uint64_t len, int code,
                          uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols);
+int     lo_ligero_get_dims_ml(int fid, unsigned n_vars, unsigned rho_num, unsigned rho_den,
+                              uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols);   /* new_ml, ligero lib.rs:128-135 */
+int     lo_sdig_get_dims_ml(int fid, unsigned n_vars, int code,
+                            uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols);     /* new_ml, brakedown lib.rs:114-123 */
 lo_enc *lo_sdig_new(int fid, uint64_t len, uint64_t seed, int code);
 lo_enc *lo_sdig_new_from_dims(int fid, uint64_t n_per_row, uint64_t n_cols, uint64_t seed, int code);
 void    lo_enc_free(lo_enc *);

@@ -544,6 +544,18 @@ class LigeroEncoding:
         return (nr1, np1, nc1) if sz1 < sz2 else (nr2, np2, nc2)
 
     @classmethod
+    def dims_ml(cls, F, n_vars, rho=(1, 2)):
+        """new_ml (lib.rs:128-135): _get_dims + its assert!s; None where they fire."""
+        n = 1 << n_vars
+        d = cls.get_dims_len(F, n, rho)
+        if d is None:
+            return None
+        nr, np_, nc = d
+        if nr & (nr - 1) or np_ & (np_ - 1) or nr * np_ != n:
+            return None
+        return d
+
+    @classmethod
     def new(cls, F, length, rho=(1, 2)):
         _, np_, nc = cls.get_dims_len(F, length, rho)
         return cls(F, np_, nc, rho)
@@ -739,12 +751,15 @@ class SdigEncoding:
         return int(math.ceil(-128.0 / den))
 
     @classmethod
-    def n_per_row_for_len(cls, F, length, code=3):
-        """lib.rs:103-110 + 69-87 (new -> _new_from_np1), n_per_row only."""
+    def n_per_row_for_len(cls, F, length, code=3, ml=False):
+        """lib.rs:103-110 (new) or, ml=True, lib.rs:114-123 (new_ml: first candidate rounded up to a power of two),
+        then lib.rs:69-87 (_new_from_np1); n_per_row only."""
         n_col_opens = cls.n_col_opens_code(code)
         lncf = float(n_col_opens * length)
         ndt = float(n_degree_tests(cls.LAMBDA, int(math.ceil(math.sqrt(lncf))) * 2, F.flog2))
         np1 = int(math.ceil(math.sqrt(lncf / ndt)))
+        if ml:
+            np1 = next_pow2(np1)
         np1 = min(np1, length)
         nr1 = (length + np1 - 1) // np1
         nd1 = n_degree_tests(cls.LAMBDA, np1 * 2, F.flog2)
@@ -756,9 +771,9 @@ class SdigEncoding:
         return np1 if sz1 < sz2 else np2
 
     @classmethod
-    def dims_only(cls, F, length, code=3):
+    def dims_only(cls, F, length, code=3, ml=False):
         """(n_rows, n_per_row, n_cols) without generating matrices."""
-        npr = cls.n_per_row_for_len(F, length, code)
+        npr = cls.n_per_row_for_len(F, length, code, ml)
         S = SdigSpec(code)
         pre, post = sdig_get_dims(S, npr, float(F.flog2))
         n_cols = pre[0][0] + post[-1][0] + sum(d[1] for d in pre[:-1]) + sum(d[1] for d in post)

@@ -60,6 +60,8 @@ def lib():
             "lo_ligero_new": (vp, [C.c_int, C.c_uint64, C.c_uint, C.c_uint]),
             "lo_ligero_new_from_dims": (vp, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint, C.c_uint]),
             "lo_sdig_get_dims": (C.c_int, [C.c_int, C.c_uint64, C.c_int, vp, vp, vp]),
+            "lo_ligero_get_dims_ml": (C.c_int, [C.c_int, C.c_uint, C.c_uint, C.c_uint, vp, vp, vp]),
+            "lo_sdig_get_dims_ml": (C.c_int, [C.c_int, C.c_uint, C.c_int, vp, vp, vp]),
             "lo_sdig_new": (vp, [C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
             "lo_sdig_new_from_dims": (vp, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]),
             "lo_enc_free": (None, [vp]),

@@ -64,6 +64,27 @@ def test_static_dims_match_oracle(oracle):
                 assert lcpc_amd.static_get_dims(fid, lcpc_amd.ENC_SDIG, n, code=code) == (a.value, b.value, c.value)
 
 
+def test_new_ml_dims_match_oracle(oracle):
+    """LigeroEncoding::new_ml / SdigEncoding::new_ml shapes (lcpc_static_get_dims_ml) == the oracle's, incl. where
+    the reference's assert!s reject the split."""
+    import ctypes as C
+    for fid in (0, 3):
+        for n_vars in range(1, 31):
+            a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            for rho in ((1, 2), (1, 4), (38, 39)):
+                rc = oracle.lib().lo_ligero_get_dims_ml(fid, n_vars, rho[0], rho[1], C.byref(a), C.byref(b), C.byref(c))
+                if rc == 0:
+                    assert lcpc_amd.static_get_dims_ml(fid, lcpc_amd.ENC_LIGERO, n_vars, rho=rho) == (a.value, b.value, c.value)
+                else:
+                    with pytest.raises(lcpc_amd.LcpcError):
+                        lcpc_amd.static_get_dims_ml(fid, lcpc_amd.ENC_LIGERO, n_vars, rho=rho)
+            for code in range(1, 7):
+                if n_vars < 6:
+                    continue
+                assert oracle.lib().lo_sdig_get_dims_ml(fid, n_vars, code, C.byref(a), C.byref(b), C.byref(c)) == 0
+                assert lcpc_amd.static_get_dims_ml(fid, lcpc_amd.ENC_SDIG, n_vars, code=code) == (a.value, b.value, c.value)
+
+
 def test_transcript_matches_oracle(oracle):
     import random
     rnd = random.Random(4)

@@ -386,3 +386,26 @@ def test_brakedown_commit_device_fused_copy(oracle):
         assert (c.coeffs() == oc.coeffs()).all() and (c.comm() == oc.comm()).all() and (c.hashes() == oc.hashes()).all()
         t = O.random_elems(fid, n_rows, 63)
         assert (c.eval_outer(t) == oc.collapse(t)).all()
+
+
+@pytest.mark.parametrize("kind,fid,n_vars", [("ligero", 3, 14), ("ligero", 0, 16), ("sdig", 3, 13), ("sdig", 1, 12)])
+def test_new_ml_commit(oracle, kind, fid, n_vars):
+    """LigeroEncoding::new_ml / SdigEncoding::new_ml (ligero lib.rs:128-135, brakedown lib.rs:114-123): the multilinear
+    constructors pick their own shape; commit of 2^n_vars coefficients == the oracle with that shape."""
+    import ctypes as C
+    O = oracle
+    n = 1 << n_vars
+    coeffs = O.random_elems(fid, n, 57)
+    a, b, c_ = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    if kind == "ligero":
+        enc = LigeroEncoding.new_ml(fid, n_vars)
+        assert O.lib().lo_ligero_get_dims_ml(fid, n_vars, 1, 2, C.byref(a), C.byref(b), C.byref(c_)) == 0
+        oenc = O.Encoding.ligero_from_dims(fid, b.value, c_.value)
+    else:
+        enc = SdigEncoding.new_ml(fid, n_vars, 5)
+        assert O.lib().lo_sdig_get_dims_ml(fid, n_vars, 3, C.byref(a), C.byref(b), C.byref(c_)) == 0
+        oenc = O.Encoding.sdig_from_dims(fid, b.value, c_.value, 5, 3)
+    assert enc.get_dims(n) == (a.value, b.value, c_.value)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+    assert (c.hashes() == oc.hashes()).all() and c.get_root() == oc.get_root()

@@ -99,6 +99,28 @@ def test_get_dims_property(oracle):
                 assert (a.value, b.value, c.value) == P.SdigEncoding.dims_only(F, n, code)
 
 
+def test_new_ml_dims(oracle):
+    """new_ml (ligero lib.rs:128-135, brakedown lib.rs:114-123): C oracle == pyref for every n_vars, all rates / codes;
+    the Ligero assert!s (power-of-two split of 2^n_vars) fire in both or in neither."""
+    O = oracle
+    for F in (P.FT63, P.FT127, P.FT255):
+        for n_vars in range(1, 31):
+            a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            for rho in ((1, 2), (1, 4), (38, 39)):
+                rc = O.lib().lo_ligero_get_dims_ml(F.fid, n_vars, rho[0], rho[1], C.byref(a), C.byref(b), C.byref(c))
+                want = P.LigeroEncoding.dims_ml(F, n_vars, rho)
+                assert (rc == 0) == (want is not None), (F.fid, n_vars, rho)
+                if want:
+                    assert (a.value, b.value, c.value) == want
+                    assert a.value * b.value == 1 << n_vars
+            for code in range(1, 7):
+                if (1 << n_vars) < 64:
+                    continue
+                assert O.lib().lo_sdig_get_dims_ml(F.fid, n_vars, code, C.byref(a), C.byref(b), C.byref(c)) == 0
+                assert (a.value, b.value, c.value) == P.SdigEncoding.dims_only(F, 1 << n_vars, code, ml=True)
+                assert b.value & (b.value - 1) == 0 or b.value == 1 << n_vars       # n_per_row: a power of two
+
+
 def _mk_tr(T, root, n_col_opens):
     # lcpc-ligero-pc/src/tests.rs:243-245
     tr = T(b"test transcript")
