@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="debug: compare the sharded root with an unsharded commit of the same data")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
     import torch
     import torch.distributed as dist
     import lcpc_amd
@@ -116,6 +117,11 @@ def main():
 
         def step(sync=False):
             return sharded_commit(engine, coeffs, n_rows_total, want_root=sync)
+
+        # bring the communicator up outside the measured region (RCCL connects lazily on the first collective)
+        t_init = torch.zeros(1, device=dev)
+        dist.all_reduce(t_init)
+        torch.cuda.synchronize()
 
     def fence():
         if distributed:
