@@ -31,7 +31,8 @@ hipError_t launch_roots(int nl, const uint32_t* pw, uint32_t log_half, const uin
 
 struct LeafArgs {
   const uint32_t* comm;        // local rows, row-major
-  uint64_t row_stride;         // elements
+  uint64_t row_stride;         // elements between consecutive rows of a column (n_cols for the row-major comm)
+  uint64_t col_stride;         // elements between consecutive columns of a row (1 for row-major; n_rows for a position-major copy)
   uint64_t n_cols;
   int64_t  row_base;           // global index of local row 0
   uint64_t n_rows_total;
@@ -65,8 +66,9 @@ hipError_t launch_field_sum(int nl, const uint32_t* parts, uint32_t n_parts, uin
 
 // open_column: vals[k][r] = comm[r][cols[k]]; paths[k][lvl] = sibling digest.  r2 non-null: comm holds canonical
 // values, multiply by R^2 on the way out so that vals are Montgomery-form elements like everything else at the ABI
-hipError_t launch_gather_columns(int nl, const uint32_t* comm, uint64_t n_rows, uint64_t n_cols, const uint64_t* cols,
-                                 uint32_t n, uint32_t* vals, const uint32_t* r2, hipStream_t st);
+// element (r, c) at comm + (r * row_stride + c * col_stride) elements (row-major comm: n_cols, 1; position-major: 1, n_rows)
+hipError_t launch_gather_columns(int nl, const uint32_t* comm, uint64_t n_rows, uint64_t row_stride, uint64_t col_stride,
+                                 const uint64_t* cols, uint32_t n, uint32_t* vals, const uint32_t* r2, hipStream_t st);
 // elementwise representation change of n elements (in may equal out): to_mont = x * R (r2 = R^2 mod p, Montgomery
 // multiply), to_canon = x * R^-1 (Montgomery reduction = PrimeField::to_repr without the byte dump)
 hipError_t launch_to_mont(int nl, const uint32_t* in, uint64_t n, const uint32_t* r2, uint32_t* out, hipStream_t st);

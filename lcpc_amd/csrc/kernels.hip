@@ -480,7 +480,7 @@ __device__ __forceinline__ void leaf_load_raw(LeafRaw<NL, PH>& r, const LeafArgs
 #pragma unroll
   for (int x = 0; x < LeafRaw<NL, PH>::NEL; x++) {
     const int64_t row = row0 + x;
-    if (row >= 0 && (u64)row < a.n_rows_total) r.el[x] = fe_load<NL>(a.comm + ((u64)(row - a.row_base) * a.row_stride + col) * NL);
+    if (row >= 0 && (u64)row < a.n_rows_total) r.el[x] = fe_load<NL>(a.comm + ((u64)(row - a.row_base) * a.row_stride + col * a.col_stride) * NL);
     else r.el[x] = fe_zero<NL>();        // the 32-byte zero prefix (rows -1, -2, ..) and the tail past the message
   }
 }
@@ -848,12 +848,12 @@ hipError_t launch_field_sum(int nl, const u32* parts, u32 n_parts, u64 n_elems, 
 // K6: open_column gathers
 // =================================================================================================
 template <int NL>
-__global__ void __launch_bounds__(256) gather_columns_kernel(const u32* comm, u64 n_rows, u64 n_cols, const u64* cols,
+__global__ void __launch_bounds__(256) gather_columns_kernel(const u32* comm, u64 n_rows, u64 row_stride, u64 col_stride, const u64* cols,
                                                             u32* vals, const u32* r2) {
   const u32 k = blockIdx.y;
   const u64 c = cols[k];
   for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (u64)gridDim.x * 256) {
-    Fe<NL> v = fe_load<NL>(comm + (r * n_cols + c) * NL);
+    Fe<NL> v = fe_load<NL>(comm + (r * row_stride + c * col_stride) * NL);
     if (r2 != nullptr) v = fe_mul<NL>(v, fe_load<NL>(r2));  // canonical comm -> Montgomery form
     fe_store<NL>(vals + ((u64)k * n_rows + r) * NL, v);
   }
@@ -881,17 +881,17 @@ hipError_t launch_to_canon(int nl, const u32* in, u64 n, u32* out, hipStream_t s
   LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(to_canon_kernel<NLV>, dim3(gx), dim3(256), 0, st, in, n, out));
   return hipGetLastError();
 }
-hipError_t launch_gather_columns(int nl, const u32* comm, u64 n_rows, u64 n_cols, const u64* cols, u32 n, u32* vals,
+hipError_t launch_gather_columns(int nl, const u32* comm, u64 n_rows, u64 row_stride, u64 col_stride, const u64* cols, u32 n, u32* vals,
                                  const u32* r2, hipStream_t st) {
   if (n == 0) return hipSuccess;
   unsigned gx = (unsigned)((n_rows + 255) / 256);
   if (gx > 64) gx = 64;
   dim3 grid(gx, n);
   switch (nl) {
-    case 2: hipLaunchKernelGGL(gather_columns_kernel<2>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals, r2); break;
-    case 4: hipLaunchKernelGGL(gather_columns_kernel<4>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals, r2); break;
-    case 6: hipLaunchKernelGGL(gather_columns_kernel<6>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals, r2); break;
-    case 8: hipLaunchKernelGGL(gather_columns_kernel<8>, grid, dim3(256), 0, st, comm, n_rows, n_cols, cols, vals, r2); break;
+    case 2: hipLaunchKernelGGL(gather_columns_kernel<2>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, cols, vals, r2); break;
+    case 4: hipLaunchKernelGGL(gather_columns_kernel<4>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, cols, vals, r2); break;
+    case 6: hipLaunchKernelGGL(gather_columns_kernel<6>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, cols, vals, r2); break;
+    case 8: hipLaunchKernelGGL(gather_columns_kernel<8>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, cols, vals, r2); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

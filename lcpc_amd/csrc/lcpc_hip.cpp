@@ -100,6 +100,10 @@ struct lcpc_ctx {
   uint64_t tmp_cap = 0;
   uint32_t* d_t = nullptr;         // Brakedown: position-major working copy T[pos][row] of the rows being encoded
   uint64_t t_cap = 0;
+  bool comm_t = false;             // Brakedown commit with >= 16 local rows: the commitment matrix lives in d_t (position-major,
+                                   // element (row, col) at (col * n_rows_local + row)); hash / open read it there, d_comm is only
+                                   // filled on demand (lcpc_get_comm) -- no back-transpose on the commit path
+  bool comm_rows_valid = false;    // d_comm holds the row-major copy of the commitment in d_t
   // commitment (device resident)
   bool committed = false;
   uint64_t n_rows = 0;             // rows of the whole commitment
@@ -263,7 +267,7 @@ int shard_nodes(uint64_t c0, uint64_t c1, uint64_t* first, uint32_t* lg) {
 // canon_out: dst receives canonical values instead of Montgomery form (commit paths of a comm_canon context only)
 int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, uint64_t n_valid, uint32_t* dst,
                        uint64_t n_rows, hipStream_t st, uint64_t n_src_total = ~(uint64_t)0, uint32_t* copy_dst = nullptr,
-                       bool canon_out = false) {
+                       bool canon_out = false, bool keep_t = false) {
   if (n_rows == 0) return 0;
   if (c->prm.encoding == LCPC_ENC_LIGERO) {
     bool first = true;
@@ -303,7 +307,7 @@ int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, ui
       c->tmp_cap = need;
     }
   }
-  if (n_rows >= 16) {
+  if (n_rows >= 16 && (keep_t || !(c->comm_t && c->committed))) {       // (d_t may be holding a live commitment)
     // fast path: position-major working copy T[pos][row] (lane = row: contiguous gathers, wave-uniform matrix)
     const uint64_t need = n_rows * c->n_cols;
     if (need > c->t_cap) {
@@ -342,6 +346,11 @@ int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, ui
       HIPCHK(c, launch_spmm_t(c->NL, a, st));
       c->launches[0]++;
       out_start += c->d_post[ii].n_out;
+    }
+    if (keep_t) {               // commit: the position-major copy IS the commitment (hash_columns / open_column read it)
+      c->comm_t = true;
+      c->comm_rows_valid = false;
+      return 0;
     }
     HIPCHK(c, launch_transpose_from_t(c->NL, c->d_t, c->n_cols, n_rows, dst, c->n_cols, st));
     c->launches[0]++;
@@ -388,8 +397,9 @@ int encode_rows_device(lcpc_ctx* c, const uint32_t* src, uint64_t src_stride, ui
 int merkleize_device(lcpc_ctx* c, hipStream_t st) {
   const uint64_t n_chunks = leaf_chunks(c, c->n_rows);
   LeafArgs la{};
-  la.comm = c->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.n_cols = c->n_cols; la.row_base = 0;
+  la.comm = c->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.col_stride = 1; la.n_cols = c->n_cols; la.row_base = 0;
   la.n_rows_total = c->n_rows; la.chunk_begin = 0; la.n_chunks_local = (uint32_t)n_chunks; la.n_chunks_total = (uint32_t)n_chunks;
+  if (c->comm_t) { la.comm = c->d_t; la.row_stride = 1; la.col_stride = c->n_rows_local; }
   if (n_chunks == 1) {
     la.out = c->d_hashes;
     HIPCHK(c, launch_leaf_chunks(c->NL, la, st));
@@ -430,10 +440,11 @@ int finish_timing(lcpc_ctx* c, hipStream_t st) {
 int commit_resident(lcpc_ctx* c, hipStream_t st, uint8_t* root, const uint32_t* ext_src = nullptr, uint64_t n_ext = 0) {
   c->launches[0] = c->launches[1] = c->launches[2] = 0;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
+  c->comm_t = false;
   int rc = ext_src ? encode_rows_device(c, ext_src, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st, n_ext, c->d_coeffs,
-                                        c->comm_canon)
+                                        c->comm_canon, true)
                    : encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st, ~(uint64_t)0,
-                                        nullptr, c->comm_canon);
+                                        nullptr, c->comm_canon, true);
   if (rc) return rc;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], st));
   if ((rc = merkleize_device(c, st))) return rc;
@@ -800,6 +811,7 @@ int lcpc_commit_from_parts(lcpc_ctx* c, const uint64_t* comm, const uint64_t* co
   int rc = ensure_buffers(c, n_rows);
   if (rc) return rc;
   const size_t eb = elem_bytes(c);
+  c->comm_t = false;
   HIPCHK(c, hipMemcpy(c->d_comm, comm, (size_t)n_rows * c->n_cols * eb, hipMemcpyHostToDevice));
   if (c->comm_canon) HIPCHK(c, launch_to_canon(c->NL, c->d_comm, n_rows * c->n_cols, c->d_comm, nullptr));
   if (coeffs) HIPCHK(c, hipMemcpy(c->d_coeffs, coeffs, (size_t)n_rows * c->n_per_row * eb, hipMemcpyHostToDevice));
@@ -842,6 +854,12 @@ int lcpc_get_comm(lcpc_ctx* c, uint64_t row0, uint64_t n, uint64_t* out) {
   if (row0 < c->row_begin || row0 + n > c->row_begin + c->n_rows_local) return LCPC_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->prm.device));
   const size_t eb = elem_bytes(c);
+  if (c->comm_t && !c->comm_rows_valid) {      // Brakedown: the commitment is position-major; make the row-major view once
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, launch_transpose_from_t(c->NL, c->d_t, c->n_cols, c->n_rows_local, c->d_comm, c->n_cols, nullptr));
+    HIPCHK(c, hipStreamSynchronize(nullptr));
+    c->comm_rows_valid = true;
+  }
   const uint32_t* src = c->d_comm + (size_t)(row0 - c->row_begin) * c->n_cols * c->NL;
   if (!c->comm_canon) {
     HIPCHK(c, hipMemcpy(out, src, (size_t)n * c->n_cols * eb, hipMemcpyDeviceToHost));
@@ -981,7 +999,10 @@ int lcpc_open_columns(lcpc_ctx* c, const uint64_t* cols, uint32_t n, uint64_t* c
   uint32_t* d_paths = reinterpret_cast<uint32_t*>(base + ((cb + 31) & ~(size_t)31) + ((vb + 31) & ~(size_t)31));
   HIPCHK(c, hipMemcpy(d_cols, cols, cb, hipMemcpyHostToDevice));
   if (col_vals) {
-    HIPCHK(c, launch_gather_columns(c->NL, c->d_comm, c->n_rows_local, c->n_cols, d_cols, n, d_vals, c->comm_canon ? c->d_r2 : nullptr, nullptr));
+    if (c->comm_t)
+      HIPCHK(c, launch_gather_columns(c->NL, c->d_t, c->n_rows_local, 1, c->n_rows_local, d_cols, n, d_vals, nullptr, nullptr));
+    else
+      HIPCHK(c, launch_gather_columns(c->NL, c->d_comm, c->n_rows_local, c->n_cols, 1, d_cols, n, d_vals, c->comm_canon ? c->d_r2 : nullptr, nullptr));
     HIPCHK(c, hipMemcpy(col_vals, d_vals, vb, hipMemcpyDeviceToHost));
   }
   if (paths && c->path_len) {
@@ -1375,6 +1396,7 @@ int lcpc_commit_shard_device(lcpc_ctx* c, const uint64_t* coeffs_local, uint64_t
   int rc = ensure_buffers(c, c->n_rows_local ? c->n_rows_local : 1);
   if (rc) return rc;
   c->launches[0] = c->launches[1] = c->launches[2] = 0;
+  c->comm_t = false;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], st));
   if (c->n_rows_local) {
     if (!coeffs_local) return LCPC_ERR_ARG;
@@ -1383,7 +1405,7 @@ int lcpc_commit_shard_device(lcpc_ctx* c, const uint64_t* coeffs_local, uint64_t
                               c->n_rows_local, st, ~(uint64_t)0, c->d_coeffs, c->comm_canon);   // coeffs copy fused into pass 1
     } else {
       HIPCHK(c, hipMemcpyAsync(c->d_coeffs, coeffs_local, (size_t)c->n_rows_local * c->n_per_row * elem_bytes(c), hipMemcpyDeviceToDevice, st));
-      rc = encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st);
+      rc = encode_rows_device(c, c->d_coeffs, c->n_per_row, c->n_per_row, c->d_comm, c->n_rows_local, st, ~(uint64_t)0, nullptr, false, true);
     }
     if (rc) return rc;
   }
@@ -1395,7 +1417,8 @@ int lcpc_commit_shard_device(lcpc_ctx* c, const uint64_t* coeffs_local, uint64_t
     bool all_single = true;
     for (int k = 0; k < n_nodes; k++) all_single = all_single && lg[k] == 0;
     LeafArgs la{};
-    la.comm = c->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.n_cols = c->n_cols; la.row_base = (int64_t)rb;
+    la.comm = c->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.col_stride = 1; la.n_cols = c->n_cols; la.row_base = (int64_t)rb;
+    if (c->comm_t) { la.comm = c->d_t; la.row_stride = 1; la.col_stride = c->n_rows_local; }
     la.n_rows_total = n_rows_total; la.chunk_begin = (uint32_t)cb; la.n_chunks_local = (uint32_t)(ce - cb);
     la.n_chunks_total = (uint32_t)nch;
     if (all_single) {                       // nothing to pre-merge: chunk CVs are the nodes
