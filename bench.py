@@ -195,6 +195,27 @@ def main():
                 "group_ms": {"encode": round(tm.encode_ms, 3), "hash": round(tm.hash_ms, 3), "merkle": round(tm.merkle_ms, 3),
                              "total": round(tm.total_ms, 3)}}
 
+    shard_ms = None
+    if distributed:
+        # where a sharded step spends its time on this rank (one extra, untimed, phase-synchronised step): local encode +
+        # node CVs, the all-gather, leaf finish + Merkle tree; MAX over ranks
+        from lcpc_amd.distributed import exchange_nodes
+        fence()
+        t_a = time.perf_counter()
+        nodes = engine.commit_shard(coeffs, n_rows_total)
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        gathered, slots = exchange_nodes(nodes, n_chunks)
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        engine.commit_finish(gathered, n_rows_total, slots, want_root=False)
+        torch.cuda.synchronize()
+        t_d = time.perf_counter()
+        ph = torch.tensor([t_b - t_a, t_c - t_b, t_d - t_c], dtype=torch.float64, device=dev)
+        dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+        shard_ms = {"local_encode_hash": round(float(ph[0]) * 1e3, 3), "all_gather": round(float(ph[1]) * 1e3, 3),
+                    "finish": round(float(ph[2]) * 1e3, 3), "gathered_MB": round(gathered.numel() / 1e6, 1)}
+
     out = {"metric": "field-elements committed/sec (whole node), Ligero 2^%d coeffs" % args.log_len,
            "value": value, "unit": "field-elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -204,6 +225,8 @@ def main():
                       "sharding": "rows x%d (BLAKE3-chunk aligned), 1 all-gather of chunk CVs" % world if distributed else "none",
                       "input": "device-resident (HBM)"},
            "roofline": roofline}
+    if shard_ms is not None:
+        out["shard_ms"] = shard_ms
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = os.cpu_count() or 1
