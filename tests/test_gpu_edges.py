@@ -173,8 +173,8 @@ def test_rate_variants_2e20(oracle):
 
 
 def test_lazy_limb_ntt_range_stress(oracle):
-    """The Ft255 NTT keeps elements loosely reduced (value < 4p, 29-bit limbs) between stages and relies on bias
-    constants / a quotient-estimate clamp (field_dev.h, namespace l9).  Inputs chosen to push every bound: rows of
+    """The Ft255 NTT keeps elements loosely reduced between stages (signed 29-bit limbs, |value| < 4p) and relies on
+    the range analysis of its multiplier and of a quotient-estimate clamp (field_dev.h, namespace l9).  Inputs chosen to push every bound: rows of
     all p-1, all (p-1)/2, alternating 0 / p-1, and limbs with all 29-bit fields saturated -- at n_cols = 2^12 (one
     pass), 2^13 (two passes) and 2^18 (the headline row: 4+5 radix-4 rounds), rates 1/2 and 38/39 (n_per_row not a
     power of two).  Bit-exact against the oracle."""
