@@ -308,6 +308,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
     const bool last_two = (t + 2 == k);
     // first round of a zero-padded row (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x * w)
     const bool zero_hi = (t == 0) && !last_two && a.n_valid <= (1ull << (k - 1));
+    const bool zero_3q = zero_hi && a.n_valid <= (1ull << (k - 2));
     for (u32 q = tid; q < T / 4; q += 256) {
       const u32 lp = q & lp_mask;
       const u32 j = (q >> lbt) & (i_mask >> 2);
@@ -321,9 +322,17 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
         // multiplies out of block 0 (w0, w1, and w2 for c1) take the converting table
         const u32* tc = canon ? a.roots29c : a.roots29;
         const Tw<NL> w0 = tw_load29(tc, g0 & gm0);
-        const Tw<NL> w1 = tw_load29(tc, g1 & gm0);
         const Tw<NL> w2c = tw_load29(tc, (g0 & gm1) << 1);
         const Tw<NL> w2 = tw_load<NL>(a, (g0 & gm1) << 1);
+        if (zero_3q) {           // rate <= 1/4: x1 is zero too; c0 = x0 stays where it is, three multiplies
+          const L9 x0 = lds9_get<LT>(lds, e0);
+          lds9_put<LT>(lds, e0 + dq, l9::mul(x0, w2c.w));
+          const L9 b2 = l9::mul(x0, w0.w);
+          lds9_put<LT>(lds, e0 + 2 * dq, b2);
+          lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(b2, w2.w));
+          continue;
+        }
+        const Tw<NL> w1 = tw_load29(tc, g1 & gm0);
         const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
         L9 c0 = l9::add(x0, x1);                                                           // [0, 2p)
         l9::normalize(c0);
