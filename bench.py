@@ -190,7 +190,7 @@ def main():
                 "algorithmic_GB_per_launch": round(enc_bytes / ntt_launches / 1e9, 3),
                 "avg_launch_ms": round(ntt_ms, 4),
                 "note": "255-bit modular multiply: integer-VALU work at the board power limit (~1.33 kW, sclk ~2.1 GHz: "
-                        "profiles/r01e_clock_power.txt), not HBM-bound (DESIGN.md section 6)",
+                        "profiles/r01f_clock_power.txt), not HBM-bound (DESIGN.md section 6)",
                 "commit_GBps": round(commit_bytes / (tm.total_ms * 1e-3) / 1e9, 1) if tm.total_ms > 0 else None,
                 "group_ms": {"encode": round(tm.encode_ms, 3), "hash": round(tm.hash_ms, 3), "merkle": round(tm.merkle_ms, 3),
                              "total": round(tm.total_ms, 3)}}

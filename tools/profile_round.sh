@@ -5,7 +5,7 @@
 #   bench_pmc_{fetch,write,sq}.txt + pmc.json     separate --pmc passes (never combined with traces)
 #   clock_power.txt           rocm-smi sclk / socket power sampled while the bench loops
 #   configs.jsonl, c3_kernel_stats.txt, c5_kernel_stats.txt   the other BASELINE.json configs
-# Run on the MI355X box:  gpurun -- 'bash tools/profile_round.sh r01e'
+# Run on the MI355X box:  gpurun -- 'bash tools/profile_round.sh r01f'
 TAG=${1:-latest}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
