@@ -95,6 +95,26 @@ void Transcript::prf(uint8_t* d, size_t n, bool more) { begin_op(SF_I | SF_A | S
 void Transcript::append_message(const uint8_t* label, size_t llen, const uint8_t* msg, size_t mlen) {
   const uint32_t l = (uint32_t)mlen;
   const uint8_t le[4] = {(uint8_t)l, (uint8_t)(l >> 8), (uint8_t)(l >> 16), (uint8_t)(l >> 24)};
+  // prove / verify call this n_per_row times in a row with a 6-byte label and one field element (lib.rs:1045-1047).
+  // When the whole operation -- meta-AD header, label, length, AD header, message -- stays inside the current rate
+  // block, no permutation (and no pos_begin reset) can happen in between, so the bytes are known up front: one XOR run.
+  const size_t total = 2 + llen + 4 + 2 + mlen;
+  if (total <= 96 && (size_t)pos_ + total < (size_t)R) {
+    uint8_t buf[96];
+    size_t o = 0;
+    buf[o++] = pos_begin_; buf[o++] = SF_M | SF_A;             // begin_op(meta-AD)
+    const uint8_t pb1 = (uint8_t)(pos_ + 1);
+    memcpy(buf + o, label, llen); o += llen;
+    memcpy(buf + o, le, 4); o += 4;                            // meta_ad(len, more = true): no header
+    buf[o++] = pb1; buf[o++] = SF_A;                           // begin_op(AD)
+    pos_begin_ = (uint8_t)(pos_ + 2 + llen + 4 + 1);
+    cur_flags_ = SF_A;
+    memcpy(buf + o, msg, mlen); o += mlen;
+    uint8_t* dst = st_.b + pos_;
+    for (size_t i = 0; i < o; i++) dst[i] ^= buf[i];
+    pos_ = (uint8_t)(pos_ + o);
+    return;
+  }
   meta_ad(label, llen, false);
   meta_ad(le, 4, true);
   ad(msg, mlen, false);
