@@ -1252,6 +1252,9 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
   const int L = f.L;
   const uint64_t F = 8 * L;
   Transcript& tr = trw->t;
+  const bool dbg = getenv("LCPC_DEBUG_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tv[6] = {now(), 0, 0, 0, 0, 0};
   Rd r{proof, proof_len};
   const uint64_t n_cols = r.u64_();
   const uint64_t n_per_row = r.u64_();
@@ -1301,24 +1304,32 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
   if (n_deg_pf < n_deg) return LCPC_VERR_MALFORMED;                            // reference indexes p_random_vec[i] (would panic)
   for (uint64_t i = 0; i < n_deg; i++) if (p_random[i].size() != n_per_row * L) return LCPC_VERR_MALFORMED;
   for (auto& cv : cols) if (cv.size() != n_rows * L) return LCPC_VERR_MALFORMED;
-  // step 1: random tensors, transcript; rows to encode = p_random[0..n_deg) then p_eval (lib.rs:868-920)
-  std::vector<std::vector<uint64_t>> rand_tensors(n_deg, std::vector<uint64_t>(n_rows * L));
+  // step 2 first: the 1 + n_deg row encodes (lib.rs:886, 918) depend only on the proof, not on the transcript, so they
+  // run on the GPU (own thread: upload, kernels, download) while this thread does step 1, the serial transcript work
   std::vector<uint64_t> enc((n_deg + 1) * n_cols * L, 0);
+  for (uint64_t i = 0; i < n_deg; i++) memcpy(&enc[i * n_cols * L], p_random[i].data(), n_per_row * F);
+  memcpy(&enc[n_deg * n_cols * L], p_eval.data(), n_per_row * F);
+  int enc_rc = 0;
+  double t_enc = 0;
+  tv[1] = now();
+  std::thread enc_thread([&] { const double t0 = now(); enc_rc = lcpc_encode_rows(c, enc.data(), n_deg + 1); t_enc = now() - t0; });
+  // step 1: random tensors, transcript (lib.rs:868-920)
+  std::vector<std::vector<uint64_t>> rand_tensors(n_deg, std::vector<uint64_t>(n_rows * L));
   for (uint64_t i = 0; i < n_deg; i++) {
     uint8_t key[32];
     tr.challenge_bytes(LBL_DT, 6, key, 32);
     ChaCha20Rng rng(key);
     for (uint64_t k = 0; k < n_rows; k++) rng.field_random(f, &rand_tensors[i][k * L]);
-    memcpy(&enc[i * n_cols * L], p_random[i].data(), n_per_row * F);
     absorb_poly(tr, LBL_PR, f, p_random[i].data(), n_per_row);
   }
   absorb_poly(tr, LBL_PE, f, p_eval.data(), n_per_row);
   uint8_t key[32];
   tr.challenge_bytes(LBL_CO, 6, key, 32);
   ChaCha20Rng rng(key);
-  memcpy(&enc[n_deg * n_cols * L], p_eval.data(), n_per_row * F);
-  int rc = lcpc_encode_rows(c, enc.data(), n_deg + 1);                         // the 1+n_deg row encodes run on the GPU
-  if (rc) return rc == LCPC_ERR_ENCODE ? LCPC_VERR_ENCODE : rc;
+  tv[2] = now();
+  enc_thread.join();
+  tv[3] = now();
+  if (enc_rc) return enc_rc == LCPC_ERR_ENCODE ? LCPC_VERR_ENCODE : enc_rc;
   // step 3: per-column checks (lib.rs:923-944), in parallel over columns like the reference's par_iter;
   // the error reported is that of the first failing column, with the reference's precedence degree > eval > path
   std::vector<uint64_t> cols_to_open(n_columns);
@@ -1348,8 +1359,12 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
       status[i] = !rnd ? LCPC_VERR_COLUMN_DEGREE : (!evl ? LCPC_VERR_COLUMN_EVAL : (!pth ? LCPC_VERR_COLUMN_PATH : 0));
     }
   });
+  tv[4] = now();
   for (uint64_t i = 0; i < n_columns; i++)
     if (status[i]) return status[i];
+  if (dbg)
+    fprintf(stderr, "[lcpc_verify] parse %.2f ms, transcript %.2f (row encodes on the GPU meanwhile: %.2f), wait for encodes %.2f, column checks %.2f\n",
+            tv[1] - tv[0], tv[2] - tv[1], t_enc, tv[3] - tv[2], tv[4] - tv[3]);
   uint64_t acc[MAXL] = {0, 0, 0, 0}, t[MAXL];                                  // lib.rs:947-951
   for (uint64_t k = 0; k < n_per_row; k++) { h_mul(f, t, inner + k * L, &p_eval[k * L]); h_add(f, acc, acc, t); }
   memcpy(eval_out, acc, F);
