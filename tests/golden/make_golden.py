@@ -117,6 +117,21 @@ def main():
         b3.append(dict(len=n, digest=P.blake3(msg).hex()))
     with open(os.path.join(HERE, "blake3_leaf_shapes.json"), "w") as f:
         json.dump(b3, f, indent=1)
+    # shapes chosen by the constructors: new(len) for the BASELINE.json lengths and new_ml(n_vars) (ligero lib.rs:128-135,
+    # brakedown lib.rs:114-123); null where the reference's assert!s reject the multilinear split
+    dims = []
+    for F in (P.FT63, P.FT255):
+        for lg in (10, 16, 20, 24, 26, 28):
+            for rho in ((1, 2), (1, 4)):
+                dims.append(dict(field=F.fid, enc="ligero", rho=list(rho), log_len=lg,
+                                 new=list(P.LigeroEncoding.get_dims_len(F, 1 << lg, rho)),
+                                 new_ml=(lambda d: list(d) if d else None)(P.LigeroEncoding.dims_ml(F, lg, rho))))
+            for code in (1, 3, 6):
+                dims.append(dict(field=F.fid, enc="sdig", code=code, log_len=lg,
+                                 new=list(P.SdigEncoding.dims_only(F, 1 << lg, code)),
+                                 new_ml=list(P.SdigEncoding.dims_only(F, 1 << lg, code, ml=True))))
+    with open(os.path.join(HERE, "constructor_dims.json"), "w") as f:
+        json.dump(dims, f, indent=1)
     print("wrote golden fixtures:", len(cases), "commit cases")
 
 

@@ -85,6 +85,27 @@ def test_new_ml_dims_match_oracle(oracle):
                 assert lcpc_amd.static_get_dims_ml(fid, lcpc_amd.ENC_SDIG, n_vars, code=code) == (a.value, b.value, c.value)
 
 
+def test_constructor_dims_fixture():
+    """the product's dims optimisers against tests/golden/constructor_dims.json (host-only: no device needed)."""
+    import json
+    import os
+    rows = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "constructor_dims.json")))
+    for r in rows:
+        fid, lg = r["field"], r["log_len"]
+        if r["enc"] == "ligero":
+            kw = dict(rho=tuple(r["rho"]))
+            enc = lcpc_amd.ENC_LIGERO
+        else:
+            kw = dict(code=r["code"])
+            enc = lcpc_amd.ENC_SDIG
+        assert list(lcpc_amd.static_get_dims(fid, enc, 1 << lg, **kw)) == r["new"]
+        if r["new_ml"] is None:
+            with pytest.raises(lcpc_amd.LcpcError):
+                lcpc_amd.static_get_dims_ml(fid, enc, lg, **kw)
+        else:
+            assert list(lcpc_amd.static_get_dims_ml(fid, enc, lg, **kw)) == r["new_ml"]
+
+
 def test_transcript_matches_oracle(oracle):
     import random
     rnd = random.Random(4)

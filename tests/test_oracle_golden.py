@@ -84,3 +84,28 @@ def test_blake3_leaf_shapes(oracle):
         n = v["len"]
         msg = b"\0" * 32 + bytes((7 * i + 3) % 256 for i in range(n - 32))
         assert oracle.blake3(msg).hex() == v["digest"]
+
+
+def test_constructor_dims_fixture(oracle):
+    """tests/golden/constructor_dims.json: shapes picked by new(len) and new_ml(n_vars) for the BASELINE.json lengths."""
+    import ctypes as C
+    import json
+    import os
+    O = oracle
+    rows = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "constructor_dims.json")))
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    for r in rows:
+        fid, lg = r["field"], r["log_len"]
+        if r["enc"] == "ligero":
+            rn, rd = r["rho"]
+            assert O.lib().lo_ligero_get_dims(fid, 1 << lg, rn, rd, C.byref(a), C.byref(b), C.byref(c)) == 0
+            assert [a.value, b.value, c.value] == r["new"]
+            rc = O.lib().lo_ligero_get_dims_ml(fid, lg, rn, rd, C.byref(a), C.byref(b), C.byref(c))
+            assert (rc == 0) == (r["new_ml"] is not None)
+            if rc == 0:
+                assert [a.value, b.value, c.value] == r["new_ml"]
+        else:
+            assert O.lib().lo_sdig_get_dims(fid, 1 << lg, r["code"], C.byref(a), C.byref(b), C.byref(c)) == 0
+            assert [a.value, b.value, c.value] == r["new"]
+            assert O.lib().lo_sdig_get_dims_ml(fid, lg, r["code"], C.byref(a), C.byref(b), C.byref(c)) == 0
+            assert [a.value, b.value, c.value] == r["new_ml"]
