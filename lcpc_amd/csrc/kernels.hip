@@ -431,7 +431,10 @@ template <int LT>
 static hipError_t launch_ntt_pass_l9_t(const NttPassArgs& a, hipStream_t st) {
   const u64 tiles = ((u64)1 << (a.log_n - a.s - a.log_tj)) * a.n_rows;
   const size_t lds_bytes = (size_t)Lds9<LT>::WORDS * 4;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};            // the attribute is per device (one process may drive several GPUs)
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_l9_kernel<LT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes);
@@ -446,7 +449,10 @@ template <int NL, int LT>
 static hipError_t launch_ntt_pass_t(const NttPassArgs& a, hipStream_t st) {
   const u64 tiles = ((u64)1 << (a.log_n - a.s - a.log_tj)) * a.n_rows;
   const size_t lds_bytes = ((size_t)NL * 4) << LT;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};            // the attribute is per device (one process may drive several GPUs)
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<NL, LT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
