@@ -409,3 +409,45 @@ def test_new_ml_commit(oracle, kind, fid, n_vars):
     c = LcCommit.commit(coeffs, enc)
     oc = O.Commit.commit(coeffs, oenc, n_threads=4)
     assert (c.hashes() == oc.hashes()).all() and c.get_root() == oc.get_root()
+
+
+@pytest.mark.parametrize("kind,lgl", [("ligero", 12), ("ligero", 15), ("ligero", 19), ("sdig", 12), ("sdig", 16)])
+def test_end_to_end_one_proof_ml(oracle, kind, lgl):
+    """lcpc-ligero-pc/src/tests.rs:264-312 / lcpc-brakedown-pc/src/tests.rs:240-288: Ft63, a multilinear-sized
+    polynomial (2^lgl coefficients, lgl in 12..19 there), encoding from new_ml, more than one row, prove, then
+    verify with an encoding rebuilt from the proof's own dims (new_from_dims(pf.get_n_per_row(), pf.get_n_cols()))."""
+    import ctypes as C
+    import pyref as P
+    O = oracle
+    fid, F = 0, P.FT63
+    n = 1 << lgl
+    coeffs = O.random_elems(fid, n, 300 + lgl)
+    a, b, c_ = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    if kind == "ligero":
+        enc = LigeroEncoding.new_ml(fid, lgl)
+        assert O.lib().lo_ligero_get_dims_ml(fid, lgl, 1, 2, C.byref(a), C.byref(b), C.byref(c_)) == 0
+        oenc = O.Encoding.ligero_from_dims(fid, b.value, c_.value)
+    else:
+        enc = SdigEncoding.new_ml(fid, lgl, 0)
+        assert O.lib().lo_sdig_get_dims_ml(fid, lgl, 3, C.byref(a), C.byref(b), C.byref(c_)) == 0
+        oenc = O.Encoding.sdig_from_dims(fid, b.value, c_.value, 0, 3)
+    c = LcCommit.commit(coeffs, enc)
+    root = c.get_root()
+    assert c.n_rows != 1
+    x = random.Random(lgl).randrange(F.p)
+    inner = powers(O, fid, x, c.n_per_row)
+    outer = powers(O, fid, x, c.n_rows, c.n_per_row)
+    nco = enc.get_n_col_opens()
+    pf = c.prove(outer, enc, mk_transcript(Transcript, root, nco))
+    if kind == "ligero":
+        enc2 = LigeroEncoding.new_from_dims(fid, pf.get_n_per_row(), pf.get_n_cols())
+    else:
+        enc2 = SdigEncoding.new_from_dims(fid, pf.get_n_per_row(), pf.get_n_cols(), 0)
+    ev = pf.verify(root, outer, inner, enc2, mk_transcript(Transcript, root, nco))
+    acc = 0
+    for v in reversed(O.to_canon_ints(fid, coeffs)):
+        acc = (acc * x + v) % F.p
+    assert O.to_canon_ints(fid, ev[None, :])[0] == acc
+    # the oracle's verifier accepts the same bytes and returns the same evaluation
+    rc, oev = O.verify(oenc, root, outer, inner, pf.to_bytes(), mk_transcript(O.Transcript, root, nco))
+    assert rc == 0 and (oev == ev).all()
