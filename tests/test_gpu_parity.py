@@ -451,3 +451,23 @@ def test_end_to_end_one_proof_ml(oracle, kind, lgl):
     # the oracle's verifier accepts the same bytes and returns the same evaluation
     rc, oev = O.verify(oenc, root, outer, inner, pf.to_bytes(), mk_transcript(O.Transcript, root, nco))
     assert rc == 0 and (oev == ev).all()
+
+
+@pytest.mark.parametrize("n_rows", [1, 3, 20])
+def test_matgen_encode_full_length_input(oracle, n_rows):
+    """lcpc-brakedown-pc/src/tests.rs:78-93 (test_matgen_encode): generate(n, seed 0) for n in 256..4352 and encode a
+    buffer that is random over its WHOLE codeword length -- everything past the message is overwritten by the code,
+    so the garbage must not leak into the result.  1 and 3 rows take the row-major kernels, 20 the position-major ones."""
+    O = oracle
+    rnd = random.Random(9 + n_rows)
+    for _ in range(3):
+        n = 256 + rnd.randrange(4096)
+        oenc = O.Encoding.sdig_from_dims(0, n, 0, 0, 3)
+        _, _, n_cols = oenc.get_dims(n)
+        enc = SdigEncoding.new_from_dims(0, n, n_cols, 0, 3)
+        xi = O.random_elems(0, n_rows * n_cols, n).reshape(n_rows, n_cols, 1)
+        got = enc.encode(xi.copy()).reshape(n_rows, n_cols, 1)
+        for r in range(n_rows):
+            exp = oenc.encode(xi[r].copy())
+            assert (got[r] == exp).all(), (n, r)
+            assert (got[r, :n] == xi[r, :n]).all()                  # systematic part untouched
