@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <atomic>
 #include <string>
@@ -1024,8 +1025,6 @@ void lcpc_transcript_challenge_bytes(lcpc_transcript* t, const uint8_t* label, s
 void lcpc_transcript_free(lcpc_transcript* t) { delete t; }
 
 // ---- prove (lib.rs:1004-1093) ----------------------------------------------------------------------------
-static void put_u64(std::vector<uint8_t>& w, uint64_t v) { const uint8_t* p = reinterpret_cast<const uint8_t*>(&v); w.insert(w.end(), p, p + 8); }
-static void put_bytes(std::vector<uint8_t>& w, const void* d, size_t n) { const uint8_t* p = static_cast<const uint8_t*>(d); w.insert(w.end(), p, p + n); }
 static void absorb_poly(Transcript& tr, const uint8_t* label, const FieldDesc& f, const uint64_t* poly, uint64_t n) {
   // to_repr (Montgomery -> canonical little-endian, lib.rs:47-57) is independent per element: done in parallel;
   // only the STROBE absorb itself is serial (lib.rs:1045-1047)
@@ -1169,30 +1168,35 @@ static int prove_impl(lcpc_ctx* c, const uint64_t* outer, uint64_t n_outer, lcpc
   std::vector<uint64_t> cols(n_open);
   for (auto& x : cols) x = rng.uniform(c->n_cols);
   if (cols_opened) memcpy(cols_opened, cols.data(), n_open * 8);
-  std::vector<uint64_t> vals((size_t)n_open * nr * L);
-  std::vector<uint8_t> paths((size_t)n_open * c->path_len * 32 + 32);
+  // (uninitialised buffers: a Brakedown proof opens 6593 columns, tens of MB that are overwritten anyway)
+  std::unique_ptr<uint64_t[]> vals(new uint64_t[(size_t)n_open * nr * L + 1]);
+  std::unique_ptr<uint8_t[]> paths(new uint8_t[(size_t)n_open * c->path_len * 32 + 32]);
   tp[3] = now();
-  int rc = xchg ? open_sharded(c, *xchg, cols.data(), (uint32_t)n_open, vals.data(), paths.data())
-                : lcpc_open_columns(c, cols.data(), (uint32_t)n_open, vals.data(), paths.data());   // lib.rs:1081-1084
+  int rc = xchg ? open_sharded(c, *xchg, cols.data(), (uint32_t)n_open, vals.get(), paths.get())
+                : lcpc_open_columns(c, cols.data(), (uint32_t)n_open, vals.get(), paths.get());   // lib.rs:1081-1084
   if (rc) return rc;
   tp[4] = now();
-  // bincode 1.3 of WrappedLcEvalProof (lib.rs:550-560): n_cols, p_eval, p_random_vec, columns
-  std::vector<uint8_t> w;
-  w.reserve(32 + (1 + n_deg) * (np * L * 8 + 8) + n_open * (nr * L * 8 + 16 + c->path_len * 40));
-  put_u64(w, c->n_cols);
-  put_u64(w, np); put_bytes(w, p_eval.data(), np * L * 8);
-  put_u64(w, n_deg);
-  for (auto& pr : p_random) { put_u64(w, np); put_bytes(w, pr.data(), np * L * 8); }
-  put_u64(w, n_open);
-  for (uint64_t k = 0; k < n_open; k++) {
-    put_u64(w, nr); put_bytes(w, &vals[k * nr * L], nr * L * 8);
-    put_u64(w, c->path_len);
-    for (uint32_t l = 0; l < c->path_len; l++) { put_u64(w, 32); put_bytes(w, &paths[((size_t)k * c->path_len + l) * 32], 32); }
-  }
-  uint8_t* out = static_cast<uint8_t*>(malloc(w.size() ? w.size() : 1));
+  // bincode 1.3 of WrappedLcEvalProof (lib.rs:550-560): n_cols, p_eval, p_random_vec, columns -- the size is known
+  // up front, so the proof is written once, straight into the buffer the caller receives
+  const size_t pbytes = np * L * 8;
+  const size_t total = 8 + (8 + pbytes) + 8 + n_deg * (8 + pbytes) + 8 + n_open * (8 + nr * L * 8 + 8 + (size_t)c->path_len * 40);
+  uint8_t* out = static_cast<uint8_t*>(malloc(total ? total : 1));
   if (!out) return LCPC_ERR_NOMEM;
-  memcpy(out, w.data(), w.size());
-  *proof = out; *proof_len = w.size();
+  uint8_t* w = out;
+  auto w64 = [&](uint64_t v) { memcpy(w, &v, 8); w += 8; };
+  auto wbytes = [&](const void* d, size_t n) { memcpy(w, d, n); w += n; };
+  w64(c->n_cols);
+  w64(np); wbytes(p_eval.data(), pbytes);
+  w64(n_deg);
+  for (auto& pr : p_random) { w64(np); wbytes(pr.data(), pbytes); }
+  w64(n_open);
+  for (uint64_t k = 0; k < n_open; k++) {
+    w64(nr); wbytes(&vals[k * nr * L], nr * L * 8);
+    w64(c->path_len);
+    for (uint32_t l = 0; l < c->path_len; l++) { w64(32); wbytes(&paths[((size_t)k * c->path_len + l) * 32], 32); }
+  }
+  if ((size_t)(w - out) != total) { free(out); return LCPC_ERR_STATE; }
+  *proof = out; *proof_len = total;
   if (dbg)
     fprintf(stderr, "[lcpc_prove] collapse %.2f ms, absorb p_random %.2f, absorb p_eval %.2f, challenges+alloc %.2f, open %.2f, bincode %.2f, total %.2f\n",
             t_collapse, t_absorb, tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], now() - tp[4], now() - tp[0]);
@@ -1255,42 +1259,50 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
   const bool dbg = getenv("LCPC_DEBUG_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tv[6] = {now(), 0, 0, 0, 0, 0};
+  // every field of the wire layout sits at a multiple of 8 bytes, so the vectors are read in place (a proof handed over
+  // at an odd address is copied once)
+  std::vector<uint64_t> realigned;
+  if (reinterpret_cast<uintptr_t>(proof) % 8 != 0) {
+    realigned.resize((proof_len + 7) / 8);
+    memcpy(realigned.data(), proof, proof_len);
+    proof = reinterpret_cast<const uint8_t*>(realigned.data());
+  }
   Rd r{proof, proof_len};
   const uint64_t n_cols = r.u64_();
   const uint64_t n_per_row = r.u64_();
   if (r.bad || n_per_row > proof_len / F) return LCPC_VERR_MALFORMED;
-  std::vector<uint64_t> p_eval(n_per_row * L);
-  { const uint8_t* q = r.take(n_per_row * F); if (!q) return LCPC_VERR_MALFORMED; memcpy(p_eval.data(), q, n_per_row * F); }
+  struct View { const uint64_t* p = nullptr; uint64_t n = 0; const uint64_t* data() const { return p; } uint64_t size() const { return n; } };
+  View p_eval;
+  { const uint8_t* q = r.take(n_per_row * F); if (!q) return LCPC_VERR_MALFORMED; p_eval = View{reinterpret_cast<const uint64_t*>(q), n_per_row * L}; }
   const uint64_t n_deg_pf = r.u64_();
   if (r.bad || n_deg_pf > 4096) return LCPC_VERR_MALFORMED;
-  std::vector<std::vector<uint64_t>> p_random(n_deg_pf);
+  std::vector<View> p_random(n_deg_pf);
   for (auto& v : p_random) {
     const uint64_t l = r.u64_();
     if (r.bad || l > proof_len / F) return LCPC_VERR_MALFORMED;
     const uint8_t* q = r.take(l * F);
     if (!q) return LCPC_VERR_MALFORMED;
-    v.resize(l * L);
-    memcpy(v.data(), q, l * F);
+    v = View{reinterpret_cast<const uint64_t*>(q), l * L};
   }
   const uint64_t n_columns = r.u64_();
   if (r.bad || n_columns > proof_len / 8) return LCPC_VERR_MALFORMED;
-  std::vector<std::vector<uint64_t>> cols(n_columns);
-  std::vector<std::vector<uint8_t>> paths(n_columns);
+  std::vector<View> cols(n_columns);
+  struct PathView { const uint8_t* p = nullptr; uint64_t n = 0; };      // n entries of (u64 32, 32 bytes): digest k at p + 40 k + 8
+  std::vector<PathView> paths(n_columns);
   for (uint64_t i = 0; i < n_columns; i++) {
     const uint64_t l = r.u64_();
     if (r.bad || l > proof_len / F) return LCPC_VERR_MALFORMED;
     const uint8_t* q = r.take(l * F);
     if (!q) return LCPC_VERR_MALFORMED;
-    cols[i].resize(l * L);
-    memcpy(cols[i].data(), q, l * F);
+    cols[i] = View{reinterpret_cast<const uint64_t*>(q), l * L};
     const uint64_t pl = r.u64_();
     if (r.bad || pl > proof_len / 40) return LCPC_VERR_MALFORMED;
-    paths[i].resize(pl * 32);
+    paths[i].p = proof + r.pos;
+    paths[i].n = pl;
     for (uint64_t k = 0; k < pl; k++) {
       const uint64_t dl = r.u64_();
       const uint8_t* d = r.take(32);
       if (r.bad || dl != 32 || !d) return LCPC_VERR_MALFORMED;     // Output<D> is 32 bytes
-      memcpy(&paths[i][k * 32], d, 32);
     }
   }
   if (r.pos != proof_len) return LCPC_VERR_MALFORMED;
@@ -1342,15 +1354,15 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
       for (uint64_t d = 0; d <= n_deg; d++) {
         const uint64_t* tensor = d < n_deg ? rand_tensors[d].data() : outer;
         uint64_t acc[MAXL] = {0, 0, 0, 0}, t[MAXL];
-        for (uint64_t k = 0; k < n_rows; k++) { h_mul(f, t, tensor + k * L, &cols[i][k * L]); h_add(f, acc, acc, t); }
+        for (uint64_t k = 0; k < n_rows; k++) { h_mul(f, t, tensor + k * L, cols[i].data() + k * L); h_add(f, acc, acc, t); }
         const bool ok = h_eq(f, acc, &enc[(d * n_cols + cn) * L]);           // verify_column_value lib.rs:985-1000
         if (d < n_deg) rnd = rnd && ok; else evl = ok;
       }
       uint8_t h[32], blk[64];                                                  // verify_column_path lib.rs:955-982
       hash_column_host(f, cols[i].data(), n_rows, h);
       uint64_t cc = cn;
-      for (uint64_t k = 0; k < paths[i].size() / 32; k++) {
-        const uint8_t* pk = &paths[i][k * 32];
+      for (uint64_t k = 0; k < paths[i].n; k++) {
+        const uint8_t* pk = paths[i].p + 40 * k + 8;
         if (cc % 2 == 0) { memcpy(blk, h, 32); memcpy(blk + 32, pk, 32); } else { memcpy(blk, pk, 32); memcpy(blk + 32, h, 32); }
         blake3_host(blk, 64, h);
         cc >>= 1;
@@ -1366,7 +1378,7 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
     fprintf(stderr, "[lcpc_verify] parse %.2f ms, transcript %.2f (row encodes on the GPU meanwhile: %.2f), wait for encodes %.2f, column checks %.2f\n",
             tv[1] - tv[0], tv[2] - tv[1], t_enc, tv[3] - tv[2], tv[4] - tv[3]);
   uint64_t acc[MAXL] = {0, 0, 0, 0}, t[MAXL];                                  // lib.rs:947-951
-  for (uint64_t k = 0; k < n_per_row; k++) { h_mul(f, t, inner + k * L, &p_eval[k * L]); h_add(f, acc, acc, t); }
+  for (uint64_t k = 0; k < n_per_row; k++) { h_mul(f, t, inner + k * L, p_eval.data() + k * L); h_add(f, acc, acc, t); }
   memcpy(eval_out, acc, F);
   return 0;
 }

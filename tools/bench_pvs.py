@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""tools/bench_pvs.py [max_lgl] -- the reference's own benchmark loops on the MI355X path, one JSON line per size:
+rough_bench (lcpc-ligero-pc/src/tests.rs:80-97, lcpc-brakedown-pc/src/tests.rs:171-190: mean commit time) and
+prove_verify_size_bench (ligero tests.rs:102-170, brakedown tests.rs:98-167: mean prove time incl. bincode, mean verify
+time, bincode proof bytes) for Ft255, len = 2^lgl, lgl = 13, 15, ... as there; encoder construction outside the timed
+region as there.  The published 64-thread CPU numbers for the same loops are in BASELINE.md."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")]
+import numpy as np
+import torch
+
+import bench_configs as B
+import oracle_lib as O
+from common import mk_transcript, powers
+from lcpc_amd import LcCommit, LigeroEncoding, SdigEncoding, Transcript
+
+N_ITERS = 10
+
+
+def run(kind, lgl):
+    n = 1 << lgl
+    enc = LigeroEncoding.new(3, n) if kind == "ligero" else SdigEncoding.new(3, n, 0)
+    coeffs = B.rand_coeffs(n, 4, lgl)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        c = LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=True)
+    t0 = time.perf_counter()
+    for _ in range(N_ITERS):
+        c = LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=True)        # root on the host every time
+    t_commit = (time.perf_counter() - t0) / N_ITERS
+    root = c.get_root()
+    x = 0x1234567 + lgl
+    inner = powers(O, 3, x, c.n_per_row)
+    outer = powers(O, 3, x, c.n_rows, c.n_per_row)
+    nco = enc.get_n_col_opens()
+    pf = c.prove(outer, enc, mk_transcript(Transcript, root, nco))
+    t0 = time.perf_counter()
+    for _ in range(N_ITERS):
+        pf = c.prove(outer, enc, mk_transcript(Transcript, root, nco))
+    t_prove = (time.perf_counter() - t0) / N_ITERS
+    pf.verify(root, outer, inner, enc, mk_transcript(Transcript, root, nco))
+    t0 = time.perf_counter()
+    for _ in range(N_ITERS):
+        pf.verify(root, outer, inner, enc, mk_transcript(Transcript, root, nco))
+    t_verify = (time.perf_counter() - t0) / N_ITERS
+    print(json.dumps({"enc": kind, "lgl": lgl, "dims": [c.n_rows, c.n_per_row, c.n_cols], "commit_ms": round(t_commit * 1e3, 3),
+                      "prove_ms": round(t_prove * 1e3, 3), "verify_ms": round(t_verify * 1e3, 3), "proof_bytes": len(pf.to_bytes())}),
+          flush=True)
+    del coeffs, c, enc
+    torch.cuda.empty_cache()
+
+
+def main():
+    max_lgl = int(sys.argv[1]) if len(sys.argv) > 1 else 27
+    for kind in ("ligero", "sdig"):
+        for lgl in range(13, max_lgl + 1, 2):
+            run(kind, lgl)
+
+
+if __name__ == "__main__":
+    main()
