@@ -48,9 +48,9 @@ void to_r29(const FieldDesc& f, const uint64_t* in4, uint32_t* out12) {
 }
 
 // small fork-join helper for the host-side glue (the reference uses rayon at the same places: lib.rs:923-944)
-template <typename Fn> void parallel_for(uint64_t n, uint64_t grain, Fn fn) {
+template <typename Fn> void parallel_for(uint64_t n, uint64_t grain, Fn fn, unsigned max_threads = 16) {
   unsigned nt = std::thread::hardware_concurrency();
-  if (nt > 16) nt = 16;
+  if (nt > max_threads) nt = max_threads;
   if (nt <= 1 || n < 2 * grain) { fn((uint64_t)0, n); return; }
   const uint64_t nchunks = (n + grain - 1) / grain;
   if (nt > nchunks) nt = (unsigned)nchunks;
@@ -1370,7 +1370,7 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
       const bool pth = memcmp(h, root, 32) == 0;
       status[i] = !rnd ? LCPC_VERR_COLUMN_DEGREE : (!evl ? LCPC_VERR_COLUMN_EVAL : (!pth ? LCPC_VERR_COLUMN_PATH : 0));
     }
-  });
+  }, n_columns * n_rows > ((uint64_t)1 << 19) ? 64u : 16u);       // Brakedown opens 6593 columns: ~0.1 s of work single-threaded
   tv[4] = now();
   for (uint64_t i = 0; i < n_columns; i++)
     if (status[i]) return status[i];
