@@ -74,6 +74,21 @@ KERNEL(k_lshl_add_u64, u64 a0=x;u64 a1=y;u64 a2=x+1;u64 a3=y+1;u64 a4=x+2;u64 a5
      : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(xx)),
   (u32)(a0^a1^a2^a3^a4^a5^a6^a7))
 
+// SDWA forms and byte permute (candidates for BLAKE3's rotations by 16 / 8), the signed mad and the 64-bit arithmetic shift
+#define SDWA8(OPSTR, MODS) asm volatile(OPSTR " %0, %0, %8 " MODS "\n" OPSTR " %1, %1, %8 " MODS "\n" OPSTR " %2, %2, %8 " MODS "\n" OPSTR " %3, %3, %8 " MODS "\n" OPSTR " %4, %4, %8 " MODS "\n" OPSTR " %5, %5, %8 " MODS "\n" OPSTR " %6, %6, %8 " MODS "\n" OPSTR " %7, %7, %8 " MODS "\n" \
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x),"v"(y))
+KERNEL(k_xor_sdwa, DECL8, SDWA8("v_xor_b32_sdwa", "dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_perm_b32, DECL8, OP8_3("v_perm_b32"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_mad_i64_i32, u64 a0=x;u64 a1=y;u64 a2=x+1;u64 a3=y+1;u64 a4=x+2;u64 a5=y+2;u64 a6=x+3;u64 a7=y+3,
+  asm volatile("v_mad_i64_i32 %0, vcc, %8, %9, %0\n v_mad_i64_i32 %1, vcc, %8, %9, %1\n v_mad_i64_i32 %2, vcc, %8, %9, %2\n v_mad_i64_i32 %3, vcc, %8, %9, %3\n"
+               "v_mad_i64_i32 %4, vcc, %8, %9, %4\n v_mad_i64_i32 %5, vcc, %8, %9, %5\n v_mad_i64_i32 %6, vcc, %8, %9, %6\n v_mad_i64_i32 %7, vcc, %8, %9, %7\n"
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x),"v"(y) : "vcc"),
+  (u32)(a0^a1^a2^a3^a4^a5^a6^a7))
+KERNEL(k_ashrrev_i64, u64 a0=x;u64 a1=y;u64 a2=x+1;u64 a3=y+1;u64 a4=x+2;u64 a5=y+2;u64 a6=x+3;u64 a7=y+3,
+  asm volatile("v_ashrrev_i64 %0, 1, %0\n v_ashrrev_i64 %1, 1, %1\n v_ashrrev_i64 %2, 1, %2\n v_ashrrev_i64 %3, 1, %3\n v_ashrrev_i64 %4, 1, %4\n v_ashrrev_i64 %5, 1, %5\n v_ashrrev_i64 %6, 1, %6\n v_ashrrev_i64 %7, 1, %7\n"
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7)),
+  (u32)(a0^a1^a2^a3^a4^a5^a6^a7))
+
 template <typename K> static double run(K kern, const char* name, int ops_per_body, int waves_per_simd, u32* d){
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   int blocks = 256 * waves_per_simd;   // 256 CUs x (waves_per_simd) blocks of 256 threads = 4 waves => waves/SIMD
@@ -97,6 +112,7 @@ int main(){
     run(k_and_b32,"v_and_b32",8,w,d); run(k_lshrrev_b32,"v_lshrrev_b32",8,w,d); run(k_bfe_u32,"v_bfe_u32",8,w,d); run(k_lshl_or_b32,"v_lshl_or_b32",8,w,d);
     run(k_cndmask,"v_cndmask_b32 (vcc)",8,w,d); run(k_cndmask_cmp,"v_cmp + 8 cndmask(vcc)",9,w,d); run(k_cndmask_e64,"v_cndmask_b32_e64 sgpr",8,w,d); run(k_sel_arith,"xor/and/xor select",8,w,d); run(k_addc_chain,"v_addc_co_u32 chain",8,w,d); run(k_lshrrev_b64,"v_lshrrev_b64",8,w,d); run(k_mad_snop,"mad_u64 + s_nop 0",4,w,d);
     run(k_lshl_add_u64,"v_lshl_add_u64",8,w,d); run(k_fma_f32,"v_fma_f32",8,w,d); run(k_fma_f64,"v_fma_f64",8,w,d);
+    run(k_xor_sdwa,"v_xor_b32_sdwa (word)",8,w,d); run(k_perm_b32,"v_perm_b32",8,w,d); run(k_mad_i64_i32,"v_mad_i64_i32",8,w,d); run(k_ashrrev_i64,"v_ashrrev_i64",8,w,d);
   }
   return 0;
 }
