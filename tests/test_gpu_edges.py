@@ -235,3 +235,43 @@ def test_canonical_comm_commit_stress(oracle, log_n, n_per_row, n_rows):
     pf = c.prove(t, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
     opf, _ = oc.prove(t, oenc, mk_transcript(O.Transcript, root, enc.get_n_col_opens()))
     assert pf.to_bytes() == opf
+
+
+def test_concurrent_contexts_and_streams(oracle):
+    """include/lcpc_hip.h: contexts are independent and may be used from different host threads at the same time; a
+    device-resident commit may be given any HIP stream.  Four threads, each with its own context (two Ligero shapes,
+    one Brakedown, one Ft63) and its own non-default stream, commit 5 different inputs each while the others run; every
+    root must equal the oracle's."""
+    import threading
+    import torch
+    O = oracle
+    specs = [("ligero", 3, 1 << 16, 11), ("ligero", 3, 50000, 12), ("sdig", 3, 40000, 13), ("ligero", 0, 1 << 17, 14)]
+    jobs = []
+    for kind, fid, n, seed in specs:
+        if kind == "ligero":
+            enc, oenc = LigeroEncoding.new(fid, n), O.Encoding.ligero(fid, n)
+        else:
+            enc, oenc = SdigEncoding.new(fid, n, 7), O.Encoding.sdig(fid, n, 7)
+        data = [O.random_elems(fid, n, seed * 10 + i) for i in range(5)]
+        want = [O.Commit.commit(d, oenc, n_threads=2).get_root() for d in data]
+        jobs.append((enc, data, want))
+    errs = []
+
+    def work(enc, data, want):
+        try:
+            st = torch.cuda.Stream()
+            for d, w in zip(data, want):
+                dev = torch.from_numpy(d.view(np.int64)).cuda()
+                st.wait_stream(torch.cuda.current_stream())
+                c = LcCommit.commit_device(dev.data_ptr(), d.shape[0], enc, st.cuda_stream, sync=True)
+                if c.get_root() != w:
+                    errs.append("root mismatch")
+        except Exception as e:
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errs, errs
