@@ -49,6 +49,30 @@ __global__ void __launch_bounds__(256) k_mix(u32* out, u32 seed) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)(a0 ^ a1) ^ b0 ^ b1;
 }
 
+// the same mad loop with one multiplicand in an SGPR (what a wave-uniform twiddle or the modulus limbs look like) and with
+// 29-bit multiplicands (the limb size the NTT uses): does the operand source / width change the energy per mad?
+__global__ void __launch_bounds__(256) k_mad_sgpr(u32* out, u32 seed) {
+  u32 x = threadIdx.x * 2654435761u + seed;
+  const u32 y = __builtin_amdgcn_readfirstlane(seed * 2654435761u + 12345u);
+  u64 a0 = x, a1 = x + 7, a2 = x + 1, a3 = x + 9;
+  for (int it = 0; it < ITERS; ++it)
+    asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3\n"
+                 "v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x), "s"(y) : "vcc");
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)(a0 ^ a1 ^ a2 ^ a3);
+}
+__global__ void __launch_bounds__(256) k_mad29(u32* out, u32 seed) {
+  u32 x = (threadIdx.x * 2654435761u + seed) & 0x1fffffffu, y = (x ^ 0x9e3779b9u) & 0x1fffffffu;
+  u64 a0 = x, a1 = y, a2 = x + 1, a3 = y + 1;
+  for (int it = 0; it < ITERS; ++it) {
+    asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3\n"
+                 "v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x), "v"(y) : "vcc");
+    if ((it & 3) == 3) { a0 >>= 29; a1 >>= 29; a2 >>= 29; a3 >>= 29; }      // keep the accumulators in the NTT's range
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)(a0 ^ a1 ^ a2 ^ a3);
+}
+
 // LDS round trips like the NTT's: one ds_write_b128 + one ds_read_b128 per iteration (32 B per lane), conflict-free
 __global__ void __launch_bounds__(256) k_lds(u32* out, u32 seed) {
   __shared__ uint4 buf[256 * 8];
@@ -76,6 +100,8 @@ int main(int argc, char** argv) {
     if (!strcmp(which, "mad")) { hipLaunchKernelGGL(k_mad, dim3(blocks), dim3(256), 0, 0, d, s); ops_per_thread = 8.0 * ITERS; }
     else if (!strcmp(which, "add")) { hipLaunchKernelGGL(k_add, dim3(blocks), dim3(256), 0, 0, d, s); ops_per_thread = 8.0 * ITERS; }
     else if (!strcmp(which, "alignbit")) { hipLaunchKernelGGL(k_alignbit, dim3(blocks), dim3(256), 0, 0, d, s); ops_per_thread = 8.0 * ITERS; }
+    else if (!strcmp(which, "mad_sgpr")) { hipLaunchKernelGGL(k_mad_sgpr, dim3(blocks), dim3(256), 0, 0, d, s); ops_per_thread = 8.0 * ITERS; }
+    else if (!strcmp(which, "mad29")) { hipLaunchKernelGGL(k_mad29, dim3(blocks), dim3(256), 0, 0, d, s); ops_per_thread = 8.0 * ITERS; }
     else if (!strcmp(which, "lds")) { hipLaunchKernelGGL(k_lds, dim3(blocks), dim3(256), 0, 0, d, s); ops_per_thread = 32.0 * ITERS; }   // bytes
     else { hipLaunchKernelGGL(k_mix, dim3(blocks), dim3(256), 0, 0, d, s); ops_per_thread = 9.0 * ITERS; }
   };

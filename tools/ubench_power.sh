@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/ubench_power.sh -- run each instruction mix of ubench_power for a few seconds and sample clock / power meanwhile
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for k in mad mix alignbit add lds; do
+for k in mad mad_sgpr mad29 mix alignbit add lds; do
   $R/tools/ubench_power $k 4 > /tmp/up_$k.txt &
   BP=$!
   sleep 1.5
