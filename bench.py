@@ -71,6 +71,9 @@ def main():
     import torch
     import torch.distributed as dist
     import lcpc_amd
+    from lcpc_amd import _lib as _lcpc_lib
+    if not os.path.exists(_lcpc_lib.LIB_PATH) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        _lcpc_lib.build()                       # a checkout without the prebuilt HIP library: build it (there is no other path)
     from lcpc_amd import LcCommit, LigeroEncoding
     from lcpc_amd.distributed import HipShardEngine, sharded_commit
 
