@@ -34,6 +34,25 @@ def device_random_coeffs(torch, n, L, seed, device):
     return t
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota (the GPU boxes show all
+    256 hardware threads but grant 16 CPUs of time; oversubscribing 256 OpenMP threads into that quota is slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]              # cgroup v2
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(log_len_sample, n_per_row, n_cols, threads):
     """the oracle (C port of the reference algorithm, OpenMP over rows / 32-column blocks) timed on this box's
     host cores on a bounded sample: same field, same row shape, fewer rows."""
@@ -237,10 +256,12 @@ def main():
         out["shard_ms"] = shard_ms
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = os.cpu_count() or 1
+        threads = usable_cores()
         v, secs, _ = cpu_baseline(args.cpu_sample_log_len, n_per_row, n_cols, threads)
         out["cpu_baseline"] = {"value": v, "unit": "field-elements/s", "cores": threads, "kind": "port",
-                               "sample": "oracle C port (OpenMP), Ligero Ft255 commit of 2^%d coeffs with the headline row "
+                               "host_hw_threads": os.cpu_count(),
+                               "sample": "oracle C port (OpenMP, one thread per usable core: affinity mask capped by the cgroup CPU "
+                                         "quota), Ligero Ft255 commit of 2^%d coeffs with the headline row "
                                          "shape (%d x %d -> %d), %.1f s wall" % (args.cpu_sample_log_len,
                                                                                  (1 << args.cpu_sample_log_len) // n_per_row, n_per_row, n_cols, secs)}
     if rank == 0:

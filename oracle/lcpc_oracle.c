@@ -27,6 +27,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -972,13 +973,28 @@ void lo_merkleize_ser(lo_commit *c) { /* lib.rs:1127-1158 */
     ins = outs; outs += width / 2; width /= 2;
   }
 }
+/* zeroed buffer; large ones on 2 MiB-aligned, huge-page-advised memory: with 4 KiB pages a 256-thread first touch of the
+ * multi-GB comm matrix spends seconds in the kernel's page-fault path, which is not the algorithm being timed */
+static void *big_calloc(size_t bytes) {
+  if (bytes < ((size_t)8 << 20)) return calloc(bytes ? bytes : 1, 1);
+  void *p = NULL;
+  const size_t rounded = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+  if (posix_memalign(&p, (size_t)2 << 20, rounded)) return NULL;
+#ifdef MADV_HUGEPAGE
+  madvise(p, rounded, MADV_HUGEPAGE);
+#endif
+  const size_t n_chunks = rounded >> 21;
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n_chunks; i++) memset((char *)p + (i << 21), 0, (size_t)1 << 21);
+  return p;
+}
 static lo_commit *commit_alloc(const lo_enc *e, u64 n_rows) {
   lo_commit *c = calloc(1, sizeof *c);
   c->f = e->f; c->n_rows = n_rows; c->n_cols = e->n_cols; c->n_per_row = e->n_per_row;
   c->n_hashes = 2 * np2(e->n_cols) - 1;
-  c->coeffs = calloc(n_rows * e->n_per_row * e->f->L, 8);
-  c->comm = calloc(n_rows * e->n_cols * e->f->L, 8);
-  c->hashes = calloc(c->n_hashes, 32);
+  c->coeffs = big_calloc(n_rows * e->n_per_row * e->f->L * 8);
+  c->comm = big_calloc(n_rows * e->n_cols * e->f->L * 8);
+  c->hashes = big_calloc(c->n_hashes * 32);
   return c;
 }
 int lo_commit_new(const lo_enc *e, const u64 *coeffs_in, u64 n, int nthreads, lo_commit **out) { /* lib.rs:622-671 */
