@@ -12,6 +12,7 @@
 #include <chrono>
 #include <memory>
 #include <mutex>
+#include <algorithm>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -48,8 +49,30 @@ void to_r29(const FieldDesc& f, const uint64_t* in4, uint32_t* out12) {
 }
 
 // small fork-join helper for the host-side glue (the reference uses rayon at the same places: lib.rs:923-944)
+// host cores this process may really use: hardware threads capped by the cgroup CPU quota (a container can show 256
+// hardware threads and be granted 16 CPUs of time; more threads than that only get throttled)
+unsigned usable_cores() {
+  static const unsigned cached = [] {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    long long q = -1, per = 100000;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                         // cgroup v2: "<quota|max> <period>"
+      char qs[32] = {0};
+      if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0) q = atoll(qs);
+      fclose(f);
+    } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {      // cgroup v1
+      if (fscanf(f1, "%lld", &q) != 1) q = -1;
+      fclose(f1);
+      if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 100000; fclose(f2); }
+    }
+    if (q > 0 && per > 0) { const unsigned lim = (unsigned)std::max<long long>(1, q / per); if (lim < n) n = lim; }
+    return n;
+  }();
+  return cached;
+}
+
 template <typename Fn> void parallel_for(uint64_t n, uint64_t grain, Fn fn, unsigned max_threads = 16) {
-  unsigned nt = std::thread::hardware_concurrency();
+  unsigned nt = usable_cores();
   if (nt > max_threads) nt = max_threads;
   if (nt <= 1 || n < 2 * grain) { fn((uint64_t)0, n); return; }
   const uint64_t nchunks = (n + grain - 1) / grain;
