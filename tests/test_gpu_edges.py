@@ -275,3 +275,28 @@ def test_concurrent_contexts_and_streams(oracle):
     for t in th:
         t.join(300)
     assert not errs, errs
+
+
+@pytest.mark.parametrize("switch", ["LCPC_NTT_PACKED", "LCPC_COMM_MONT"])
+def test_ab_switch_paths_stay_correct(oracle, switch):
+    """the A/B switches select alternative kernels (packed-limb NTT; Montgomery-form comm with the
+    reduction inside the hash kernel).  They are read when the context is created; both paths must keep producing the
+    oracle's commitment and proof."""
+    import os
+    O = oracle
+    n = 3 * 4096 - 5
+    coeffs = O.random_elems(3, n, 77)
+    oenc = O.Encoding.ligero_from_dims(3, 4096, 8192)
+    oc = O.Commit.commit(coeffs, oenc)
+    os.environ[switch] = "1"
+    try:
+        enc = LigeroEncoding.new_from_dims(3, 4096, 8192)
+    finally:
+        del os.environ[switch]
+    c = LcCommit.commit(coeffs, enc)
+    assert (c.comm() == oc.comm()).all() and (c.hashes() == oc.hashes()).all()
+    root = c.get_root()
+    t = O.random_elems(3, c.n_rows, 78)
+    pf = c.prove(t, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+    opf, _ = oc.prove(t, oenc, mk_transcript(O.Transcript, root, enc.get_n_col_opens()))
+    assert pf.to_bytes() == opf
