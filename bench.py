@@ -34,6 +34,44 @@ def device_random_coeffs(torch, n, L, seed, device):
     return t
 
 
+def sample_power(step, torch, seconds=1.6):
+    """rocm-smi shader clock (MHz) and socket power (W), sampled while `step` loops on another thread; None if rocm-smi
+    is unavailable or prints something else."""
+    import re
+    import subprocess
+    import threading
+    stop = threading.Event()
+
+    def loop():
+        while not stop.is_set():
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
+
+    th = threading.Thread(target=loop)
+    th.start()
+    clk, pw = [], []
+    try:
+        time.sleep(0.5)
+        t_end = time.time() + seconds
+        while time.time() < t_end:
+            txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+            m = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", txt)
+            w = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+            if m and w:
+                clk.append(int(m.group(1)))
+                pw.append(float(w.group(1)))
+    except Exception:
+        pass
+    finally:
+        stop.set()
+        th.join()
+    if not clk:
+        return None
+    return {"sclk_MHz": round(sum(clk) / len(clk)), "socket_W": round(sum(pw) / len(pw)), "samples": len(clk),
+            "source": "rocm-smi while the commit loops (after the timed region)"}
+
+
 def usable_cores():
     """host cores this process may actually use: affinity mask, capped by the cgroup CPU quota (the GPU boxes show all
     256 hardware threads but grant 16 CPUs of time; oversubscribing 256 OpenMP threads into that quota is slower)."""
@@ -80,6 +118,7 @@ def main():
     ap.add_argument("--log-len", type=int, default=26)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-sample", action="store_true")
     ap.add_argument("--cpu-sample-log-len", type=int, default=25)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (debug: ranks may share a GPU)")
     ap.add_argument("--force-device", type=int, default=None, help="debug: every rank uses this HIP device")
@@ -219,8 +258,15 @@ def main():
                 "note": "255-bit modular multiply: integer-VALU work at the board power limit (~1.33 kW, sclk ~2.1 GHz: "
                         "profiles/r01f_clock_power.txt), not HBM-bound (DESIGN.md section 6)",
                 "commit_GBps": round(commit_bytes / (tm.total_ms * 1e-3) / 1e9, 1) if tm.total_ms > 0 else None,
+                "power": None,
                 "group_ms": {"encode": round(tm.encode_ms, 3), "hash": round(tm.hash_ms, 3), "merkle": round(tm.merkle_ms, 3),
                              "total": round(tm.total_ms, 3)}}
+
+    # shader clock and socket power while the same step loops (N = 1 only; ~1.5 s, outside the timed region): the NTT runs
+    # at the board power limit, so these two numbers are part of the roofline story
+    power = None
+    if not distributed and not args.no_power_sample:
+        power = sample_power(step, torch)
 
     shard_ms = None
     if distributed:
@@ -252,6 +298,7 @@ def main():
                       "sharding": "rows x%d (BLAKE3-chunk aligned), 1 all-gather of chunk CVs" % world if distributed else "none",
                       "input": "device-resident (HBM)"},
            "roofline": roofline}
+    roofline["power"] = power
     if shard_ms is not None:
         out["shard_ms"] = shard_ms
 
