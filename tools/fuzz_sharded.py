@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""tools/fuzz_sharded.py [n_cases] -- random row-sharded commits (G shard contexts on one GPU, emulated all-gather, as in
+tests/test_gpu_sharded.py): field, shape, row count and shard count drawn at random; every rank's root and full hashes
+array must equal the unsharded oracle commitment.  One-off soak, not part of the test suite."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+import numpy as np
+import torch
+
+import oracle_lib as O
+import test_gpu_sharded as T
+from lcpc_amd import LcCommit, LigeroEncoding
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rnd = random.Random(4242)
+for case in range(n_cases):
+    fid = rnd.choice([0, 1, 3, 3])
+    L = O.limbs(fid)
+    log_n = rnd.randrange(2, 13)
+    n_cols = 1 << log_n
+    n_per_row = rnd.randrange(1, n_cols)
+    n_rows = rnd.randrange(1, 700)
+    G = rnd.choice([2, 3, 4, 5, 8])
+    coeffs = O.random_elems(fid, n_rows * n_per_row, rnd.randrange(1 << 30))
+    dev = torch.from_numpy(coeffs.view(np.int64)).cuda().reshape(n_rows, n_per_row, L)
+    roots, engines = T.run_sharded(lambda sh: LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=sh), G, dev, n_rows)
+    oc = O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4)
+    assert all(r == oc.get_root() for r in roots), (case, fid, n_rows, n_per_row, n_cols, G)
+    for eng in engines:
+        assert (LcCommit(eng.enc).hashes() == oc.hashes()).all(), (case, "hashes")
+    if case % 25 == 0:
+        print("case", case, "ok", flush=True)
+print("all", n_cases, "sharded cases ok")
