@@ -113,3 +113,28 @@ def test_headline_dims():
     assert P.LigeroEncoding.get_dims_len(F, 1 << 28) == (1024, 262144, 524288)
     assert P.SdigEncoding.dims_only(F, 1 << 24, 3) == (101, 166292, 252931)
     assert P.LigeroEncoding.n_col_opens_rho((1, 2)) == 309 and P.SdigEncoding.n_col_opens_code(3) == 6593
+
+
+def test_field_definitions_independent():
+    """The four field definitions (decimal modulus + generator, lcpc-test-fields/src/lib.rs:18-58) checked with sympy,
+    independently of the restatement: the modulus is prime, S is the 2-adicity of p - 1, ROOT_OF_UNITY = g^t with
+    p - 1 = 2^S t (ff_derive's rule [3P]) has order exactly 2^S, R = 2^(64 L) mod p, INV = -p^-1 mod 2^64."""
+    import sympy
+    defs = {
+        "ft63": ("5102708120182849537", 10),
+        "ft127": ("146823888364060453008360742206866194433", 3),
+        "ft191": ("1697146272512170708389931801544665676545308500647389167617", 5),
+        "ft255": ("46242760681095663677370860714659204618859642560429202607213929836750194081793", 5),
+    }
+    for F in P.FIELDS:
+        p, g = int(defs[F.name][0]), defs[F.name][1]
+        assert F.p == p and sympy.isprime(p)
+        s, t = 0, p - 1
+        while t % 2 == 0:
+            s, t = s + 1, t // 2
+        assert F.S == s
+        assert pow(g, (p - 1) // 2, p) == p - 1                      # g is a quadratic non-residue: g^t has full 2-power order
+        assert F.root_of_unity == pow(g, t, p)
+        assert F.R == pow(2, 64 * F.L, p) and F.R2 == pow(2, 128 * F.L, p)
+        assert (F.inv64 * p + 1) % (1 << 64) == 0
+        assert F.flog2 == p.bit_length() - 1
