@@ -8,11 +8,17 @@ coefficients (rho = 1/2, BLAKE3), BASELINE.json's metric, on N MI355X of one nod
 A "step" is one full commit (pad -> row NTTs -> column BLAKE3 -> Merkle tree, lcpc-2d/src/lib.rs:622-671) of
 one synthetic coefficient vector that is already resident in HBM when the timed region starts.  For N > 1 the
 512 rows of the SAME 2^26 commitment are sharded by BLAKE3-chunk-aligned row blocks across the ranks, with one
-RCCL all-gather of chunk chaining values (strong scaling; `--scaling weak` keeps 512 rows per GPU instead).
+RCCL exchange of subtree chaining values inside the library (strong scaling; `--scaling weak` keeps 512 rows per GPU).
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+
+Timing protocol (mirroring rough_bench, lcpc-ligero-pc/src/tests.rs:78-98): the encoder is built outside
+the timed region; W warm-up steps; K steps between barrier + synchronize brackets give `value` / `ms_per_step` (mean);
+HIP events between the same steps give `min_ms_per_step`; afterwards, untimed: one instrumented step (kernel-group
+events), the end-to-end figure from host memory (`e2e_host`, PCIe-inclusive, never `value`) and the CPU baseline.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -22,6 +28,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+KERNEL_SOURCES = ("kernels.hip", "field_dev.h", "field_r29_gen.h", "blake3_dev.h", "kernels.h")
+
+
+def kernel_stamp():
+    """sha256 over the device sources: a committed PMC file is only quoted while it describes these kernels."""
+    h = hashlib.sha256()
+    for n in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "lcpc_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def device_random_coeffs(torch, n, L, seed, device):
@@ -91,23 +107,38 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(log_len_sample, n_per_row, n_cols, threads):
-    """the oracle (C port of the reference algorithm, OpenMP over rows / 32-column blocks) timed on this box's
-    host cores on a bounded sample: same field, same row shape, fewer rows."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-    import oracle_lib as O
-    fid = 3
-    n = 1 << log_len_sample
-    enc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
-    rng = np.random.default_rng(1)
+def host_memory_available():
+    """bytes this process may still allocate: MemAvailable capped by the cgroup limit (a box that dies of OOM is a strike)."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except Exception:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read())
+            avail = min(avail, int(lim) - cur) if avail is not None else int(lim) - cur
+    except Exception:
+        pass
+    return avail
+
+
+def cpu_commit(O, np, log_len, n_per_row, n_cols, threads, seed=1):
+    """one oracle commit (C port of the reference algorithm, OpenMP over rows / 32-column blocks) of 2^log_len Ft255
+    coefficients with the headline row shape; returns (rate, seconds, root, coeffs)."""
+    n = 1 << log_len
+    enc = O.Encoding.ligero_from_dims(3, n_per_row, n_cols)
+    rng = np.random.default_rng(seed)
     coeffs = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)      # < p, as on the GPU side
     t0 = time.perf_counter()
     c = O.Commit.commit(coeffs, enc, n_threads=threads)
     dt = time.perf_counter() - t0
     root = c.get_root()
     del c
-    return n / dt, dt, root
+    return n / dt, dt, root, coeffs
 
 
 def main():
@@ -117,10 +148,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-len", type=int, default=26)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--copy-coeffs", action="store_true", help="LcCommit.coeffs as a private copy (the reference's semantics) instead of "
+                    "borrowing the caller's HBM buffer (LCPC_COMMIT_BORROW_COEFFS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power-sample", action="store_true")
-    ap.add_argument("--cpu-sample-log-len", type=int, default=25)
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (debug: ranks may share a GPU)")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--cpu-sample-log-len", type=int, default=None, help="default: the full 2^log-len if host memory allows, else one less")
+    ap.add_argument("--exchange", choices=["native", "torch"], default="native",
+                    help="N > 1: native = RCCL inside the library (lcpc_commit_sharded_device); torch = torch.distributed all-gather "
+                         "between the two library phases")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (debug: ranks may share a GPU; implies --exchange torch)")
     ap.add_argument("--force-device", type=int, default=None, help="debug: every rank uses this HIP device")
     ap.add_argument("--check", action="store_true", help="debug: compare the sharded root with an unsharded commit of the same data")
     args = ap.parse_args()
@@ -147,6 +184,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
+    if args.dist_backend != "nccl":
+        args.exchange = "torch"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -157,32 +196,36 @@ def main():
     fid, L, F = lcpc_amd.FT255, 4, 32
     n_total = 1 << args.log_len
     n_rows1, n_per_row, n_cols = lcpc_amd.static_get_dims(fid, lcpc_amd.ENC_LIGERO, n_total)
-    if args.scaling == "weak":
-        n_rows_total = n_rows1 * world
-    else:
-        n_rows_total = n_rows1
+    n_rows_total = n_rows1 * world if args.scaling == "weak" else n_rows1
     n_coeffs_job = n_rows_total * n_per_row
+    borrow = not args.copy_coeffs
+    stream = torch.cuda.current_stream().cuda_stream
 
     if not distributed:
         enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=local_rank)
         coeffs = device_random_coeffs(torch, n_coeffs_job, L, 1234, dev)
-        stream = torch.cuda.current_stream().cuda_stream
+        cm = LcCommit(enc)                     # ONE LcCommit object refilled every step (buffers reused; no hipMalloc in the loop)
 
-        def step(sync=False):
-            return LcCommit.commit_device(coeffs.data_ptr(), n_coeffs_job, enc, stream, sync=sync)
+        def step(sync=False, borrow_=borrow):
+            return LcCommit.commit_device(coeffs.data_ptr(), n_coeffs_job, enc, stream, sync=sync, borrow=borrow_, into=cm)
     else:
         enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=local_rank, shard=(rank, world))
         engine = HipShardEngine(enc)
+        cm = engine.cm
         rb, re, cb, ce, n_chunks = engine.layout(n_rows_total)
         coeffs = device_random_coeffs(torch, max(re - rb, 1) * n_per_row, L, 1234 + rank, dev)
-
-        def step(sync=False):
-            return sharded_commit(engine, coeffs, n_rows_total, want_root=sync)
-
-        # bring the communicator up outside the measured region (RCCL connects lazily on the first collective)
+        # bring the communicators up outside the measured region (RCCL connects lazily on the first collective)
         t_init = torch.zeros(1, device=dev)
         dist.all_reduce(t_init)
         torch.cuda.synchronize()
+        if args.exchange == "native":
+            engine.comm_init()
+
+            def step(sync=False, borrow_=borrow):
+                return engine.commit_native(coeffs, n_rows_total, want_root=sync, borrow=borrow_)
+        else:
+            def step(sync=False, borrow_=borrow):
+                return sharded_commit(engine, coeffs, n_rows_total, want_root=sync)
 
     def fence():
         if distributed:
@@ -200,8 +243,7 @@ def main():
             parts.append(device_random_coeffs(torch, max(re_r - rb_r, 1) * n_per_row, L, 1234 + r, dev)[:(re_r - rb_r) * n_per_row])
             del e_r
         full = torch.cat(parts, dim=0).contiguous()
-        ref = LcCommit.commit_device(full.data_ptr(), n_coeffs_job, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=local_rank),
-                                     torch.cuda.current_stream().cuda_stream)
+        ref = LcCommit.commit_device(full.data_ptr(), n_coeffs_job, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=local_rank), stream)
         ok = ref.get_root() == root_sharded
         print("[rank %d] sharded root %s unsharded root: %s" % (rank, "==" if ok else "!=", root_sharded.hex()), file=sys.stderr)
         if not ok:
@@ -216,9 +258,12 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]    # on the launch stream (torch's current stream)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
+        evs[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     if distributed:
@@ -227,12 +272,18 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = n_coeffs_job * args.steps / dt
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    min_ms = min(step_ms)
+    if distributed:
+        t = torch.tensor([min_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        min_ms = float(t.item())
 
     # kernel-group timing with HIP events on the launch stream (one extra, untimed, instrumented step)
-    enc.set_timing(True)
+    cm.set_timing(True)
     step(sync=True)
-    tm = enc.timings()
-    enc.set_timing(False)
+    tm = cm.timings()
+    cm.set_timing(False)
     rows_local = n_rows_total if not distributed else (re - rb)
     enc_bytes = F * rows_local * (n_per_row + n_cols)                 # read coeffs + write comm
     np2 = n_cols
@@ -241,35 +292,74 @@ def main():
     ntt_ms = tm.encode_ms / ntt_launches
     achieved = (enc_bytes / ntt_launches) / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_latest.json")
+    stamp = kernel_stamp()
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path) and world == 1 and args.log_len == 26:
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+        # (tools/profile_round.sh); quoted only while the file was taken from exactly these kernel sources
         pmc = json.load(open(pmc_path))
-        for kname, v in pmc["kernels"].items():
-            if kname.startswith("ntt_pass"):
-                traffic = round((2.0 * v["FETCH_KB"] + v["WRITE_KB"]) * 1024 / 1e9, 3)
-                traffic_src = "profiles/r01_pmc_latest.json (rocprofv3 --pmc; GB per launch = 2*FETCH_SIZE + WRITE_SIZE; " \
-                              "2-pass NTT: each pass reads+writes the matrix, pass 1 also writes LcCommit.coeffs)"
+        if pmc.get("kernel_stamp") == stamp and pmc.get("borrow_coeffs", False) == borrow:
+            for kname, v in pmc["kernels"].items():
+                if kname.startswith("ntt_pass"):
+                    traffic = round((2.0 * v["FETCH_KB"] + v["WRITE_KB"]) * 1024 / 1e9, 3)
+                    traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc, kernel stamp %s; GB per launch = 2*FETCH_SIZE + WRITE_SIZE)" % stamp
+        else:
+            traffic_src = "profiles/pmc_latest.json is stale for these kernels (stamp %s != %s): not quoted" % (pmc.get("kernel_stamp"), stamp)
     roofline = {"bound": "hbm", "kernel": "ntt_pass_l9_kernel (row NTT, Ft255 signed lazy-limb variant; %d launches per commit)" % ntt_launches,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_unit": "GB/launch", "traffic_source": traffic_src,
                 "algorithmic_GB_per_launch": round(enc_bytes / ntt_launches / 1e9, 3),
                 "avg_launch_ms": round(ntt_ms, 4),
-                "note": "255-bit modular multiply: integer-VALU work at the board power limit (~1.33 kW, sclk ~2.1 GHz: "
-                        "profiles/r01f_clock_power.txt), not HBM-bound (DESIGN.md section 6)",
+                "note": "255-bit modular multiply: integer-VALU bound (DESIGN.md section 6), not HBM-bound",
                 "commit_GBps": round(commit_bytes / (tm.total_ms * 1e-3) / 1e9, 1) if tm.total_ms > 0 else None,
                 "power": None,
                 "group_ms": {"encode": round(tm.encode_ms, 3), "hash": round(tm.hash_ms, 3), "merkle": round(tm.merkle_ms, 3),
                              "total": round(tm.total_ms, 3)}}
 
-    # shader clock and socket power while the same step loops (N = 1 only; ~1.5 s, outside the timed region): the NTT runs
-    # at the board power limit, so these two numbers are part of the roofline story
+    # shader clock and socket power while the same step loops (N = 1 only; ~1.5 s, outside the timed region)
     power = None
     if not distributed and not args.no_power_sample:
         power = sample_power(step, torch)
 
+    # secondary figures, N = 1, untimed region: the other LcCommit.coeffs mode and the end-to-end commit from host memory
+    other_mode, e2e = None, None
+    if not distributed:
+        for _ in range(2):
+            step(borrow_=not borrow)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step(borrow_=not borrow)
+        torch.cuda.synchronize()
+        other_mode = {"coeffs": "borrowed" if not borrow else "copied (the reference's LcCommit owns its coeffs)",
+                      "ms_per_step": round((time.perf_counter() - t1) / 5 * 1e3, 3)}
+        step()
+        torch.cuda.synchronize()
+        if not args.no_e2e:
+            try:
+                host = torch.empty((n_coeffs_job, L), dtype=torch.int64).pin_memory()
+                host.copy_(coeffs)
+                cm2 = LcCommit(enc)
+                root_buf = (C.c_uint8 * 32)()
+                lib = _lcpc_lib.lib()
+                ts = []
+                for _ in range(4):
+                    t1 = time.perf_counter()
+                    cm2._check(lib.lcpc_commit(cm2._h, C.c_void_p(host.data_ptr()), n_coeffs_job, root_buf))
+                    ts.append(time.perf_counter() - t1)
+                ts = ts[1:]
+                root_dev = step(sync=True).get_root()
+                e2e = {"ms_mean": round(sum(ts) / len(ts) * 1e3, 2), "ms_min": round(min(ts) * 1e3, 2),
+                       "value": n_coeffs_job / (sum(ts) / len(ts)), "unit": "field-elements/s",
+                       "root_matches_device_commit": bytes(root_buf) == root_dev,
+                       "what": "lcpc_commit from pinned host memory: H2D of the coefficients (row batches overlapped with the NTTs) + "
+                               "commit + root D2H; PCIe-inclusive, reported beside `value`, never as it"}
+                del cm2, host
+            except Exception as ex:          # e.g. not enough pinnable host memory: the headline does not depend on it
+                e2e = {"error": repr(ex)}
+
     shard_ms = None
-    if distributed:
+    if distributed and args.exchange == "torch":
         # where a sharded step spends its time on this rank (one extra, untimed, phase-synchronised step): local encode +
         # node CVs, the all-gather, leaf finish + Merkle tree; MAX over ranks
         from lcpc_amd.distributed import exchange_nodes
@@ -288,29 +378,60 @@ def main():
         dist.all_reduce(ph, op=dist.ReduceOp.MAX)
         shard_ms = {"local_encode_hash": round(float(ph[0]) * 1e3, 3), "all_gather": round(float(ph[1]) * 1e3, 3),
                     "finish": round(float(ph[2]) * 1e3, 3), "gathered_MB": round(gathered.numel() / 1e6, 1)}
+    elif distributed:
+        # native exchange: the library's own event brackets (encode | hash | exchange + finish), MAX over ranks
+        ph = torch.tensor([tm.encode_ms, tm.hash_ms, tm.merkle_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+        shard_ms = {"local_encode": round(float(ph[0]), 3), "local_hash": round(float(ph[1]), 3),
+                    "exchange_plus_finish": round(float(ph[2]), 3)}
 
     out = {"metric": "field-elements committed/sec (whole node), Ligero 2^%d coeffs" % args.log_len,
            "value": value, "unit": "field-elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+           "ms_per_step": ms_per_step, "min_ms_per_step": round(min_ms, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
            "dtype": "u32 limbs (255-bit prime field Ft255, Montgomery form)", "data": "synthetic",
            "config": {"workload": "lcpc-ligero-pc commit, Ft255, 2^%d coeffs, rho=1/2, BLAKE3" % args.log_len,
                       "n_rows": n_rows_total, "n_per_row": n_per_row, "n_cols": n_cols,
-                      "sharding": "rows x%d (BLAKE3-chunk aligned), 1 all-gather of chunk CVs" % world if distributed else "none",
-                      "input": "device-resident (HBM)"},
+                      "sharding": ("rows x%d (BLAKE3-chunk aligned), 1 exchange of subtree CVs (%s)" %
+                                   (world, "RCCL inside the library" if args.exchange == "native" else "torch.distributed all-gather")) if distributed else "none",
+                      "input": "device-resident (HBM)",
+                      "coeffs": "borrowed: LcCommit.coeffs aliases the caller's HBM buffer (LCPC_COMMIT_BORROW_COEFFS)" if borrow
+                                else "copied into the LcCommit"},
            "roofline": roofline}
     roofline["power"] = power
+    if other_mode is not None:
+        out["other_coeffs_mode"] = other_mode
+    if e2e is not None:
+        out["e2e_host"] = e2e
     if shard_ms is not None:
         out["shard_ms"] = shard_ms
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import numpy as np
+        import oracle_lib as O
         threads = usable_cores()
-        v, secs, _ = cpu_baseline(args.cpu_sample_log_len, n_per_row, n_cols, threads)
+        lg = args.cpu_sample_log_len
+        if lg is None:
+            avail = host_memory_available()
+            need = lambda l: 10 * (32 << l)            # coeffs + the oracle's coeffs copy + comm (2x) + slack
+            lg = args.log_len if (avail is None or avail > need(args.log_len) + (8 << 30)) else args.log_len - 1
+        v, secs, root_cpu, cpu_coeffs = cpu_commit(O, np, lg, n_per_row, n_cols, threads)
+        # the same sample through the HIP path: the baseline doubles as a full-size parity check
+        dev_sample = torch.from_numpy(cpu_coeffs.view(np.int64)).to(dev)
+        root_gpu = LcCommit.commit_device(dev_sample.data_ptr(), 1 << lg, enc, stream, sync=True).get_root()
+        if root_gpu != root_cpu:
+            raise SystemExit("bench.py: HIP root != oracle root on the CPU-baseline sample (2^%d): %s vs %s" % (lg, root_gpu.hex(), root_cpu.hex()))
+        del dev_sample, cpu_coeffs
+        lg1 = max(lg - 4, 17)
+        v1, secs1, _, _ = cpu_commit(O, np, lg1, n_per_row, n_cols, 1)
         out["cpu_baseline"] = {"value": v, "unit": "field-elements/s", "cores": threads, "kind": "port",
                                "host_hw_threads": os.cpu_count(),
+                               "root_equals_hip_root": True,
+                               "one_thread": {"value": v1, "cores": 1, "sample": "2^%d coeffs (%d rows), %.1f s wall" % (lg1, (1 << lg1) // n_per_row, secs1)},
                                "sample": "oracle C port (OpenMP, one thread per usable core: affinity mask capped by the cgroup CPU "
                                          "quota), Ligero Ft255 commit of 2^%d coeffs with the headline row "
-                                         "shape (%d x %d -> %d), %.1f s wall" % (args.cpu_sample_log_len,
-                                                                                 (1 << args.cpu_sample_log_len) // n_per_row, n_per_row, n_cols, secs)}
+                                         "shape (%d x %d -> %d), %.1f s wall; the same coefficients committed through the HIP "
+                                         "path give the same root" % (lg, (1 << lg) // n_per_row, n_per_row, n_cols, secs)}
     if rank == 0:
         print(json.dumps(out))
     if distributed:

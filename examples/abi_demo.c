@@ -34,7 +34,9 @@ int main(void) {
   uint64_t coeffs[1024];
   for (int i = 0; i < 1024; i++) coeffs[i] = to_mont63((uint64_t)i + 1);
   uint8_t root[32];
-  CHECK(lcpc_commit(ctx, coeffs, 1024, root));
+  lcpc_commit_t *cm = NULL;                     /* LcCommit::commit(&coeffs, &enc) */
+  CHECK(lcpc_commit_create(ctx, &cm));
+  CHECK(lcpc_commit(cm, coeffs, 1024, root));
   printf("root ");
   for (int i = 0; i < 32; i++) printf("%02x", root[i]);
   printf("\n");
@@ -56,7 +58,7 @@ int main(void) {
   lcpc_transcript *tv = lcpc_transcript_clone(tp);
   uint8_t *proof = NULL;
   uint64_t proof_len = 0;
-  CHECK(lcpc_prove(ctx, outer, n_rows, tp, &proof, &proof_len, NULL));
+  CHECK(lcpc_prove(cm, outer, n_rows, tp, &proof, &proof_len, NULL));
   uint64_t eval_mont = 0;
   CHECK(lcpc_verify(ctx, root, outer, n_rows, inner, n_per_row, proof, proof_len, tv, &eval_mont));
   /* the true evaluation sum (i+1) x^i, by Horner, and the verifier's answer brought out of Montgomery form */
@@ -72,6 +74,7 @@ int main(void) {
   lcpc_transcript_free(tv);
   free(inner);
   free(outer);
+  lcpc_commit_destroy(cm);
   lcpc_ctx_destroy(ctx);
   return eval == (uint64_t)acc ? 0 : 2;
 }

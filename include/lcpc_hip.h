@@ -13,9 +13,13 @@
  *  - field elements cross exactly as ff_derive stores them: L little-endian uint64_t limbs in
  *    Montgomery form (R = 2^(64 L)), so a Rust `&[Ft255]` is passed as `*const u64` unchanged
  *    (lcpc-test-fields/src/lib.rs:18-58); digests are 32 raw bytes;
- *  - the caller owns every host buffer; the context owns all device memory (coeffs, comm, hashes
- *    stay on the GPU after commit, as LcCommit retains them, lib.rs:172-184);
- *  - a context is used by one host thread at a time; contexts are independent;
+ *  - two handle types, as in the reference: `lcpc_ctx` is an LcEncoding implementor (`&E`: twiddle tables /
+ *    expander matrices on the device, immutable after creation, shared by any number of commitments and
+ *    usable from several host threads at once, like a `Sync` encoder), and `lcpc_commit_t` is an
+ *    LcCommit<D, E> (lib.rs:172-184): comm / coeffs / hashes of ONE commitment, resident in HBM, created by
+ *    commit() and consumed by prove / open_column / collapse_columns.  Many commitments may be live under
+ *    one encoder (lib.rs:299-311); each is used by one host thread at a time;
+ *  - the caller owns every host buffer; device memory belongs to the handle that allocated it;
  *  - `*_device` entry points take HIP device pointers + a hipStream_t (passed as void*), so a host
  *    runtime (torch, or a Rust hip-sys binding) can keep inputs resident in HBM.
  */
@@ -27,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LCPC_ABI_VERSION 1
+#define LCPC_ABI_VERSION 2
 
 /* fields of lcpc-test-fields/src/lib.rs:13-59 */
 enum { LCPC_FT63 = 0, LCPC_FT127 = 1, LCPC_FT191 = 2, LCPC_FT255 = 3 };
@@ -52,7 +56,8 @@ typedef enum {
   LCPC_ERR_HIP = -16,
   LCPC_ERR_NOMEM = -17,
   LCPC_ERR_NO_DEVICE = -18,
-  LCPC_ERR_XCHG = -19,      /* the caller's all-gather callback of a sharded prove failed */
+  LCPC_ERR_XCHG = -19,      /* the all-gather of a sharded commit / prove failed (callback or RCCL) */
+  LCPC_ERR_NO_RCCL = -20,   /* librccl could not be loaded (native exchange only) */
   /* VerifierError, lib.rs:137-166 */
   LCPC_VERR_NUM_COL_OPENS = -32,
   LCPC_VERR_COLUMN_PATH = -33,
@@ -65,7 +70,8 @@ typedef enum {
   LCPC_VERR_MALFORMED = -40 /* bincode payload does not parse (serde error in the reference) */
 } lcpc_status;
 
-typedef struct lcpc_ctx lcpc_ctx;
+typedef struct lcpc_ctx lcpc_ctx;            /* an LcEncoding implementor (`enc`) */
+typedef struct lcpc_commit_s lcpc_commit_t;    /* an LcCommit<D, E> */
 typedef struct lcpc_transcript lcpc_transcript;
 
 typedef struct {
@@ -89,6 +95,7 @@ typedef struct {
  *      SdigEncoding::new / new_from_dims (brakedown lib.rs:103-137).  Twiddles / expander matrices
  *      are built and uploaded here, outside any timed commit (as in rough_bench, ligero tests.rs:86-90). */
 int  lcpc_ctx_create(const lcpc_params *params, lcpc_ctx **out);
+/* commitments created from the context keep its tables alive until they are destroyed themselves */
 void lcpc_ctx_destroy(lcpc_ctx *ctx);
 const char *lcpc_strerror(int status);
 const char *lcpc_last_error(const lcpc_ctx *ctx);     /* detail string for LCPC_ERR_HIP etc. */
@@ -113,30 +120,42 @@ int  lcpc_static_get_dims_ml(const lcpc_params *params, uint32_t n_vars, uint64_
 int  lcpc_encode_rows(lcpc_ctx *ctx, uint64_t *rows_host, uint64_t n_rows);
 
 /* ---- LcCommit (lcpc-2d/src/lib.rs:172-184, 270-312) ---- */
+/* An empty LcCommit bound to `enc` (no device memory yet); every commit entry point below fills it.  Filling it
+ * again replaces the commitment and reuses the buffers (a benchmark loop commits into one object; the reference
+ * would drop and reallocate its Vecs).  The object holds a reference on `enc`. */
+int  lcpc_commit_create(lcpc_ctx *enc, lcpc_commit_t **out);
+void lcpc_commit_destroy(lcpc_commit_t *cm);
+const char *lcpc_commit_last_error(const lcpc_commit_t *cm);
 /* commit(coeffs, enc) (lib.rs:299-301 -> 622-671): pad, encode every row, hash columns, Merkleize.
- * comm / coeffs / hashes stay on the device.  `root` (32 bytes) may be NULL. */
-int  lcpc_commit(lcpc_ctx *ctx, const uint64_t *coeffs_host, uint64_t n_coeffs, uint8_t *root);
+ * comm / coeffs / hashes stay on the device.  `root` (32 bytes) may be NULL.  Returns after the work is complete. */
+int  lcpc_commit(lcpc_commit_t *cm, const uint64_t *coeffs_host, uint64_t n_coeffs, uint8_t *root);
 /* same with the coefficients already resident in HBM (device pointer), work enqueued on `stream`;
- * if `root` is non-NULL the call synchronises the stream and copies the root out. */
-int  lcpc_commit_device(lcpc_ctx *ctx, const uint64_t *coeffs_dev, uint64_t n_coeffs, void *stream, uint8_t *root);
+ * if `root` is non-NULL the call synchronises the stream and copies the root out.
+ * flags & LCPC_COMMIT_BORROW_COEFFS: LcCommit.coeffs (lib.rs:636-645) is not copied -- the commitment keeps reading the
+ * caller's buffer (prove / collapse), which must stay valid and unchanged until the commitment is replaced or
+ * destroyed.  Honoured when n_coeffs fills whole rows (n_coeffs == n_rows * n_per_row); a ragged vector is copied
+ * (the padded tail has to exist somewhere). */
+enum { LCPC_COMMIT_BORROW_COEFFS = 1 };
+int  lcpc_commit_device(lcpc_commit_t *cm, const uint64_t *coeffs_dev, uint64_t n_coeffs, void *stream, uint32_t flags,
+                        uint8_t *root);
 /* test hook for lcpc-2d/src/tests.rs:435-466 `random_comm` + `merkleize` (tests.rs:136-149): install a
  * caller-supplied comm (n_rows x n_cols) and coeffs (n_rows x n_per_row, may be NULL), then Merkleize. */
-int  lcpc_commit_from_parts(lcpc_ctx *ctx, const uint64_t *comm_host, const uint64_t *coeffs_host,
+int  lcpc_commit_from_parts(lcpc_commit_t *cm, const uint64_t *comm_host, const uint64_t *coeffs_host,
                             uint64_t n_rows, uint8_t *root);
-int  lcpc_get_root(lcpc_ctx *ctx, uint8_t root[32]);                /* get_root lib.rs:276-281 */
-int  lcpc_commit_dims(const lcpc_ctx *ctx, uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols,
-                      uint64_t *n_hashes);                           /* get_n_rows/.. lib.rs:283-296 */
-int  lcpc_get_hashes(lcpc_ctx *ctx, uint8_t *hashes);               /* LcCommit.hashes: (2*np2-1)*32 bytes */
-int  lcpc_get_comm(lcpc_ctx *ctx, uint64_t row0, uint64_t n_rows, uint64_t *out);    /* LcCommit.comm rows (Montgomery form,
-                                                                                         whatever the device keeps) */
-int  lcpc_get_coeffs(lcpc_ctx *ctx, uint64_t row0, uint64_t n_rows, uint64_t *out);  /* LcCommit.coeffs rows */
+int  lcpc_get_root(lcpc_commit_t *cm, uint8_t root[32]);                /* get_root lib.rs:276-281 */
+int  lcpc_commit_dims(const lcpc_commit_t *cm, uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols,
+                      uint64_t *n_hashes);                               /* get_n_rows/.. lib.rs:283-296 */
+int  lcpc_get_hashes(lcpc_commit_t *cm, uint8_t *hashes);               /* LcCommit.hashes: (2*np2-1)*32 bytes */
+int  lcpc_get_comm(lcpc_commit_t *cm, uint64_t row0, uint64_t n_rows, uint64_t *out);    /* LcCommit.comm rows (Montgomery form,
+                                                                                             whatever the device keeps) */
+int  lcpc_get_coeffs(lcpc_commit_t *cm, uint64_t row0, uint64_t n_rows, uint64_t *out);  /* LcCommit.coeffs rows */
 
 /* collapse_columns (lib.rs:1095-1123; test alias eval_outer lib.rs:1176-1202) for n_tensors tensors
  * of n_rows elements each, fused into one pass over coeffs: polys[t][j] = sum_r coeffs[r][j]*tensors[t][r]. */
-int  lcpc_collapse(lcpc_ctx *ctx, const uint64_t *tensors_host, uint32_t n_tensors, uint64_t *polys_host);
+int  lcpc_collapse(lcpc_commit_t *cm, const uint64_t *tensors_host, uint32_t n_tensors, uint64_t *polys_host);
 /* open_column (lib.rs:788-825) for n columns: col_vals[n][n_rows][L], paths[n][path_len][32],
  * path_len = ceil(log2 n_cols).  LCPC_ERR_COLUMN_NUMBER if any column >= n_cols. */
-int  lcpc_open_columns(lcpc_ctx *ctx, const uint64_t *cols, uint32_t n, uint64_t *col_vals, uint8_t *paths);
+int  lcpc_open_columns(lcpc_commit_t *cm, const uint64_t *cols, uint32_t n, uint64_t *col_vals, uint8_t *paths);
 
 /* ---- merlin::Transcript (the `tr: &mut Transcript` argument of prove/verify, lib.rs:304-311, 518-527) ---- */
 lcpc_transcript *lcpc_transcript_new(const uint8_t *label, size_t len);
@@ -146,10 +165,10 @@ void lcpc_transcript_challenge_bytes(lcpc_transcript *, const uint8_t *label, si
 void lcpc_transcript_free(lcpc_transcript *);
 
 /* ---- prove / verify ---- */
-/* LcCommit::prove (lib.rs:304-311 -> 1004-1093).  The proof is returned in the reference's bincode 1.3
+/* LcCommit::prove (lib.rs:304-311 -> 1004-1093); the encoder is the one the commitment was made with.  The proof is returned in the reference's bincode 1.3
  * wire layout (lib.rs:550-609): the only way to hand an LcEvalProof to the reference (its fields are
  * private).  `*proof` is malloc'ed; free with lcpc_free.  cols_opened (n_col_opens entries) may be NULL. */
-int  lcpc_prove(lcpc_ctx *ctx, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
+int  lcpc_prove(lcpc_commit_t *cm, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
                 uint8_t **proof, uint64_t *proof_len, uint64_t *cols_opened);
 /* LcEvalProof::verify (lib.rs:518-527 -> 832-952) on a bincode proof; `ctx` plays the role of `enc`
  * (it need not hold a commitment).  eval_out: L limbs. */
@@ -160,8 +179,13 @@ int  lcpc_verify(lcpc_ctx *ctx, const uint8_t root[32], const uint64_t *outer_te
 void lcpc_root_bincode(const uint8_t root[32], uint8_t out[40]);
 void lcpc_free(void *p);
 
-/* ---- row-sharded commit across GPUs (one ctx per GPU; the exchange is done by the caller, e.g.
- *      torch.distributed all_gather over RCCL/xGMI) ---- */
+/* ---- row-sharded commit across GPUs: one encoder ctx (shard_rank / shard_count set) and one process per
+ *      GPU.  Rows are split into blocks aligned to the BLAKE3 chunk boundaries of the leaf message, so a rank reduces its
+ *      rows to chaining values alone; the ONE exchange step of the path is an all-gather of those.  Two ways to run it:
+ *      (a) native: lcpc_comm_init() gives the encoder an RCCL communicator and lcpc_commit_sharded_device() /
+ *          lcpc_prove_sharded_rccl() do shard -> ncclAllGather -> finish on one stream (xGMI, no host round trip);
+ *      (b) split phases + a caller-supplied exchange (torch.distributed, MPI, a test harness): lcpc_commit_shard_device,
+ *          the caller's all-gather, lcpc_commit_finish_device; lcpc_prove_sharded with an lcpc_allgather_fn. ---- */
 /* rows [row_begin,row_end) and leaf-message chunks [chunk_begin,chunk_end) owned by this shard for a
  * commitment of n_rows_total rows; n_chunks_total = BLAKE3 chunks per leaf message. */
 int  lcpc_shard_layout(const lcpc_ctx *ctx, uint64_t n_rows_total, uint64_t *row_begin, uint64_t *row_end,
@@ -171,34 +195,49 @@ int  lcpc_shard_layout(const lcpc_ctx *ctx, uint64_t n_rows_total, uint64_t *row
  * (n_chunks_total, shard_count, shard_rank): node k of that shard starts at chunk first_chunk[k]. */
 int  lcpc_shard_nodes(uint64_t n_chunks_total, uint32_t shard_count, uint32_t shard_rank, uint32_t *n_nodes,
                       uint64_t *first_chunk /* [64] */, uint32_t *log_size /* [64] */);
-/* phase 1: encode the local rows (coeffs_dev = local rows only, row-major, padded) and reduce them to one
+/* (a) native exchange.  One rank calls lcpc_comm_unique_id (ncclGetUniqueId) and distributes the 128 bytes by any
+ * means; every rank then calls lcpc_comm_init on its sharded encoder (ncclCommInitRank on the encoder's device;
+ * rank / world must equal shard_rank / shard_count; world == 1 is allowed and still goes through RCCL).
+ * librccl is loaded at run time (dlopen): LCPC_ERR_NO_RCCL if it is absent. */
+int  lcpc_comm_unique_id(uint8_t id[128]);
+int  lcpc_comm_init(lcpc_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_t world);
+int  lcpc_comm_destroy(lcpc_ctx *ctx);
+/* whole sharded commit on `stream`: encode + hash the local rows (coeffs_local_dev = this rank's rows, row-major),
+ * ncclAllGather of the node chaining values, leaf digests + Merkle tree (replicated).  No host synchronisation unless
+ * `root` is non-NULL.  flags as lcpc_commit_device. */
+int  lcpc_commit_sharded_device(lcpc_commit_t *cm, const uint64_t *coeffs_local_dev, uint64_t n_rows_total, void *stream,
+                                uint32_t flags, uint8_t *root);
+/* LcCommit::prove on a sharded commitment with the three all-gathers on RCCL (see lcpc_prove_sharded). */
+int  lcpc_prove_sharded_rccl(lcpc_commit_t *cm, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
+                             uint8_t **proof, uint64_t *proof_len, uint64_t *cols_opened);
+/* (b) phase 1: encode the local rows (coeffs_dev = local rows only, row-major, padded) and reduce them to one
  * BLAKE3 chaining value per (local node, column): nodes_dev[k * n_cols + col][32 B], k < n_nodes. */
-int  lcpc_commit_shard_device(lcpc_ctx *ctx, const uint64_t *coeffs_local_dev, uint64_t n_rows_total,
-                              void *stream, uint8_t *nodes_dev);
+int  lcpc_commit_shard_device(lcpc_commit_t *cm, const uint64_t *coeffs_local_dev, uint64_t n_rows_total,
+                              void *stream, uint32_t flags, uint8_t *nodes_dev);
 /* phase 2 (after the all-gather): gathered_dev is the raw all-gather output, rank g's nodes at
  * [(g * slots_per_rank + k) * n_cols + col][32 B] (slots_per_rank >= max nodes per rank; unused slots ignored)
  * -> leaf digests, Merkle tree, root.  The buffer is clobbered. */
-int  lcpc_commit_finish_device(lcpc_ctx *ctx, uint8_t *gathered_dev, uint64_t n_rows_total, uint32_t slots_per_rank,
+int  lcpc_commit_finish_device(lcpc_commit_t *cm, uint8_t *gathered_dev, uint64_t n_rows_total, uint32_t slots_per_rank,
                                void *stream, uint8_t *root);
 /* collapse on the local rows only (tensor entries for the local rows); partial results are summed
  * mod p by lcpc_field_sum_device after an all-gather. */
-int  lcpc_collapse_device(lcpc_ctx *ctx, const uint64_t *tensors_dev, uint32_t n_tensors, void *stream,
+int  lcpc_collapse_device(lcpc_commit_t *cm, const uint64_t *tensors_dev, uint32_t n_tensors, void *stream,
                           uint64_t *polys_dev);
 int  lcpc_field_sum_device(lcpc_ctx *ctx, const uint64_t *parts_dev, uint32_t n_parts, uint64_t n_elems,
                            void *stream, uint64_t *out_dev);
-/* LcCommit::prove (lib.rs:1004-1093) on a row-sharded commitment (after lcpc_commit_shard_device +
- * lcpc_commit_finish_device on every rank).  collapse_columns splits by rows: each rank sums its rows, the partial
+/* LcCommit::prove (lib.rs:1004-1093) on a row-sharded commitment (after the sharded commit on every rank).
+ * collapse_columns splits by rows: each rank sums its rows, the partial
  * polynomials are all-gathered and added mod p; open_column gathers each rank's rows of the requested columns and
  * all-gathers them; transcript, challenges and bincode are computed identically on every rank, so every rank returns
  * the same proof bytes (== the unsharded proof).  The exchange is the caller's: `allgather(user, bytes)` must
  * all-gather the first `bytes` bytes of send_dev from every rank into recv_dev (rank g's block at g * bytes) -- e.g.
- * ncclAllGather on RCCL, torch.distributed.all_gather_into_tensor -- and return 0 once recv_dev is complete and
+ * torch.distributed.all_gather_into_tensor -- and return 0 once recv_dev is complete and
  * visible to the null stream.  All ranks must call with the same outer_tensor (all n_rows_total entries) and the
  * same transcript state.  send_dev: max_bytes, recv_dev: shard_count * max_bytes device bytes,
  * max_bytes >= lcpc_prove_sharded_bytes().  3 exchanges for n_degree_tests = 1. */
 typedef int (*lcpc_allgather_fn)(void *user, uint64_t bytes);
 uint64_t lcpc_prove_sharded_bytes(const lcpc_ctx *ctx, uint64_t n_rows_total);
-int  lcpc_prove_sharded(lcpc_ctx *ctx, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
+int  lcpc_prove_sharded(lcpc_commit_t *cm, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
                         uint8_t *send_dev, uint8_t *recv_dev, uint64_t max_bytes, lcpc_allgather_fn allgather, void *user,
                         uint8_t **proof, uint64_t *proof_len, uint64_t *cols_opened);
 
@@ -207,8 +246,8 @@ typedef struct {
   float encode_ms, hash_ms, merkle_ms, total_ms;
   uint32_t encode_launches, hash_launches, merkle_launches;
 } lcpc_timings;
-int  lcpc_set_timing(lcpc_ctx *ctx, int enable);
-int  lcpc_get_timings(lcpc_ctx *ctx, lcpc_timings *out);
+int  lcpc_set_timing(lcpc_commit_t *cm, int enable);
+int  lcpc_get_timings(lcpc_commit_t *cm, lcpc_timings *out);
 
 #ifdef __cplusplus
 }

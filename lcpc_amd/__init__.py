@@ -110,17 +110,9 @@ class _Encoding:
         self._check(_lib.lib().lcpc_encode_rows(self._h, _ptr(rows), n))
         return rows
 
-    def set_timing(self, on=True):
-        self._check(_lib.lib().lcpc_set_timing(self._h, 1 if on else 0))
-
-    def timings(self):
-        t = LcpcTimings()
-        self._check(_lib.lib().lcpc_get_timings(self._h, C.byref(t)))
-        return t
-
     def __del__(self):
         try:
-            _lib.lib().lcpc_ctx_destroy(self._h)
+            _lib.lib().lcpc_ctx_destroy(self._h)      # commitments made with it keep the tables alive (refcount)
         except Exception:
             pass
 
@@ -208,41 +200,63 @@ class SdigEncoding(_Encoding):
         return cls(field, None, seed, code, device, _dims=(n_per_row, n_cols))
 
 
+BORROW_COEFFS = 1      # LCPC_COMMIT_BORROW_COEFFS
+
+
 class LcCommit:
-    """LcCommit<D, E> (lcpc-2d/src/lib.rs:172-184, 270-312) with D = BLAKE3: comm / coeffs / hashes stay in HBM,
-    owned by the encoding's context (one live commitment per encoding object)."""
+    """LcCommit<D, E> (lcpc-2d/src/lib.rs:172-184, 270-312) with D = BLAKE3: one lcpc_commit_t -- comm / coeffs / hashes
+    of ONE commitment, resident in HBM.  Any number of them may be live under one encoding object (lib.rs:299-311)."""
 
     def __init__(self, enc):
+        """an empty commitment bound to `enc` (lcpc_commit_create); the commit constructors below fill it."""
         self.enc = enc
+        h = C.c_void_p()
+        rc = _lib.lib().lcpc_commit_create(enc._h, C.byref(h))
+        if rc:
+            raise LcpcError(rc)
+        self._h = h
+        self.n_rows = self.n_per_row = self.n_cols = self.n_hashes = 0
+
+    def _check(self, rc):
+        if rc:
+            raise LcpcError(rc, _lib.lib().lcpc_commit_last_error(self._h).decode())
+
+    def _refresh(self):
         a, b, c, d = (C.c_uint64() for _ in range(4))
-        enc._check(_lib.lib().lcpc_commit_dims(enc._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        self._check(_lib.lib().lcpc_commit_dims(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         self.n_rows, self.n_per_row, self.n_cols, self.n_hashes = a.value, b.value, c.value, d.value
+        return self
 
     @classmethod
-    def commit(cls, coeffs, enc):
-        """LcCommit::commit(&coeffs, &enc) (lib.rs:299-301) from host memory."""
+    def commit(cls, coeffs, enc, into=None):
+        """LcCommit::commit(&coeffs, &enc) (lib.rs:299-301) from host memory.  `into`: refill that object (buffers reused)."""
         coeffs = _elems(coeffs, enc.L)
-        enc._check(_lib.lib().lcpc_commit(enc._h, _ptr(coeffs), coeffs.size // enc.L, None))
-        return cls(enc)
+        cm = into if into is not None else cls(enc)
+        cm._check(_lib.lib().lcpc_commit(cm._h, _ptr(coeffs), coeffs.size // enc.L, None))
+        return cm._refresh()
 
     @classmethod
-    def commit_device(cls, coeffs_ptr, n_coeffs, enc, stream=0, sync=True):
-        """same, coefficients already in HBM (`coeffs_ptr` = device address, e.g. torch tensor .data_ptr())."""
+    def commit_device(cls, coeffs_ptr, n_coeffs, enc, stream=0, sync=True, borrow=False, into=None):
+        """same, coefficients already in HBM (`coeffs_ptr` = device address, e.g. torch tensor .data_ptr()).
+        borrow: LCPC_COMMIT_BORROW_COEFFS -- the commitment keeps reading the caller's buffer instead of copying it."""
+        cm = into if into is not None else cls(enc)
         root = (C.c_uint8 * 32)() if sync else None
-        enc._check(_lib.lib().lcpc_commit_device(enc._h, C.c_void_p(coeffs_ptr), n_coeffs, C.c_void_p(stream), root))
-        return cls(enc)
+        cm._check(_lib.lib().lcpc_commit_device(cm._h, C.c_void_p(coeffs_ptr), n_coeffs, C.c_void_p(stream),
+                                                BORROW_COEFFS if borrow else 0, root))
+        return cm._refresh()
 
     @classmethod
     def from_parts(cls, enc, comm, coeffs, n_rows):
         """test hook = lcpc-2d/src/tests.rs:435-466 random_comm + merkleize."""
         comm = _elems(comm, enc.L)
         cp = _ptr(_elems(coeffs, enc.L)) if coeffs is not None else None
-        enc._check(_lib.lib().lcpc_commit_from_parts(enc._h, _ptr(comm), cp, n_rows, None))
-        return cls(enc)
+        cm = cls(enc)
+        cm._check(_lib.lib().lcpc_commit_from_parts(cm._h, _ptr(comm), cp, n_rows, None))
+        return cm._refresh()
 
     def get_root(self):
         out = (C.c_uint8 * 32)()
-        self.enc._check(_lib.lib().lcpc_get_root(self.enc._h, out))
+        self._check(_lib.lib().lcpc_get_root(self._h, out))
         return bytes(out)
 
     def get_n_rows(self):
@@ -256,29 +270,29 @@ class LcCommit:
 
     def hashes(self):
         out = np.zeros((self.n_hashes, 32), np.uint8)
-        self.enc._check(_lib.lib().lcpc_get_hashes(self.enc._h, _ptr(out)))
+        self._check(_lib.lib().lcpc_get_hashes(self._h, _ptr(out)))
         return out
 
     def comm(self, row0=0, n_rows=None):
         n_rows = self.n_rows - row0 if n_rows is None else n_rows
         out = np.zeros((n_rows * self.n_cols, self.enc.L), np.uint64)
-        self.enc._check(_lib.lib().lcpc_get_comm(self.enc._h, row0, n_rows, _ptr(out)))
+        self._check(_lib.lib().lcpc_get_comm(self._h, row0, n_rows, _ptr(out)))
         return out
 
     def coeffs(self, row0=0, n_rows=None):
         n_rows = self.n_rows - row0 if n_rows is None else n_rows
         out = np.zeros((n_rows * self.n_per_row, self.enc.L), np.uint64)
-        self.enc._check(_lib.lib().lcpc_get_coeffs(self.enc._h, row0, n_rows, _ptr(out)))
+        self._check(_lib.lib().lcpc_get_coeffs(self._h, row0, n_rows, _ptr(out)))
         return out
 
     def eval_outer(self, tensors):
         """collapse_columns (lib.rs:1095-1123) for one (n_rows, L) or several (k, n_rows, L) tensors."""
         t = _elems(tensors, self.enc.L)
-        k = t.size // (self.n_rows * self.enc.L)
-        if k * self.n_rows * self.enc.L != t.size or k == 0:
+        k = t.size // (self.n_rows * self.enc.L) if self.n_rows else 0
+        if k == 0 or k * self.n_rows * self.enc.L != t.size:
             raise LcpcError(ERR_OUTER_TENSOR)
         out = np.zeros((k, self.n_per_row, self.enc.L), np.uint64)
-        self.enc._check(_lib.lib().lcpc_collapse(self.enc._h, _ptr(t), k, _ptr(out)))
+        self._check(_lib.lib().lcpc_collapse(self._h, _ptr(t), k, _ptr(out)))
         return out[0] if k == 1 and np.ndim(tensors) <= 2 else out
 
     def open_columns(self, cols):
@@ -287,7 +301,7 @@ class LcCommit:
         path_len = max(0, (self.n_cols - 1).bit_length())
         vals = np.zeros((n, self.n_rows, self.enc.L), np.uint64)
         paths = np.zeros((n, max(path_len, 1), 32), np.uint8)
-        self.enc._check(_lib.lib().lcpc_open_columns(self.enc._h, _ptr(cols), n, _ptr(vals), _ptr(paths)))
+        self._check(_lib.lib().lcpc_open_columns(self._h, _ptr(cols), n, _ptr(vals), _ptr(paths)))
         return vals, paths[:, :path_len]
 
     def open_column(self, col):
@@ -301,10 +315,24 @@ class LcCommit:
         t = _elems(outer_tensor, enc.L)
         pp, plen = C.c_void_p(), C.c_uint64()
         cols = np.zeros(enc.get_n_col_opens(), np.uint64)
-        enc._check(_lib.lib().lcpc_prove(enc._h, _ptr(t), t.size // enc.L, tr._h, C.byref(pp), C.byref(plen), _ptr(cols)))
+        self._check(_lib.lib().lcpc_prove(self._h, _ptr(t), t.size // enc.L, tr._h, C.byref(pp), C.byref(plen), _ptr(cols)))
         data = C.string_at(pp, plen.value)
         _lib.lib().lcpc_free(pp)
         return LcEvalProof(data, enc.L, cols)
+
+    def set_timing(self, on=True):
+        self._check(_lib.lib().lcpc_set_timing(self._h, 1 if on else 0))
+
+    def timings(self):
+        t = LcpcTimings()
+        self._check(_lib.lib().lcpc_get_timings(self._h, C.byref(t)))
+        return t
+
+    def __del__(self):
+        try:
+            _lib.lib().lcpc_commit_destroy(self._h)
+        except Exception:
+            pass
 
 
 class LcEvalProof:

@@ -1,11 +1,12 @@
 """ctypes loader for lcpc_amd/lib/liblcpc_hip.so (the product: HIP kernels + C ABI of include/lcpc_hip.h).
 
 There is deliberately NO fallback: if the shared library is missing or no HIP device is usable, every
-entry point raises.  Nothing in this package imports oracle/."""
+entry point raises.  Nothing in this package touches the CPU restatement the tests check it against."""
 import ctypes as C
 import os
 import subprocess
 
+ABI_VERSION = 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblcpc_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
@@ -41,8 +42,11 @@ SYMBOLS = {
     "lcpc_static_get_dims": (_i32, [C.POINTER(LcpcParams), _vp, _vp, _vp]),
     "lcpc_static_get_dims_ml": (_i32, [_vp, _u32, _vp, _vp, _vp]),
     "lcpc_encode_rows": (_i32, [_vp, _vp, _u64]),
+    "lcpc_commit_create": (_i32, [_vp, C.POINTER(_vp)]),
+    "lcpc_commit_destroy": (None, [_vp]),
+    "lcpc_commit_last_error": (C.c_char_p, [_vp]),
     "lcpc_commit": (_i32, [_vp, _vp, _u64, _vp]),
-    "lcpc_commit_device": (_i32, [_vp, _vp, _u64, _vp, _vp]),
+    "lcpc_commit_device": (_i32, [_vp, _vp, _u64, _vp, _u32, _vp]),
     "lcpc_commit_from_parts": (_i32, [_vp, _vp, _vp, _u64, _vp]),
     "lcpc_get_root": (_i32, [_vp, _vp]),
     "lcpc_commit_dims": (_i32, [_vp, _vp, _vp, _vp, _vp]),
@@ -62,7 +66,12 @@ SYMBOLS = {
     "lcpc_free": (None, [_vp]),
     "lcpc_shard_layout": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     "lcpc_shard_nodes": (_i32, [_u64, _u32, _u32, _vp, _vp, _vp]),
-    "lcpc_commit_shard_device": (_i32, [_vp, _vp, _u64, _vp, _vp]),
+    "lcpc_comm_unique_id": (_i32, [_vp]),
+    "lcpc_comm_init": (_i32, [_vp, _vp, _u32, _u32]),
+    "lcpc_comm_destroy": (_i32, [_vp]),
+    "lcpc_commit_sharded_device": (_i32, [_vp, _vp, _u64, _vp, _u32, _vp]),
+    "lcpc_prove_sharded_rccl": (_i32, [_vp, _vp, _u64, _vp, _vp, _vp, _vp]),
+    "lcpc_commit_shard_device": (_i32, [_vp, _vp, _u64, _vp, _u32, _vp]),
     "lcpc_commit_finish_device": (_i32, [_vp, _vp, _u64, _u32, _vp, _vp]),
     "lcpc_collapse_device": (_i32, [_vp, _vp, _u32, _vp, _vp]),
     "lcpc_field_sum_device": (_i32, [_vp, _vp, _u32, _u64, _vp, _vp]),
@@ -101,7 +110,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.lcpc_abi_version() != 1:
+        if L.lcpc_abi_version() != ABI_VERSION:
             raise RuntimeError("lcpc_amd: ABI version mismatch")
         _lib = L
     return _lib

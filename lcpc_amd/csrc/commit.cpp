@@ -1,0 +1,503 @@
+// lcpc_amd/csrc/commit.cpp -- lcpc_commit: an LcCommit<D, E> resident in HBM.
+//
+// commit (lcpc-2d/src/lib.rs:622-671), merkleize (690-704), check_comm (673-688), open_column (788-825) and
+// collapse_columns (1095-1123) of /root/reference.  Many commitments may be live under one encoder context
+// (lib.rs:299-311 borrow `&E`); each object owns its comm / coeffs / hashes and its scratch.
+#include "internal.h"
+
+using namespace lcpc;
+
+namespace lcpc {
+
+int ensure_scratch(lcpc_commit_t* m, uint64_t bytes) { return ensure_dev(&m->err, &m->d_scratch, &m->scratch_cap, bytes); }
+
+int ensure_cvs(lcpc_commit_t* m, uint64_t n_chunks) {
+  uint64_t cap_b = m->cap_cvs * 32;
+  int rc = ensure_dev(&m->err, &m->d_cvs, &cap_b, n_chunks * m->enc->n_cols * 32);
+  m->cap_cvs = rc ? 0 : cap_b / 32;
+  return rc;
+}
+
+// comm (unless the commitment will live position-major in ws.d_t), coeffs (unless borrowed), hashes
+int ensure_commit_buffers(lcpc_commit_t* m, uint64_t n_rows_local, bool own_coeffs) {
+  const lcpc_ctx* c = m->enc;
+  const size_t eb = elem_bytes(c);
+  const uint64_t rows = n_rows_local ? n_rows_local : 1;
+  int rc;
+  if (own_coeffs && (rows > m->cap_coeff_rows || !m->d_coeffs)) {
+    dev_free(m->d_coeffs); m->d_coeffs = nullptr; m->cap_coeff_rows = 0;
+    if ((rc = dev_alloc(&m->err, &m->d_coeffs, (size_t)rows * c->n_per_row * eb))) return rc;
+    m->cap_coeff_rows = rows;
+  }
+  const bool need_comm = !(c->prm.encoding == LCPC_ENC_SDIG && n_rows_local >= 16);   // else made on demand (lcpc_get_comm)
+  if (need_comm && (rows > m->cap_comm_rows || !m->d_comm)) {
+    dev_free(m->d_comm); m->d_comm = nullptr; m->cap_comm_rows = 0;
+    if ((rc = dev_alloc(&m->err, &m->d_comm, (size_t)rows * c->n_cols * eb))) return rc;
+    m->cap_comm_rows = rows;
+  }
+  if (!m->d_hashes && (rc = dev_alloc(&m->err, &m->d_hashes, (size_t)(2 * c->np2 - 1) * 32))) return rc;
+  return 0;
+}
+
+static LeafArgs leaf_args(const lcpc_commit_t* m) {
+  const lcpc_ctx* c = m->enc;
+  LeafArgs la{};
+  la.comm = m->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.col_stride = 1; la.n_cols = c->n_cols;
+  if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = 0; la.row_stride = 1; la.col_stride = m->n_rows_local; }
+  la.n_rows_total = m->n_rows;
+  return la;
+}
+
+int merkle_top(lcpc_commit_t* m, hipStream_t st) {
+  const lcpc_ctx* c = m->enc;
+  if (c->np2 > c->n_cols)   // hashes[n_cols..np2) stay zero (lib.rs:656-666)
+    HIPCHK(m, hipMemsetAsync(m->d_hashes + c->n_cols * 8, 0, (size_t)(c->np2 - c->n_cols) * 32, st));
+  if (c->np2 > 1) {
+    HIPCHK(m, launch_merkle_tree(m->d_hashes, c->np2, st));
+    m->launches[2]++;
+  }
+  return 0;
+}
+
+// hash_columns + merkle_tree on the local comm (unsharded) -- lib.rs:690-704
+static int merkleize_device(lcpc_commit_t* m, hipStream_t st) {
+  const lcpc_ctx* c = m->enc;
+  const uint64_t n_chunks = leaf_chunks(c, m->n_rows);
+  LeafArgs la = leaf_args(m);
+  la.row_base = 0; la.chunk_begin = 0; la.n_chunks_local = (uint32_t)n_chunks; la.n_chunks_total = (uint32_t)n_chunks;
+  if (n_chunks == 1) {
+    la.out = m->d_hashes;
+    HIPCHK(m, launch_leaf_chunks(c->NL, la, st));
+    m->launches[1]++;
+  } else {
+    int rc = ensure_cvs(m, n_chunks);
+    if (rc) return rc;
+    la.out = m->d_cvs;
+    HIPCHK(m, launch_leaf_chunks(c->NL, la, st));
+    HIPCHK(m, launch_leaf_finish(m->d_cvs, (uint32_t)n_chunks, c->n_cols, m->d_hashes, st));
+    m->launches[1] += 2;
+  }
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], st));
+  return merkle_top(m, st);
+}
+
+int finish_timing(lcpc_commit_t* m, hipStream_t st) {
+  if (!m->timing) return 0;
+  HIPCHK(m, hipEventRecord(m->ev[3], st));
+  HIPCHK(m, hipEventSynchronize(m->ev[3]));
+  (void)hipEventElapsedTime(&m->last.encode_ms, m->ev[0], m->ev[1]);
+  (void)hipEventElapsedTime(&m->last.hash_ms, m->ev[1], m->ev[2]);
+  (void)hipEventElapsedTime(&m->last.merkle_ms, m->ev[2], m->ev[3]);
+  (void)hipEventElapsedTime(&m->last.total_ms, m->ev[0], m->ev[3]);
+  m->last.encode_launches = m->launches[0];
+  m->last.hash_launches = m->launches[1];
+  m->last.merkle_launches = m->launches[2];
+  return 0;
+}
+
+// a new commit starts: whatever the object held is gone, and stays gone if anything below fails
+static void begin_commit(lcpc_commit_t* m, uint64_t n_rows_total, uint64_t row_begin, uint64_t n_rows_local) {
+  m->committed = false;
+  m->comm_t = false;
+  m->comm_rows_valid = false;
+  m->coeffs_view = nullptr;
+  m->n_rows = n_rows_total; m->row_begin = row_begin; m->n_rows_local = n_rows_local;
+  m->launches[0] = m->launches[1] = m->launches[2] = 0;
+}
+
+// encode the local rows of `src` (row-major, n_per_row per row; flat elements >= n_src_total read as zero) into the
+// commitment matrix; copy_coeffs: write the padded LcCommit.coeffs copy while the source streams through
+static int encode_commit(lcpc_commit_t* m, const uint32_t* src, uint64_t n_src_total, bool copy_coeffs, hipStream_t st) {
+  const lcpc_ctx* c = m->enc;
+  EncodeJob j;
+  j.src = src; j.src_stride = c->n_per_row; j.n_valid = c->n_per_row; j.dst = m->d_comm; j.n_rows = m->n_rows_local;
+  j.n_src_total = n_src_total;
+  j.copy_dst = copy_coeffs ? m->d_coeffs : nullptr;
+  j.canon_out = c->comm_canon;
+  j.keep_t = true;
+  bool kept = false;
+  j.kept_t = &kept;
+  int rc = encode_rows_device(c, &m->ws, j, st, &m->err, &m->launches[0]);
+  if (rc) return rc;
+  m->comm_t = kept;
+  return 0;
+}
+
+// can the first encode pass write the coeffs copy on the fly?  (Ligero: fused into the first NTT pass; Brakedown with
+// >= 16 rows: fused into the input transpose)
+static bool fused_copy(const lcpc_ctx* c, uint64_t n_rows_local) { return c->prm.encoding == LCPC_ENC_LIGERO || n_rows_local >= 16; }
+
+static int commit_tail(lcpc_commit_t* m, hipStream_t st, uint8_t* root) {
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[1], st));
+  int rc;
+  if ((rc = merkleize_device(m, st))) return rc;
+  if ((rc = finish_timing(m, st))) return rc;
+  m->committed = true;
+  if (root) {
+    HIPCHK(m, hipMemcpyAsync(root, m->d_hashes + (2 * m->enc->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(m, hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
+static uint32_t collapse_splits(const lcpc_commit_t* m) {
+  const uint64_t col_blocks = (m->enc->n_per_row + 255) / 256;
+  uint32_t n_splits = 1;   // split the row range so that the grid has >= ~2k workgroups even for narrow matrices
+  while (n_splits < 64 && col_blocks * n_splits < 2048 && m->n_rows_local / (n_splits * 2) >= 16) n_splits *= 2;
+  return n_splits;
+}
+size_t collapse_scratch_bytes(const lcpc_commit_t* m, uint32_t n_tensors) {
+  return (size_t)collapse_splits(m) * n_tensors * m->enc->n_per_row * elem_bytes(m->enc);
+}
+static int collapse_local(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_out) {
+  const lcpc_ctx* c = m->enc;
+  const uint32_t n_splits = collapse_splits(m);
+  CollapseArgs a{};
+  a.coeffs = m->coeffs_view; a.tensors = d_tensors; a.n_rows = m->n_rows_local; a.n_per_row = c->n_per_row;
+  a.n_tensors = n_tensors; a.n_splits = n_splits;
+  if (c->NL == 8) {
+    const uint64_t ne = (uint64_t)n_tensors * m->n_rows_local;
+    int rc = ensure_dev(&m->err, &m->d_t29, &m->t29_cap, ne * 48);
+    if (rc) return rc;
+    HIPCHK(m, launch_to_r29(d_tensors, ne, m->d_t29, st));
+    a.tensors29 = m->d_t29;
+  }
+  if (n_splits == 1) {
+    a.out = d_out;
+    HIPCHK(m, launch_collapse(c->NL, a, st));
+    return 0;
+  }
+  const size_t part_bytes = (size_t)n_splits * n_tensors * c->n_per_row * elem_bytes(c);
+  // partials live at the end of scratch (callers reserve it; scratch_cap is a multiple of 256, part_bytes of 16)
+  uint32_t* d_part = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(m->d_scratch) + m->scratch_cap - ((part_bytes + 255) & ~(size_t)255));
+  a.out = d_part;
+  HIPCHK(m, launch_collapse(c->NL, a, st));
+  HIPCHK(m, launch_field_sum(c->NL, d_part, n_splits, (uint64_t)n_tensors * c->n_per_row, d_out, st));
+  return 0;
+}
+// scratch layout for collapse: [tensors (host entry only)] [polys (host entry only)] ... [partials at the end]
+int collapse_run(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_polys) {
+  const lcpc_ctx* c = m->enc;
+  for (uint32_t t = 0; t < n_tensors; t += 2) {
+    const uint32_t nt = (n_tensors - t) >= 2 ? 2 : 1;
+    int rc = collapse_local(m, d_tensors + (size_t)t * m->n_rows_local * c->NL, nt, st, d_polys + (size_t)t * c->n_per_row * c->NL);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int open_columns_device(lcpc_commit_t* m, const uint64_t* d_cols, uint32_t n, uint32_t* d_vals, uint32_t* d_paths, hipStream_t st) {
+  const lcpc_ctx* c = m->enc;
+  if (d_vals && m->n_rows_local) {
+    if (m->comm_t)
+      HIPCHK(m, launch_gather_columns(c->NL, m->ws.d_t, m->n_rows_local, 1, m->n_rows_local, d_cols, n, d_vals, nullptr, st));
+    else
+      HIPCHK(m, launch_gather_columns(c->NL, m->d_comm, m->n_rows_local, c->n_cols, 1, d_cols, n, d_vals, c->comm_canon ? c->d_r2 : nullptr, st));
+  }
+  if (d_paths && c->path_len) HIPCHK(m, launch_gather_paths(m->d_hashes, c->np2, c->path_len, d_cols, n, d_paths, st));
+  return 0;
+}
+
+}  // namespace lcpc
+
+// =====================================================================================================
+// C ABI: LcCommit
+// =====================================================================================================
+extern "C" {
+
+int lcpc_commit_create(lcpc_ctx* enc, lcpc_commit_t** out) {
+  if (!enc || !out) return LCPC_ERR_ARG;
+  *out = nullptr;
+  lcpc_commit_t* m = new (std::nothrow) lcpc_commit_t();
+  if (!m) return LCPC_ERR_NOMEM;
+  m->enc = enc;
+  ctx_ref(enc);
+  if (hipSetDevice(enc->prm.device) != hipSuccess) { lcpc_commit_destroy(m); return LCPC_ERR_NO_DEVICE; }
+  for (auto& e : m->ev)
+    if (hipEventCreate(&e) != hipSuccess) { lcpc_commit_destroy(m); return LCPC_ERR_HIP; }
+  *out = m;
+  return 0;
+}
+
+void lcpc_commit_destroy(lcpc_commit_t* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->enc->prm.device);
+  dev_free(m->d_coeffs); dev_free(m->d_comm); dev_free(m->d_hashes); dev_free(m->d_cvs); dev_free(m->d_scratch); dev_free(m->d_node_tab);
+  dev_free(m->d_t29); dev_free(m->ws.d_tmp); dev_free(m->ws.d_t); dev_free(m->d_gather); dev_free(m->d_xsend); dev_free(m->d_xrecv);
+  for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : m->ev_batch) if (e) (void)hipEventDestroy(e);
+  if (m->s_copy) (void)hipStreamDestroy(m->s_copy);
+  if (m->s_comp) (void)hipStreamDestroy(m->s_comp);
+  ctx_unref(m->enc);
+  delete m;
+}
+const char* lcpc_commit_last_error(const lcpc_commit_t* m) { return m ? m->err.c_str() : ""; }
+
+int lcpc_commit_device(lcpc_commit_t* m, const uint64_t* coeffs_dev, uint64_t n_coeffs, void* stream, uint32_t flags, uint8_t* root) {
+  if (!m || !coeffs_dev || n_coeffs == 0) return LCPC_ERR_ARG;
+  const lcpc_ctx* c = m->enc;
+  if (c->prm.shard_count > 1) return LCPC_ERR_STATE;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t n_rows = (n_coeffs + c->n_per_row - 1) / c->n_per_row;    // get_dims (ligero lib.rs:166-169)
+  begin_commit(m, n_rows, 0, n_rows);
+  const uint64_t padded = n_rows * c->n_per_row;
+  const bool borrow = (flags & LCPC_COMMIT_BORROW_COEFFS) && padded == n_coeffs;
+  int rc = ensure_commit_buffers(m, n_rows, !borrow);
+  if (rc) return rc;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(coeffs_dev);
+  const size_t eb = elem_bytes(c);
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[0], st));
+  if (borrow) {
+    // LcCommit.coeffs IS the caller's buffer: nothing but comm and the digests is written
+    if ((rc = encode_commit(m, src, n_coeffs, false, st))) return rc;
+    m->coeffs_view = src;
+  } else if (fused_copy(c, n_rows)) {
+    // the padded local copy of coeffs (lib.rs:636-645; LcCommit keeps it for prove) is written by the first
+    // NTT pass (Ligero) / the input transpose (Brakedown, >= 16 rows) while it streams the caller's buffer
+    if ((rc = encode_commit(m, src, n_coeffs, true, st))) return rc;
+    m->coeffs_view = m->d_coeffs;
+  } else {
+    HIPCHK(m, hipMemcpyAsync(m->d_coeffs, coeffs_dev, (size_t)n_coeffs * eb, hipMemcpyDeviceToDevice, st));
+    if (padded > n_coeffs)
+      HIPCHK(m, hipMemsetAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + (size_t)n_coeffs * eb, 0, (size_t)(padded - n_coeffs) * eb, st));
+    if ((rc = encode_commit(m, m->d_coeffs, ~(uint64_t)0, false, st))) return rc;
+    m->coeffs_view = m->d_coeffs;
+  }
+  return commit_tail(m, st, root);
+  LCPC_CATCH(m)
+}
+
+int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uint8_t* root) {
+  if (!m || !coeffs || n_coeffs == 0) return LCPC_ERR_ARG;
+  const lcpc_ctx* c = m->enc;
+  if (c->prm.shard_count > 1) return LCPC_ERR_STATE;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  const uint64_t n_rows = (n_coeffs + c->n_per_row - 1) / c->n_per_row;
+  begin_commit(m, n_rows, 0, n_rows);
+  int rc = ensure_commit_buffers(m, n_rows, true);
+  if (rc) return rc;
+  const size_t eb = elem_bytes(c);
+  const uint64_t padded = n_rows * c->n_per_row;
+  const size_t total_bytes = (size_t)n_coeffs * eb;
+  // Small inputs, Brakedown (whole-matrix transposes) and timing runs: one copy, then the resident path.
+  if (c->prm.encoding != LCPC_ENC_LIGERO || total_bytes < ((size_t)64 << 20) || n_rows < 16 || m->timing) {
+    HIPCHK(m, hipMemcpyAsync(m->d_coeffs, coeffs, total_bytes, hipMemcpyHostToDevice, nullptr));
+    if (padded > n_coeffs)
+      HIPCHK(m, hipMemsetAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + total_bytes, 0, (size_t)(padded - n_coeffs) * eb, nullptr));
+    if (m->timing) HIPCHK(m, hipEventRecord(m->ev[0], nullptr));
+    if ((rc = encode_commit(m, m->d_coeffs, ~(uint64_t)0, false, nullptr))) return rc;
+    m->coeffs_view = m->d_coeffs;
+    if ((rc = commit_tail(m, nullptr, root))) return rc;
+    HIPCHK(m, hipStreamSynchronize(nullptr));     // the caller's (possibly pageable) buffer is no longer in use on return
+    return 0;
+  }
+  // Large Ligero commit from host memory: rows are independent (lcpc-2d lib.rs:648-653), so the matrix is
+  // uploaded in row batches on a copy stream while the previous batch runs its NTT passes on a compute stream;
+  // column hashing starts once the last batch is encoded.  The end-to-end time tends to the PCIe time.
+  if (!m->s_copy) HIPCHK(m, hipStreamCreateWithFlags(&m->s_copy, hipStreamNonBlocking));
+  if (!m->s_comp) HIPCHK(m, hipStreamCreateWithFlags(&m->s_comp, hipStreamNonBlocking));
+  constexpr int NB = 16;
+  for (auto& e : m->ev_batch)
+    if (!e) HIPCHK(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(m, hipDeviceSynchronize());                       // earlier work on this object's buffers (null stream) is done
+  if (padded > n_coeffs)
+    HIPCHK(m, hipMemsetAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + total_bytes, 0, (size_t)(padded - n_coeffs) * eb, m->s_copy));
+  const uint64_t rows_per = (n_rows + NB - 1) / NB;
+  for (int b = 0; b < NB; b++) {
+    const uint64_t r0 = (uint64_t)b * rows_per;
+    if (r0 >= n_rows) break;
+    const uint64_t r1 = r0 + rows_per < n_rows ? r0 + rows_per : n_rows;
+    const uint64_t e0 = r0 * c->n_per_row, e1 = r1 * c->n_per_row < n_coeffs ? r1 * c->n_per_row : n_coeffs;
+    if (e1 > e0)
+      HIPCHK(m, hipMemcpyAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + (size_t)e0 * eb, reinterpret_cast<const uint8_t*>(coeffs) + (size_t)e0 * eb,
+                               (size_t)(e1 - e0) * eb, hipMemcpyHostToDevice, m->s_copy));
+    HIPCHK(m, hipEventRecord(m->ev_batch[b], m->s_copy));
+    HIPCHK(m, hipStreamWaitEvent(m->s_comp, m->ev_batch[b], 0));
+    EncodeJob j;
+    j.src = m->d_coeffs + (size_t)r0 * c->n_per_row * c->NL; j.src_stride = c->n_per_row; j.n_valid = c->n_per_row;
+    j.dst = m->d_comm + (size_t)r0 * c->n_cols * c->NL; j.n_rows = r1 - r0; j.canon_out = c->comm_canon;
+    if ((rc = encode_rows_device(c, &m->ws, j, m->s_comp, &m->err, &m->launches[0]))) return rc;
+  }
+  m->coeffs_view = m->d_coeffs;
+  if ((rc = merkleize_device(m, m->s_comp))) return rc;
+  if (root) HIPCHK(m, hipMemcpyAsync(root, m->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, m->s_comp));
+  HIPCHK(m, hipStreamSynchronize(m->s_comp));              // later calls use the null stream / caller streams
+  m->committed = true;
+  return 0;
+  LCPC_CATCH(m)
+}
+
+int lcpc_commit_from_parts(lcpc_commit_t* m, const uint64_t* comm, const uint64_t* coeffs, uint64_t n_rows, uint8_t* root) {
+  if (!m || !comm || n_rows == 0) return LCPC_ERR_ARG;
+  const lcpc_ctx* c = m->enc;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  begin_commit(m, n_rows, 0, n_rows);
+  const size_t eb = elem_bytes(c);
+  int rc = ensure_commit_buffers(m, n_rows, true);
+  if (rc) return rc;
+  if (!m->d_comm || m->cap_comm_rows < n_rows) {           // (Brakedown >= 16 rows: ensure_commit_buffers leaves comm for later)
+    dev_free(m->d_comm); m->d_comm = nullptr; m->cap_comm_rows = 0;
+    if ((rc = dev_alloc(&m->err, &m->d_comm, (size_t)n_rows * c->n_cols * eb))) return rc;
+    m->cap_comm_rows = n_rows;
+  }
+  HIPCHK(m, hipMemcpy(m->d_comm, comm, (size_t)n_rows * c->n_cols * eb, hipMemcpyHostToDevice));
+  if (c->comm_canon) HIPCHK(m, launch_to_canon(c->NL, m->d_comm, n_rows * c->n_cols, m->d_comm, nullptr));
+  if (coeffs) HIPCHK(m, hipMemcpy(m->d_coeffs, coeffs, (size_t)n_rows * c->n_per_row * eb, hipMemcpyHostToDevice));
+  else HIPCHK(m, hipMemset(m->d_coeffs, 0, (size_t)n_rows * c->n_per_row * eb));
+  m->coeffs_view = m->d_coeffs;
+  if (m->timing) { HIPCHK(m, hipEventRecord(m->ev[0], nullptr)); }
+  return commit_tail(m, nullptr, root);
+  LCPC_CATCH(m)
+}
+
+int lcpc_get_root(lcpc_commit_t* m, uint8_t root[32]) {
+  if (!m || !root) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  HIPCHK(m, hipMemcpy(root, m->d_hashes + (2 * m->enc->np2 - 2) * 8, 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+int lcpc_commit_dims(const lcpc_commit_t* m, uint64_t* nr, uint64_t* np, uint64_t* nc, uint64_t* nh) {
+  if (!m) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  if (nr) *nr = m->n_rows;
+  if (np) *np = m->enc->n_per_row;
+  if (nc) *nc = m->enc->n_cols;
+  if (nh) *nh = 2 * m->enc->np2 - 1;
+  return 0;
+}
+int lcpc_get_hashes(lcpc_commit_t* m, uint8_t* hashes) {
+  if (!m || !hashes) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  HIPCHK(m, hipMemcpy(hashes, m->d_hashes, (size_t)(2 * m->enc->np2 - 1) * 32, hipMemcpyDeviceToHost));
+  return 0;
+}
+int lcpc_get_comm(lcpc_commit_t* m, uint64_t row0, uint64_t n, uint64_t* out) {
+  if (!m || !out) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  if (row0 < m->row_begin || row0 + n > m->row_begin + m->n_rows_local) return LCPC_ERR_ARG;
+  const lcpc_ctx* c = m->enc;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  if (m->comm_t && !m->comm_rows_valid) {      // Brakedown: the commitment is position-major; make the row-major view once
+    if (!m->d_comm || m->cap_comm_rows < m->n_rows_local) {
+      dev_free(m->d_comm); m->d_comm = nullptr; m->cap_comm_rows = 0;
+      int rc = dev_alloc(&m->err, &m->d_comm, (size_t)m->n_rows_local * c->n_cols * eb);
+      if (rc) return rc;
+      m->cap_comm_rows = m->n_rows_local;
+    }
+    HIPCHK(m, launch_transpose_from_t(c->NL, m->ws.d_t, c->n_cols, m->n_rows_local, m->d_comm, c->n_cols, nullptr));
+    HIPCHK(m, hipStreamSynchronize(nullptr));
+    m->comm_rows_valid = true;
+  }
+  const uint32_t* src = m->d_comm + (size_t)(row0 - m->row_begin) * c->n_cols * c->NL;
+  if (!c->comm_canon || m->comm_t) {
+    HIPCHK(m, hipMemcpy(out, src, (size_t)n * c->n_cols * eb, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  // canonical on the device, Montgomery form (as ff_derive stores elements) at the ABI: convert a row batch at a time
+  const uint64_t batch = std::max<uint64_t>(1, ((uint64_t)64 << 20) / (c->n_cols * eb));
+  uint32_t* tmp = nullptr;
+  int rc = dev_alloc(&m->err, &tmp, (size_t)std::min(batch, n ? n : 1) * c->n_cols * eb);
+  if (rc) return rc;
+  for (uint64_t r = 0; r < n; r += batch) {
+    const uint64_t nb = std::min(batch, n - r);
+    hipError_t he = launch_to_mont(c->NL, src + (size_t)r * c->n_cols * c->NL, nb * c->n_cols, c->d_r2, tmp, nullptr);
+    if (he == hipSuccess)
+      he = hipMemcpy(reinterpret_cast<uint8_t*>(out) + (size_t)r * c->n_cols * eb, tmp, (size_t)nb * c->n_cols * eb, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) { dev_free(tmp); return fail_hip(&m->err, he, "lcpc_get_comm"); }
+  }
+  dev_free(tmp);
+  return 0;
+  LCPC_CATCH(m)
+}
+int lcpc_get_coeffs(lcpc_commit_t* m, uint64_t row0, uint64_t n, uint64_t* out) {
+  if (!m || !out) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  if (row0 < m->row_begin || row0 + n > m->row_begin + m->n_rows_local) return LCPC_ERR_ARG;
+  const lcpc_ctx* c = m->enc;
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  HIPCHK(m, hipMemcpy(out, reinterpret_cast<const uint8_t*>(m->coeffs_view) + (size_t)(row0 - m->row_begin) * c->n_per_row * eb,
+                      (size_t)n * c->n_per_row * eb, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- collapse / open ---------------------------------------------------------------------------------
+int lcpc_collapse_device(lcpc_commit_t* m, const uint64_t* tensors_dev, uint32_t n_tensors, void* stream, uint64_t* polys_dev) {
+  if (!m || !tensors_dev || !polys_dev || n_tensors == 0) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  int rc = ensure_scratch(m, collapse_scratch_bytes(m, 2) + 256);
+  if (rc) return rc;
+  return collapse_run(m, reinterpret_cast<const uint32_t*>(tensors_dev), n_tensors, (hipStream_t)stream,
+                      reinterpret_cast<uint32_t*>(polys_dev));
+  LCPC_CATCH(m)
+}
+
+int lcpc_collapse(lcpc_commit_t* m, const uint64_t* tensors, uint32_t n_tensors, uint64_t* polys) {
+  if (!m || !tensors || !polys || n_tensors == 0) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  const lcpc_ctx* c = m->enc;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  const size_t tb = ((size_t)n_tensors * m->n_rows_local * eb + 255) & ~(size_t)255;
+  const size_t pb = ((size_t)n_tensors * c->n_per_row * eb + 255) & ~(size_t)255;
+  int rc = ensure_scratch(m, tb + pb + collapse_scratch_bytes(m, 2) + 512);
+  if (rc) return rc;
+  uint8_t* base = reinterpret_cast<uint8_t*>(m->d_scratch);
+  uint32_t* d_t = reinterpret_cast<uint32_t*>(base);
+  uint32_t* d_p = reinterpret_cast<uint32_t*>(base + tb);
+  HIPCHK(m, hipMemcpyAsync(d_t, tensors, (size_t)n_tensors * m->n_rows_local * eb, hipMemcpyHostToDevice, nullptr));
+  if ((rc = collapse_run(m, d_t, n_tensors, nullptr, d_p))) return rc;
+  HIPCHK(m, hipMemcpy(polys, d_p, (size_t)n_tensors * c->n_per_row * eb, hipMemcpyDeviceToHost));
+  return 0;
+  LCPC_CATCH(m)
+}
+
+int lcpc_open_columns(lcpc_commit_t* m, const uint64_t* cols, uint32_t n, uint64_t* col_vals, uint8_t* paths) {
+  if (!m || !cols || (!col_vals && !paths)) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  const lcpc_ctx* c = m->enc;
+  for (uint32_t i = 0; i < n; i++)
+    if (cols[i] >= c->n_cols) return LCPC_ERR_COLUMN_NUMBER;        // lib.rs:797-799
+  if (n == 0) return 0;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  const size_t vb = (((size_t)n * m->n_rows_local * eb) + 255) & ~(size_t)255, pb = (((size_t)n * c->path_len * 32) + 255) & ~(size_t)255;
+  const size_t cb = (((size_t)n * 8) + 255) & ~(size_t)255;
+  int rc = ensure_scratch(m, vb + pb + cb);
+  if (rc) return rc;
+  uint8_t* base = reinterpret_cast<uint8_t*>(m->d_scratch);
+  uint64_t* d_cols = reinterpret_cast<uint64_t*>(base);
+  uint32_t* d_vals = reinterpret_cast<uint32_t*>(base + cb);
+  uint32_t* d_paths = reinterpret_cast<uint32_t*>(base + cb + vb);
+  HIPCHK(m, hipMemcpyAsync(d_cols, cols, (size_t)n * 8, hipMemcpyHostToDevice, nullptr));
+  if ((rc = open_columns_device(m, d_cols, n, col_vals ? d_vals : nullptr, paths ? d_paths : nullptr, nullptr))) return rc;
+  if (col_vals && m->n_rows_local) HIPCHK(m, hipMemcpyAsync(col_vals, d_vals, (size_t)n * m->n_rows_local * eb, hipMemcpyDeviceToHost, nullptr));
+  if (paths && c->path_len) HIPCHK(m, hipMemcpyAsync(paths, d_paths, (size_t)n * c->path_len * 32, hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(m, hipStreamSynchronize(nullptr));
+  return 0;
+  LCPC_CATCH(m)
+}
+
+int lcpc_set_timing(lcpc_commit_t* m, int enable) { if (!m) return LCPC_ERR_ARG; m->timing = enable != 0; return 0; }
+int lcpc_get_timings(lcpc_commit_t* m, lcpc_timings* out) { if (!m || !out) return LCPC_ERR_ARG; *out = m->last; return 0; }
+
+}  // extern "C"

@@ -1,0 +1,508 @@
+// lcpc_amd/csrc/ctx.cpp -- lcpc_ctx: the two LcEncoding implementors on the device.
+//
+// LigeroEncodingRho::{new, new_from_dims, encode, get_dims, dims_ok, ...} (lcpc-ligero-pc/src/lib.rs:45-185) and
+// SdigEncodingS::{new, new_from_dims, encode, ...} (lcpc-brakedown-pc/src/lib.rs:54-176, encode.rs:36-110) of
+// /root/reference.  A context is immutable after creation (the reference shares `&E` across Rayon workers,
+// lcpc-2d/src/lib.rs:74-104); commitments made with it live in their own objects (commit.cpp).
+// There is no CPU fallback: without a usable HIP device lcpc_ctx_create fails with LCPC_ERR_NO_DEVICE.
+#include "internal.h"
+
+using namespace lcpc;
+
+namespace lcpc {
+
+const uint8_t LBL_DT[7] = "$l//DT", LBL_PR[7] = "$l//PR", LBL_PE[7] = "$l//PE", LBL_CO[7] = "$l//CO";  // macros.rs:31-34
+
+void to_r29(const FieldDesc& f, const uint64_t* in4, uint32_t* out12) {
+  uint64_t t[4];
+  memcpy(t, in4, 32);
+  for (int d = 0; d < 5; d++) h_add(f, t, t, t);
+  for (int k = 0; k < 9; k++) {
+    const int b = 29 * k, w = b / 64, sh = b % 64;
+    uint64_t x = t[w] >> sh;
+    if (sh > 35 && w + 1 < 4) x |= t[w + 1] << (64 - sh);
+    out12[k] = (uint32_t)(x & ((1u << 29) - 1));
+  }
+  out12[9] = out12[10] = out12[11] = 0;
+}
+
+// a container can show 256 hardware threads and be granted 16 CPUs of time; more threads than that only get throttled
+unsigned usable_cores() {
+  static const unsigned cached = [] {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    long long q = -1, per = 100000;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                         // cgroup v2: "<quota|max> <period>"
+      char qs[32] = {0};
+      if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0) q = atoll(qs);
+      fclose(f);
+    } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {      // cgroup v1
+      if (fscanf(f1, "%lld", &q) != 1) q = -1;
+      fclose(f1);
+      if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 100000; fclose(f2); }
+    }
+    if (q > 0 && per > 0) { const unsigned lim = (unsigned)std::max<long long>(1, q / per); if (lim < n) n = lim; }
+    return n;
+  }();
+  return cached;
+}
+
+void ctx_ref(lcpc_ctx* c) { c->refs.fetch_add(1); }
+
+static void ctx_free(lcpc_ctx* c) {
+  (void)hipSetDevice(c->prm.device);
+  comm_release(c);
+  dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
+  dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->d_scratch);
+  for (auto* v : {&c->d_pre, &c->d_post})
+    for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); dev_free(d.vals29); }
+  delete c;
+}
+void ctx_unref(lcpc_ctx* c) {
+  if (c->refs.fetch_sub(1) == 1) ctx_free(c);
+}
+
+// ---- NTT pass plan (DESIGN.md "K1") ----------------------------------------------------------------
+static void plan_passes(lcpc_ctx* c) {
+  const unsigned k = c->log_n;
+  const int NL = c->NL;
+  const int lt_small = NL >= 6 ? 10 : (NL == 4 ? 11 : 12);      // 32 KiB (24 KiB for NL=6) tiles
+  const int lt_big = NL >= 6 ? 11 : 12;
+  unsigned ltj_min = 0;                                          // >= 128 B contiguous runs in strided passes
+  while (((size_t)NL * 4 << ltj_min) < 128) ltj_min++;
+  c->passes.clear();
+  if ((int)k <= lt_small) {
+    c->passes.push_back({0, k, 0, lt_small});
+    return;
+  }
+  int LT = lt_small;
+  auto n_pass = [&](int lt) { unsigned per = lt - ltj_min, rest = k - lt; return 1 + (rest + per - 1) / per; };
+  if (n_pass(lt_small) > 2 && n_pass(lt_big) < n_pass(lt_small)) LT = lt_big;
+  const unsigned P = n_pass(LT);
+  const unsigned s_final = LT;
+  unsigned rem = k - s_final, t0 = 0;
+  for (unsigned i = 0; i + 1 < P; i++) {
+    const unsigned left = P - 1 - i;
+    const unsigned s = (rem + left - 1) / left;
+    c->passes.push_back({t0, s, (uint32_t)LT - s, LT});
+    t0 += s;
+    rem -= s;
+  }
+  c->passes.push_back({t0, s_final, 0u, LT});
+}
+
+#define ECHK(call)                                                        \
+  do {                                                                    \
+    hipError_t e__ = (call);                                              \
+    if (e__ != hipSuccess) return fail_hip(err, e__, #call);              \
+  } while (0)
+
+// ---- encode rows: LcEncoding::encode, batched over rows -----------------------------------------------
+int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipStream_t st, std::string* err, uint32_t* launches) {
+  uint32_t dummy = 0;
+  uint32_t& nl = launches ? *launches : dummy;
+  if (j.kept_t) *j.kept_t = false;
+  const uint64_t n_rows = j.n_rows;
+  if (n_rows == 0) return 0;
+  if (c->prm.encoding == LCPC_ENC_LIGERO) {
+    bool first = true;
+    for (const Pass& p : c->passes) {
+      NttPassArgs a;
+      a.roots29c = j.canon_out ? c->d_roots29c : nullptr;
+      // the trailing stages multiply by 1 only: a final radix-4 round leaves 4 elements per row unconverted, a final
+      // radix-2 stage 2 (ntt_pass_l9_kernel)
+      a.mont_prefix = (j.canon_out && p.t0 + p.s == c->log_n) ? (c->log_n == 0 ? 1u : (p.s % 2 == 0 ? 4u : 2u)) : 0u;
+      a.src = first ? j.src : j.dst;
+      a.dst = j.dst;
+      a.roots = c->d_roots;
+      a.roots29 = c->d_roots29;
+      a.qp29 = c->d_qp29;
+      a.src_stride = first ? j.src_stride : c->n_cols;
+      a.dst_stride = c->n_cols;
+      a.n_valid = first ? j.n_valid : c->n_cols;
+      a.n_src_total = first ? j.n_src_total : ~(uint64_t)0;
+      a.copy_dst = first ? j.copy_dst : nullptr;
+      a.n_rows = n_rows;
+      a.log_n = c->log_n; a.t0 = p.t0; a.s = p.s; a.log_tj = p.log_tj;
+      ECHK(launch_ntt_pass(c->NL, p.log_tile, a, st));
+      nl++;
+      first = false;
+    }
+    return 0;
+  }
+  // Brakedown: systematic part, then precodes down, R-S base case, postcodes up (encode.rs:36-94)
+  const size_t t = c->d_pre.size();
+  const DevCsr& pl = c->d_pre[t - 1];
+  const size_t eb = elem_bytes(c);
+  {
+    uint64_t cap_b = ws->tmp_cap * eb;
+    int rc = ensure_dev(err, &ws->d_tmp, &cap_b, n_rows * pl.n_out * eb);
+    if (rc) { ws->tmp_cap = 0; return rc; }
+    ws->tmp_cap = cap_b / eb;
+  }
+  if (n_rows >= 16) {
+    // fast path: position-major working copy T[pos][row] (lane = row: contiguous gathers, wave-uniform matrix)
+    {
+      uint64_t cap_b = ws->t_cap * eb;
+      int rc = ensure_dev(err, &ws->d_t, &cap_b, n_rows * c->n_cols * eb);
+      if (rc) { ws->t_cap = 0; return rc; }
+      ws->t_cap = cap_b / eb;
+    }
+    ECHK(launch_transpose_to_t(c->NL, j.src, j.src_stride, j.n_valid, n_rows, ws->d_t, st, j.n_src_total, j.copy_dst));
+    nl++;
+    uint64_t in_start = 0;
+    SpmmTArgs a{};
+    a.t = ws->d_t; a.n_rows = n_rows;
+    auto set_mat = [&](const DevCsr& m) { a.rowptr = m.rowptr; a.colidx = m.colidx; a.vals = m.vals; a.vals29 = m.vals29; a.m = m.n_out; };
+    for (size_t i = 0; i + 1 < t; i++) {
+      const uint64_t in_end = in_start + c->d_pre[i].n_in;
+      a.out_alt = nullptr; a.in_off = in_start; a.out_off = in_end;
+      set_mat(c->d_pre[i]);
+      ECHK(launch_spmm_t(c->NL, a, st));
+      nl++;
+      in_start = in_end;
+    }
+    const uint64_t in_end = in_start + pl.n_in;
+    a.out_alt = ws->d_tmp; a.in_off = in_start; a.out_off = 0;
+    set_mat(pl);
+    ECHK(launch_spmm_t(c->NL, a, st));
+    const uint64_t out_end = in_end + c->d_post[t - 1].n_in;
+    ECHK(launch_sdig_rs_t(c->NL, ws->d_tmp, (uint32_t)pl.n_out, ws->d_t, in_end, (uint32_t)c->d_post[t - 1].n_in, n_rows, c->d_r2, st));
+    nl += 2;
+    in_start = in_end + pl.n_out;
+    uint64_t out_start = out_end;
+    for (size_t ii = t; ii-- > 0;) {
+      in_start -= c->d_pre[ii].n_out;
+      a.out_alt = nullptr; a.in_off = in_start; a.out_off = out_start;
+      set_mat(c->d_post[ii]);
+      ECHK(launch_spmm_t(c->NL, a, st));
+      nl++;
+      out_start += c->d_post[ii].n_out;
+    }
+    if (j.keep_t) {               // commit: the position-major copy IS the commitment (hash_columns / open_column read it)
+      if (j.kept_t) *j.kept_t = true;
+      return 0;
+    }
+    ECHK(launch_transpose_from_t(c->NL, ws->d_t, c->n_cols, n_rows, j.dst, c->n_cols, st));
+    nl++;
+    return 0;
+  }
+  // few rows (the verifier's 1 + n_degree_tests single-row encodes): lane = output on the row-major rows
+  if (j.src != j.dst || j.src_stride != c->n_cols) {
+    ECHK(launch_pad_rows(c->NL, j.src, j.src_stride, j.dst, c->n_cols, j.n_valid, n_rows, st));
+    nl++;
+  }
+  uint64_t in_start = 0;
+  SpmvArgs a{};
+  a.mat = j.dst; a.stride = c->n_cols; a.n_rows = n_rows;
+  for (size_t i = 0; i + 1 < t; i++) {
+    const uint64_t in_end = in_start + c->d_pre[i].n_in;
+    a.out_alt = nullptr; a.in_off = in_start; a.out_off = in_end;
+    a.rowptr = c->d_pre[i].rowptr; a.colidx = c->d_pre[i].colidx; a.vals = c->d_pre[i].vals; a.m = c->d_pre[i].n_out;
+    ECHK(launch_spmv(c->NL, a, st));
+    nl++;
+    in_start = in_end;
+  }
+  const uint64_t in_end = in_start + pl.n_in;
+  a.out_alt = ws->d_tmp; a.out_alt_stride = pl.n_out; a.in_off = in_start; a.out_off = 0;
+  a.rowptr = pl.rowptr; a.colidx = pl.colidx; a.vals = pl.vals; a.m = pl.n_out;
+  ECHK(launch_spmv(c->NL, a, st));
+  const uint64_t out_end = in_end + c->d_post[t - 1].n_in;
+  ECHK(launch_sdig_rs(c->NL, ws->d_tmp, pl.n_out, (uint32_t)pl.n_out, j.dst, c->n_cols, in_end,
+                      (uint32_t)c->d_post[t - 1].n_in, n_rows, c->d_r2, st));
+  nl += 2;
+  in_start = in_end + pl.n_out;
+  uint64_t out_start = out_end;
+  for (size_t ii = t; ii-- > 0;) {
+    in_start -= c->d_pre[ii].n_out;
+    a.out_alt = nullptr; a.in_off = in_start; a.out_off = out_start;
+    a.rowptr = c->d_post[ii].rowptr; a.colidx = c->d_post[ii].colidx; a.vals = c->d_post[ii].vals; a.m = c->d_post[ii].n_out;
+    ECHK(launch_spmv(c->NL, a, st));
+    nl++;
+    out_start += c->d_post[ii].n_out;
+  }
+  return 0;
+}
+
+}  // namespace lcpc
+
+// =====================================================================================================
+// C ABI: encoder
+// =====================================================================================================
+extern "C" {
+
+int lcpc_abi_version(void) { return LCPC_ABI_VERSION; }
+
+const char* lcpc_strerror(int s) {
+  switch (s) {
+    case LCPC_OK: return "ok";
+    case LCPC_ERR_TOO_BIG: return "n_cols is too large for this encoding";
+    case LCPC_ERR_ENCODE: return "encoding error";
+    case LCPC_ERR_COMMIT: return "inconsistent commitment fields";
+    case LCPC_ERR_COLUMN_NUMBER: return "bad column number";
+    case LCPC_ERR_OUTER_TENSOR: return "outer tensor: wrong size";
+    case LCPC_ERR_DIMS: return "dimensions not valid for this encoding";
+    case LCPC_ERR_ARG: return "invalid argument";
+    case LCPC_ERR_STATE: return "no commitment in this object";
+    case LCPC_ERR_HIP: return "HIP runtime error";
+    case LCPC_ERR_NOMEM: return "out of memory";
+    case LCPC_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case LCPC_ERR_XCHG: return "all-gather of the sharded commit / prove failed";
+    case LCPC_ERR_NO_RCCL: return "librccl could not be loaded";
+    case LCPC_VERR_NUM_COL_OPENS: return "wrong number of column openings in proof";
+    case LCPC_VERR_COLUMN_PATH: return "column verification: merkle path failed";
+    case LCPC_VERR_COLUMN_EVAL: return "column verification: eval dot product failed";
+    case LCPC_VERR_COLUMN_DEGREE: return "column verification: degree test dot product failed";
+    case LCPC_VERR_OUTER_TENSOR: return "outer tensor: wrong size";
+    case LCPC_VERR_INNER_TENSOR: return "inner tensor: wrong size";
+    case LCPC_VERR_ENCODING_DIMS: return "encoding dimension mismatch";
+    case LCPC_VERR_ENCODE: return "encoding error";
+    case LCPC_VERR_MALFORMED: return "malformed proof bytes";
+  }
+  return "unknown status";
+}
+const char* lcpc_last_error(const lcpc_ctx* c) { return c ? c->err.c_str() : ""; }
+
+int lcpc_static_get_dims(const lcpc_params* p, uint64_t* nr, uint64_t* np, uint64_t* nc) {
+  if (!p || !nr || !np || !nc) return LCPC_ERR_ARG;
+  LCPC_TRY
+  const FieldDesc* f = field_desc((int)p->field);
+  if (!f || p->n_coeffs == 0) return LCPC_ERR_ARG;
+  if (p->encoding == LCPC_ENC_LIGERO) {
+    if (p->rho_num == 0 || p->rho_num >= p->rho_den) return LCPC_ERR_ARG;
+    return ligero_get_dims(*f, p->n_coeffs, p->rho_num, p->rho_den, nr, np, nc) ? LCPC_ERR_TOO_BIG : 0;
+  } else if (p->encoding == LCPC_ENC_SDIG) {
+    SdigSpec s;
+    const int code = p->sdig_code ? (int)p->sdig_code : 3;
+    uint64_t npr;
+    if (!sdig_spec(code, &s) || !sdig_n_per_row(*f, p->n_coeffs, code, &npr)) return LCPC_ERR_ARG;
+    std::vector<LevelDims> pre, post;
+    if (!sdig_level_dims(s, npr, (double)f->flog2(), pre, post)) return LCPC_ERR_DIMS;
+    *nr = (p->n_coeffs + npr - 1) / npr; *np = npr; *nc = sdig_codeword_length(pre, post);
+    return 0;
+  }
+  return LCPC_ERR_ARG;
+  LCPC_CATCH((lcpc_ctx*)nullptr)
+}
+
+// new_ml (ligero lib.rs:128-135, brakedown lib.rs:114-123): dims for a multilinear polynomial in n_vars variables
+int lcpc_static_get_dims_ml(const lcpc_params* p, uint32_t n_vars, uint64_t* nr, uint64_t* np, uint64_t* nc) {
+  if (!p || !nr || !np || !nc || n_vars >= 63) return LCPC_ERR_ARG;
+  LCPC_TRY
+  const FieldDesc* f = field_desc((int)p->field);
+  if (!f) return LCPC_ERR_ARG;
+  const uint64_t n = (uint64_t)1 << n_vars;
+  if (p->encoding == LCPC_ENC_LIGERO) {
+    lcpc_params q = *p;
+    q.n_coeffs = n;
+    int rc = lcpc_static_get_dims(&q, nr, np, nc);
+    if (rc) return rc;
+    // the reference's assert!s (lib.rs:131-133)
+    if ((*nr & (*nr - 1)) || (*np & (*np - 1)) || *nr * *np != n) return LCPC_ERR_DIMS;
+    return 0;
+  } else if (p->encoding == LCPC_ENC_SDIG) {
+    SdigSpec s;
+    const int code = p->sdig_code ? (int)p->sdig_code : 3;
+    uint64_t npr;
+    if (!sdig_spec(code, &s) || !sdig_n_per_row(*f, n, code, &npr, true)) return LCPC_ERR_ARG;
+    std::vector<LevelDims> pre, post;
+    if (!sdig_level_dims(s, npr, (double)f->flog2(), pre, post)) return LCPC_ERR_DIMS;
+    *nr = (n + npr - 1) / npr; *np = npr; *nc = sdig_codeword_length(pre, post);
+    return 0;
+  }
+  return LCPC_ERR_ARG;
+  LCPC_CATCH((lcpc_ctx*)nullptr)
+}
+
+static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
+  const FieldDesc* f = c->f;
+  std::string* err = &c->err;
+  int rc = 0;
+  if (p->encoding == LCPC_ENC_LIGERO) {
+    if (p->rho_num == 0 || p->rho_num >= p->rho_den) return LCPC_ERR_ARG;
+    uint64_t nr, np_, nc;
+    if (p->n_per_row && p->n_cols) { np_ = p->n_per_row; nc = p->n_cols; }      // new_from_dims (ligero lib.rs:138-148)
+    else if ((rc = lcpc_static_get_dims(p, &nr, &np_, &nc))) return rc;
+    if (!(np_ < nc) || (nc & (nc - 1)) || log2_ceil(nc) > f->S) return LCPC_ERR_DIMS;   // _dims_ok + precomp_fft
+    if (log2_ceil(nc) > 30) return LCPC_ERR_TOO_BIG;      // device kernels index a row with 32 bits
+    c->n_per_row = np_; c->n_cols = nc; c->log_n = (unsigned)log2_ceil(nc);
+    {
+      // precomp_fft (fffft [3P]): w = ROOT_OF_UNITY^(2^(S - log_n)); the host only computes the log_n - 1 squares
+      // w^(2^j), the n/2-entry tables are filled on the device (kernels.hip roots_kernel)
+      const unsigned log_half = c->log_n ? c->log_n - 1 : 0;
+      const size_t n_roots = (size_t)1 << log_half;
+      std::vector<uint64_t> pw((size_t)(log_half + 1) * f->L);
+      uint64_t w[MAXL];
+      memcpy(w, f->rou, 8 * f->L);
+      for (unsigned i = 0; i < f->S - c->log_n; i++) h_mul(*f, w, w, w);
+      for (unsigned j = 0; j <= log_half; j++) { memcpy(&pw[(size_t)j * f->L], w, 8 * f->L); h_mul(*f, w, w, w); }
+      uint32_t *d_pw = nullptr, *d_one = nullptr;
+      if ((rc = dev_alloc(err, &d_pw, pw.size() * 8)) || (rc = dev_alloc(err, &d_one, 8 * f->L)) ||
+          (rc = dev_alloc(err, &c->d_roots, n_roots * 8 * f->L)) ||
+          (f->L == 4 && (rc = dev_alloc(err, &c->d_roots29, n_roots * 48))) ||
+          (f->L == 4 && (rc = dev_alloc(err, &c->d_roots29c, n_roots * 48)))) {
+        dev_free(d_pw); dev_free(d_one);
+        return rc;
+      }
+      hipError_t he = hipMemcpy(d_pw, pw.data(), pw.size() * 8, hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = hipMemcpy(d_one, f->r, 8 * f->L, hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = launch_roots(c->NL, d_pw, log_half, d_one, c->d_roots, c->d_roots29, c->d_roots29c, nullptr);
+      if (he == hipSuccess) he = hipDeviceSynchronize();
+      dev_free(d_pw); dev_free(d_one);
+      if (he != hipSuccess) return fail_hip(err, he, "precomp_fft");
+    }
+    if (f->L == 4 && !getenv("LCPC_NTT_PACKED")) {
+      // (i - 24) * p for i < 64 as normalised signed 29-bit limbs (limbs 0..7 in [0, 2^29), limb 8 two's complement):
+      // the table behind l9::clamp (lazy-limb NTT kernel; QOFF in field_dev.h)
+      std::vector<uint32_t> tab(64 * 12, 0);
+      for (int i = 0; i < 64; i++) {
+        const int q = i - 24;
+        uint64_t mag[5] = {0, 0, 0, 0, 0};                      // |q| * p
+        unsigned __int128 cy = 0;
+        for (int w = 0; w < 5; w++) { cy += (unsigned __int128)(w < 4 ? f->p[w] : 0) * (uint64_t)(q < 0 ? -q : q); mag[w] = (uint64_t)cy; cy >>= 64; }
+        if (q < 0) {                                            // two's complement over 320 bits
+          unsigned __int128 c2 = 1;
+          for (int w = 0; w < 5; w++) { c2 += (unsigned __int128)(~mag[w]); mag[w] = (uint64_t)c2; c2 >>= 64; }
+        }
+        for (int k = 0; k < 9; k++) {
+          const int b = 29 * k, w = b / 64, sh = b % 64;
+          uint64_t x = mag[w] >> sh;
+          if (sh > 35) x |= mag[w + 1] << (64 - sh);
+          tab[i * 12 + k] = k < 8 ? (uint32_t)(x & ((1u << 29) - 1)) : (uint32_t)x;      // limb 8: bits 232..263, sign-extended
+        }
+      }
+      if ((rc = dev_alloc(err, &c->d_qp29, tab.size() * 4))) return rc;
+      HIPCHK(c, hipMemcpy(c->d_qp29, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+      c->comm_canon = !getenv("LCPC_COMM_MONT");
+    }
+    if ((rc = dev_alloc(err, &c->d_r2, 8 * f->L))) return rc;
+    HIPCHK(c, hipMemcpy(c->d_r2, f->r2, 8 * f->L, hipMemcpyHostToDevice));
+    plan_passes(c);
+    return 0;
+  }
+  if (p->encoding != LCPC_ENC_SDIG) return LCPC_ERR_ARG;
+  if (!sdig_spec((int)c->prm.sdig_code, &c->spec)) return LCPC_ERR_ARG;
+  uint64_t npr = p->n_per_row;
+  if (!(p->n_per_row && p->n_cols)) {
+    if (!sdig_n_per_row(*f, p->n_coeffs, (int)c->prm.sdig_code, &npr)) return LCPC_ERR_ARG;
+  }
+  std::vector<CsrMatrix> pre, post;
+  if (!sdig_generate(*f, c->spec, npr, p->seed, pre, post, c->pre_dims, c->post_dims)) return LCPC_ERR_DIMS;
+  c->n_per_row = npr;
+  c->n_cols = sdig_codeword_length(c->pre_dims, c->post_dims);
+  if (p->n_per_row && p->n_cols && p->n_cols != c->n_cols) return LCPC_ERR_DIMS;   // new_from_dims assert
+  auto upload = [&](const CsrMatrix& m, DevCsr& d) -> int {
+    d.n_in = m.n_in; d.n_out = m.n_out;
+    int r;
+    if ((r = dev_alloc(err, &d.rowptr, m.rowptr.size() * 4))) return r;
+    if ((r = dev_alloc(err, &d.colidx, m.colidx.size() * 4))) return r;
+    if ((r = dev_alloc(err, &d.vals, m.vals.size() * 8))) return r;
+    HIPCHK(c, hipMemcpy(d.rowptr, m.rowptr.data(), m.rowptr.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d.colidx, m.colidx.data(), m.colidx.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d.vals, m.vals.data(), m.vals.size() * 8, hipMemcpyHostToDevice));
+    if (f->L == 4) {
+      const size_t nnz = m.colidx.size();
+      std::vector<uint32_t> v29(nnz * 12 + 12);
+      parallel_for(nnz, 16384, [&](uint64_t b, uint64_t e) { for (uint64_t k = b; k < e; k++) to_r29(*f, &m.vals[k * 4], &v29[k * 12]); });
+      if ((r = dev_alloc(err, &d.vals29, v29.size() * 4))) return r;
+      HIPCHK(c, hipMemcpy(d.vals29, v29.data(), v29.size() * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+  };
+  c->d_pre.resize(pre.size());
+  c->d_post.resize(post.size());
+  for (size_t i = 0; i < pre.size() && !rc; i++) { rc = upload(pre[i], c->d_pre[i]); if (!rc) rc = upload(post[i], c->d_post[i]); }
+  if (!rc) rc = dev_alloc(err, &c->d_r2, 8 * f->L);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpy(c->d_r2, f->r2, 8 * f->L, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
+  if (!p || !out) return LCPC_ERR_ARG;
+  *out = nullptr;
+  lcpc_ctx* c = nullptr;
+  LCPC_TRY
+  const FieldDesc* f = field_desc((int)p->field);
+  if (!f || p->hash != LCPC_HASH_BLAKE3) return LCPC_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) return LCPC_ERR_NO_DEVICE;
+  if (hipSetDevice(p->device) != hipSuccess) return LCPC_ERR_NO_DEVICE;
+  c = new lcpc_ctx();
+  c->prm = *p;
+  c->f = f; c->L = f->L; c->NL = 2 * f->L;
+  if (c->prm.sdig_code == 0) c->prm.sdig_code = 3;
+  int rc = 0;
+  // row sharding needs rows that do not straddle BLAKE3 chunks (F | 1024)
+  if (c->prm.shard_count > 1 && (c->prm.shard_rank >= c->prm.shard_count || 1024 % (8 * f->L) != 0)) rc = LCPC_ERR_ARG;
+  if (!rc) rc = ctx_build(c, p);
+  if (rc) { ctx_unref(c); return rc; }
+  c->np2 = next_pow2(c->n_cols);
+  c->path_len = (uint32_t)log2_ceil(c->n_cols);
+  *out = c;
+  return 0;
+  } catch (...) {
+    if (c) ctx_unref(c);
+    return LCPC_ERR_NOMEM;
+  }
+}
+
+void lcpc_ctx_destroy(lcpc_ctx* c) {
+  if (c) ctx_unref(c);
+}
+
+int lcpc_get_dims(const lcpc_ctx* c, uint64_t len, uint64_t* nr, uint64_t* np, uint64_t* nc) {
+  if (!c || len == 0) return LCPC_ERR_ARG;
+  if (nr) *nr = (len + c->n_per_row - 1) / c->n_per_row;      // ligero lib.rs:166-169
+  if (np) *np = c->n_per_row;
+  if (nc) *nc = c->n_cols;
+  return 0;
+}
+int lcpc_dims_ok(const lcpc_ctx* c, uint64_t n_per_row, uint64_t n_cols) {
+  if (!c) return 0;
+  bool ok = n_per_row < n_cols && n_per_row == c->n_per_row && n_cols == c->n_cols;
+  if (c->prm.encoding == LCPC_ENC_LIGERO) ok = ok && (n_cols & (n_cols - 1)) == 0;
+  return ok ? 1 : 0;
+}
+uint64_t lcpc_get_n_col_opens(const lcpc_ctx* c) {
+  if (!c) return 0;
+  return c->prm.encoding == LCPC_ENC_LIGERO ? ligero_n_col_opens(c->prm.rho_num, c->prm.rho_den) : sdig_n_col_opens((int)c->prm.sdig_code);
+}
+uint64_t lcpc_get_n_degree_tests(const lcpc_ctx* c) { return c ? n_degree_tests(128, c->n_cols, c->f->flog2()) : 0; }
+uint32_t lcpc_field_limbs(const lcpc_ctx* c) { return c ? (uint32_t)c->L : 0; }
+
+int lcpc_encode_rows(lcpc_ctx* c, uint64_t* rows, uint64_t n_rows) {
+  if (!c || !rows) return LCPC_ERR_ARG;
+  if (n_rows == 0) return 0;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  const size_t bytes = (size_t)n_rows * c->n_cols * elem_bytes(c);
+  int rc = ensure_dev(&c->err, &c->d_scratch, &c->scratch_cap, bytes);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpy(c->d_scratch, rows, bytes, hipMemcpyHostToDevice));
+  // the trait contract (lib.rs:651-652): entries >= n_per_row are zero on entry; they are read as given here
+  EncodeJob j;
+  j.src = c->d_scratch; j.src_stride = c->n_cols; j.n_valid = c->n_cols; j.dst = c->d_scratch; j.n_rows = n_rows;
+  if ((rc = encode_rows_device(c, &c->ws, j, nullptr, &c->err, nullptr))) return rc;
+  HIPCHK(c, hipMemcpy(rows, c->d_scratch, bytes, hipMemcpyDeviceToHost));
+  return 0;
+  LCPC_CATCH(c)
+}
+
+int lcpc_field_sum_device(lcpc_ctx* c, const uint64_t* parts, uint32_t n_parts, uint64_t n_elems, void* stream, uint64_t* out) {
+  if (!c || !parts || !out || n_parts == 0) return LCPC_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  HIPCHK(c, launch_field_sum(c->NL, reinterpret_cast<const uint32_t*>(parts), n_parts, n_elems, reinterpret_cast<uint32_t*>(out),
+                             (hipStream_t)stream));
+  return 0;
+}
+
+void lcpc_root_bincode(const uint8_t root[32], uint8_t out[40]) {
+  const uint64_t l = 32;
+  memcpy(out, &l, 8);
+  memcpy(out + 8, root, 32);
+}
+void lcpc_free(void* p) { free(p); }
+
+}  // extern "C"

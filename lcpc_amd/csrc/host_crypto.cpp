@@ -119,6 +119,9 @@ void Transcript::append_message(const uint8_t* label, size_t llen, const uint8_t
   meta_ad(le, 4, true);
   ad(msg, mlen, false);
 }
+void Transcript::append_messages(const uint8_t* label, size_t llen, const uint8_t* msgs, size_t mlen, size_t n) {
+  for (size_t i = 0; i < n; i++) append_message(label, llen, msgs + i * mlen, mlen);
+}
 void Transcript::challenge_bytes(const uint8_t* label, size_t llen, uint8_t* out, size_t n) {
   const uint32_t l = (uint32_t)n;
   const uint8_t le[4] = {(uint8_t)l, (uint8_t)(l >> 8), (uint8_t)(l >> 16), (uint8_t)(l >> 24)};

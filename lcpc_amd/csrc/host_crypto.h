@@ -17,6 +17,9 @@ class Transcript {
  public:
   explicit Transcript(const uint8_t* label, size_t len);
   void append_message(const uint8_t* label, size_t llen, const uint8_t* msg, size_t mlen);
+  // n calls of append_message(label, msgs + i * mlen, mlen), i = 0..n-1: the shape of prove / verify's coefficient
+  // absorbs (lcpc-2d lib.rs:1045-1047, 1066-1068)
+  void append_messages(const uint8_t* label, size_t llen, const uint8_t* msgs, size_t mlen, size_t n);
   void challenge_bytes(const uint8_t* label, size_t llen, uint8_t* out, size_t n);
 
  private:

@@ -1,0 +1,258 @@
+// lcpc_amd/csrc/internal.h -- shared internals of the C ABI implementation (include/lcpc_hip.h).
+//
+//   ctx.cpp     lcpc_ctx     = an LcEncoding implementor (ligero lib.rs:31-186, brakedown lib.rs:41-176): twiddle tables /
+//                              expander matrices on the device, dims, batched encode.  Immutable after creation, shared
+//                              by any number of commitments (the reference's `&E`, lcpc-2d lib.rs:74-104).
+//   commit.cpp  lcpc_commit  = an LcCommit<D, E> (lcpc-2d lib.rs:172-184): comm / coeffs / hashes in HBM, created by
+//                              commit(), consumed by prove / open_column / collapse_columns.
+//   prove.cpp   transcript wrappers, prove (lib.rs:1004-1093), verify (lib.rs:832-1000), bincode (lib.rs:550-609)
+//   shard.cpp   row-sharded commit / prove across GPUs and the RCCL exchange
+#pragma once
+#include "../../include/lcpc_hip.h"
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+#include "encoding.h"
+#include "host_crypto.h"
+#include "host_field.h"
+#include "kernels.h"
+
+namespace lcpc {
+
+struct DevCsr {
+  uint64_t n_in = 0, n_out = 0;
+  uint32_t *rowptr = nullptr, *colidx = nullptr, *vals = nullptr;
+  uint32_t* vals29 = nullptr;     // Ft255: values in the 29-bit-limb / 2^261 form (lazy29_mac)
+};
+struct Pass { uint32_t t0, s, log_tj; int log_tile; };
+
+// device working buffers of one Brakedown encode: owned by a commitment (where the position-major copy IS the
+// commitment matrix) or, for lcpc_encode_rows, by the encoder context
+struct EncodeWs {
+  uint32_t* d_tmp = nullptr;       // last precode output, n_rows x m_last
+  uint64_t tmp_cap = 0;
+  uint32_t* d_t = nullptr;         // position-major working copy T[pos][row] of the rows being encoded
+  uint64_t t_cap = 0;
+};
+
+}  // namespace lcpc
+
+struct lcpc_transcript {
+  lcpc::Transcript t;
+  lcpc_transcript(const uint8_t* l, size_t n) : t(l, n) {}
+};
+
+struct lcpc_ctx {
+  lcpc_params prm{};
+  const lcpc::FieldDesc* f = nullptr;
+  int L = 0, NL = 0;
+  uint64_t n_per_row = 0, n_cols = 0, np2 = 0;
+  uint32_t path_len = 0;
+  // Ligero
+  unsigned log_n = 0;
+  uint32_t* d_roots = nullptr;
+  uint32_t* d_roots29 = nullptr;   // Ft255: twiddles in radix-2^29 / R'=2^261 Montgomery form (field_dev.h fe_mul_r29)
+  uint32_t* d_qp29 = nullptr;      // Ft255: q*p as 29-bit limbs (l9::clamp); null = packed-form NTT kernel
+  uint32_t* d_roots29c = nullptr;  // Ft255 lazy-limb kernel: w^i * 2^5, the table that converts to canonical on the fly
+  bool comm_canon = false;         // d_comm of a commit holds canonical values (x * R^-1), not Montgomery form: the column
+                                   // hash reads them as they are; every read-out (get_comm, open_columns) converts back
+  std::vector<lcpc::Pass> passes;
+  // Brakedown
+  lcpc::SdigSpec spec{};
+  std::vector<lcpc::LevelDims> pre_dims, post_dims;
+  std::vector<lcpc::DevCsr> d_pre, d_post;
+  uint32_t* d_r2 = nullptr;
+  // lcpc_encode_rows (the verifier's row encodes): scratch under `mu`
+  lcpc::EncodeWs ws;
+  uint32_t* d_scratch = nullptr;
+  uint64_t scratch_cap = 0;
+  // RCCL communicator of a sharded encoder (lcpc_comm_init); opaque ncclComm_t
+  void* comm = nullptr;
+  std::atomic<int> refs{1};        // the handle itself + one per live lcpc_commit
+  std::string err;
+  std::mutex mu;
+};
+
+struct lcpc_commit_s {
+  lcpc_ctx* enc = nullptr;
+  bool committed = false;
+  uint64_t n_rows = 0;             // rows of the whole commitment
+  uint64_t row_begin = 0, n_rows_local = 0;
+  uint64_t chunk_begin = 0, chunk_end = 0, n_chunks = 0;
+  uint32_t *d_coeffs = nullptr, *d_comm = nullptr, *d_hashes = nullptr, *d_cvs = nullptr;
+  const uint32_t* coeffs_view = nullptr;   // LcCommit.coeffs as prove/collapse read it: d_coeffs, or the caller's buffer
+                                           // when the commit was made with LCPC_COMMIT_BORROW_COEFFS
+  uint64_t cap_coeff_rows = 0, cap_comm_rows = 0, cap_cvs = 0;
+  lcpc::EncodeWs ws;
+  bool comm_t = false;             // Brakedown commit with >= 16 local rows: the commitment matrix lives in ws.d_t (position-major,
+                                   // element (row, col) at (col * n_rows_local + row)); hash / open read it there, d_comm is only
+                                   // filled on demand (lcpc_get_comm) -- no back-transpose on the commit path
+  bool comm_rows_valid = false;    // d_comm holds the row-major copy of the commitment in ws.d_t
+  uint32_t* d_node_tab = nullptr;  // sharded finish: node_slot[0..n) then node_log[0..n)
+  uint64_t node_tab_key = 0;
+  std::vector<uint32_t> node_slot_h, node_log_h;
+  uint8_t* d_gather = nullptr;     // native sharded commit (lcpc_commit_sharded_device): this rank's nodes + the all-gather output
+  uint64_t gather_cap = 0;
+  uint8_t *d_xsend = nullptr, *d_xrecv = nullptr;   // native sharded prove: exchange buffers
+  uint64_t xchg_cap = 0;
+  // scratch for prove / collapse / open
+  uint32_t* d_scratch = nullptr;
+  uint64_t scratch_cap = 0;
+  uint32_t* d_t29 = nullptr;       // collapse: tensors in the 29-bit-limb form
+  uint64_t t29_cap = 0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t s_copy = nullptr, s_comp = nullptr;   // lcpc_commit (host pointer): H2D of row batch b+1 overlaps the NTTs of batch b
+  hipEvent_t ev_batch[16] = {nullptr};
+  lcpc_timings last{};
+  uint32_t launches[3] = {0, 0, 0};
+  std::string err;
+  std::mutex mu;
+};
+
+namespace lcpc {
+
+// ---- error plumbing ---------------------------------------------------------------------------------
+inline int fail_hip(std::string* err, hipError_t e, const char* what) {
+  if (err) *err = std::string(what) + ": " + hipGetErrorString(e);
+  return e == hipErrorOutOfMemory ? LCPC_ERR_NOMEM : LCPC_ERR_HIP;
+}
+// `c` is an lcpc_ctx* or lcpc_commit_t* (both have .err)
+#define HIPCHK(c, call)                                                   \
+  do {                                                                    \
+    hipError_t e__ = (call);                                              \
+    if (e__ != hipSuccess) return lcpc::fail_hip((c) ? &(c)->err : nullptr, e__, #call); \
+  } while (0)
+
+// nothing may unwind through the C ABI (include/lcpc_hip.h): every extern "C" body that can allocate runs inside this
+#define LCPC_TRY try {
+#define LCPC_CATCH(c)                                                     \
+  } catch (const std::bad_alloc&) {                                       \
+    if (c) (c)->err = "host allocation failed";                          \
+    return LCPC_ERR_NOMEM;                                                \
+  } catch (const std::exception& ex__) {                                  \
+    if (c) (c)->err = ex__.what();                                       \
+    return LCPC_ERR_STATE;                                                \
+  } catch (...) {                                                         \
+    return LCPC_ERR_STATE;                                                \
+  }
+
+template <typename T> int dev_alloc(std::string* err, T** p, size_t bytes) {
+  *p = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes);
+  if (e != hipSuccess) return fail_hip(err, e, "hipMalloc");
+  return 0;
+}
+inline void dev_free(void* p) { if (p) (void)hipFree(p); }
+// grow-only device buffer; the requested size is rounded up to 256 bytes so that offsets computed from the capacity
+// (collapse partials at the end of scratch) stay 16-byte aligned for the uint4 element accesses
+template <typename T> int ensure_dev(std::string* err, T** p, uint64_t* cap, uint64_t bytes) {
+  bytes = (bytes + 255) & ~(uint64_t)255;
+  if (bytes > *cap || !*p) {
+    dev_free(*p);
+    *p = nullptr; *cap = 0;
+    int rc = dev_alloc(err, p, (size_t)bytes);
+    if (rc) return rc;
+    *cap = bytes;
+  }
+  return 0;
+}
+
+inline size_t elem_bytes(const lcpc_ctx* c) { return (size_t)8 * c->L; }
+// leaf message = 32 + F * n_rows bytes -> BLAKE3 chunks of 1 KiB
+inline uint64_t leaf_chunks(const lcpc_ctx* c, uint64_t n_rows) { return (32 + elem_bytes(c) * n_rows + 1023) / 1024; }
+
+// host cores this process may really use (hardware threads capped by the cgroup CPU quota)
+unsigned usable_cores();
+
+// small fork-join helper for the host-side glue (the reference uses rayon at the same places: lib.rs:923-944)
+template <typename Fn> void parallel_for(uint64_t n, uint64_t grain, Fn fn, unsigned max_threads = 16) {
+  unsigned nt = usable_cores();
+  if (nt > max_threads) nt = max_threads;
+  if (nt <= 1 || n < 2 * grain) { fn((uint64_t)0, n); return; }
+  const uint64_t nchunks = (n + grain - 1) / grain;
+  if (nt > nchunks) nt = (unsigned)nchunks;
+  std::atomic<uint64_t> next{0};
+  auto body = [&] {
+    for (;;) {
+      const uint64_t c = next.fetch_add(1);
+      if (c >= nchunks) return;
+      const uint64_t b = c * grain, e = b + grain < n ? b + grain : n;
+      fn(b, e);
+    }
+  };
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  try {
+    for (unsigned t = 0; t + 1 < nt; t++) th.emplace_back(body);
+  } catch (...) {       // thread creation failed: the calling thread (and whatever started) finishes the work
+  }
+  body();
+  for (auto& x : th) x.join();
+}
+
+// labels of the transcript (macros.rs:31-34)
+extern const uint8_t LBL_DT[7], LBL_PR[7], LBL_PE[7], LBL_CO[7];
+
+// Ft255 element in ff_derive's Montgomery form (a * 2^256) -> a * 2^261 mod p as 9 limbs of 29 bits, 12-word stride
+void to_r29(const FieldDesc& f, const uint64_t* in4, uint32_t* out12);
+
+// ---- ctx.cpp ----------------------------------------------------------------------------------------
+void ctx_ref(lcpc_ctx* c);
+void ctx_unref(lcpc_ctx* c);
+// encode n_rows rows: src (src_stride elements per row, first n_valid valid, flat elements >= n_src_total zero) -> dst
+// (n_cols per row).  err: where HIP error text goes; launches: encode launch counter or null.
+struct EncodeJob {
+  const uint32_t* src = nullptr;
+  uint64_t src_stride = 0, n_valid = 0;
+  uint32_t* dst = nullptr;
+  uint64_t n_rows = 0;
+  uint64_t n_src_total = ~(uint64_t)0;
+  uint32_t* copy_dst = nullptr;    // padded LcCommit.coeffs copy written while the source streams through (or null)
+  bool canon_out = false;          // dst receives canonical values instead of Montgomery form (commit paths of a comm_canon context)
+  bool keep_t = false;             // Brakedown: leave the result position-major in ws->d_t (the commit path); *kept_t reports it
+  bool* kept_t = nullptr;
+};
+int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipStream_t st, std::string* err, uint32_t* launches);
+
+// ---- commit.cpp -------------------------------------------------------------------------------------
+int ensure_scratch(lcpc_commit_t* m, uint64_t bytes);
+int ensure_cvs(lcpc_commit_t* m, uint64_t n_chunks);
+int ensure_commit_buffers(lcpc_commit_t* m, uint64_t n_rows_local, bool own_coeffs);
+int merkle_top(lcpc_commit_t* m, hipStream_t st);       // zero padding leaves + tree above the leaf digests
+int finish_timing(lcpc_commit_t* m, hipStream_t st);
+int collapse_run(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_polys);
+size_t collapse_scratch_bytes(const lcpc_commit_t* m, uint32_t n_tensors);
+// open_column values / paths into device buffers (either may be null)
+int open_columns_device(lcpc_commit_t* m, const uint64_t* d_cols, uint32_t n, uint32_t* d_vals, uint32_t* d_paths, hipStream_t st);
+
+// ---- shard.cpp --------------------------------------------------------------------------------------
+void shard_layout_of(const lcpc_ctx* c, uint64_t g, uint64_t n_rows, uint64_t* rb, uint64_t* re, uint64_t* cb, uint64_t* ce, uint64_t* nch);
+int shard_nodes(uint64_t c0, uint64_t c1, uint64_t* first, uint32_t* lg);
+void comm_release(lcpc_ctx* c);
+// the exchange of a row-sharded prove: every rank contributes `bytes` from send_dev, receives all ranks'
+// blocks in rank order in recv_dev
+struct ShardXchg {
+  uint8_t *send_dev, *recv_dev;
+  uint64_t max_bytes;
+  lcpc_allgather_fn fn;
+  void* user;
+};
+int collapse_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* tensors_full, uint32_t nt, uint64_t* polys);
+int open_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* cols, uint32_t n, uint64_t* vals, uint8_t* paths);
+
+// ---- prove.cpp --------------------------------------------------------------------------------------
+int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t** proof, uint64_t* proof_len,
+               uint64_t* cols_opened, const ShardXchg* xchg);
+
+}  // namespace lcpc

@@ -1,0 +1,491 @@
+// lcpc_amd/csrc/shard.cpp -- row-sharded commit / prove across the GPUs of a node.
+//
+// commit (lcpc-2d/src/lib.rs:622-671) shards by rows: the encode (lib.rs:648-653) is independent per row and the
+// column hash (lib.rs:706-745) is a BLAKE3 tree over the leaf message, so a rank that owns a chunk-aligned block of
+// rows reduces it to subtree chaining values on its own.  The single exchange step is one all-gather of those
+// (here: ncclAllGather on RCCL over xGMI, or a caller-supplied all-gather); every rank then finishes the leaf
+// digests and builds the Merkle tree redundantly.  prove (lib.rs:1004-1093): collapse_columns (1095-1123) is a sum
+// over rows -> partial sums per rank + all-gather + sum mod p; open_column (788-825) gathers per rank + all-gather.
+#include "internal.h"
+#include <dlfcn.h>
+
+using namespace lcpc;
+
+namespace lcpc {
+
+// rows / chunks of shard `g` (DESIGN.md "multi-GPU"): chunk-aligned row blocks
+void shard_layout_of(const lcpc_ctx* c, uint64_t g, uint64_t n_rows, uint64_t* rb, uint64_t* re, uint64_t* cb, uint64_t* ce, uint64_t* nch) {
+  const uint64_t n_chunks = leaf_chunks(c, n_rows);
+  const uint64_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
+  if (G == 1) g = 0;
+  const uint64_t c0 = n_chunks * g / G, c1 = n_chunks * (g + 1) / G;
+  const uint64_t F = elem_bytes(c);
+  auto first_row = [&](uint64_t chunk) -> uint64_t {   // first row whose bytes start in or after this chunk
+    if (chunk == 0) return 0;
+    const uint64_t byte = chunk * 1024 - 32;             // F | 1024 is enforced for sharded contexts
+    uint64_t r = byte / F;
+    return r < n_rows ? r : n_rows;
+  };
+  *cb = c0; *ce = c1; *nch = n_chunks;
+  *rb = first_row(c0);
+  *re = c1 >= n_chunks ? n_rows : first_row(c1);
+  if (c0 == c1) *re = *rb;
+}
+
+// aligned power-of-two decomposition of the chunk range [c0, c1): the subtree nodes a shard exchanges
+int shard_nodes(uint64_t c0, uint64_t c1, uint64_t* first, uint32_t* lg) {
+  int n = 0;
+  for (uint64_t pos = c0; pos < c1;) {
+    uint32_t l = 0;
+    while ((pos == 0 || (pos & (((uint64_t)2 << l) - 1)) == 0) && pos + ((uint64_t)2 << l) <= c1) l++;
+    first[n] = pos; lg[n] = l; n++;
+    pos += (uint64_t)1 << l;
+  }
+  return n;
+}
+
+// ---- RCCL, loaded at run time ---------------------------------------------------------------------------
+// The library itself does not link librccl: a single-GPU host never needs it, and a process that already carries a
+// copy (torch bundles one) must keep using that one.  Prototypes as in rccl.h (NCCL 2.x ABI).
+namespace {
+typedef struct { char internal[128]; } NcclUniqueId;
+struct Rccl {
+  void* h = nullptr;
+  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+  int (*CommInitRank)(void** comm, int nranks, NcclUniqueId id, int rank) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t st) = nullptr;
+  int (*Broadcast)(const void* send, void* recv, size_t count, int dtype, int root, void* comm, hipStream_t st) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+Rccl& rccl() {
+  static Rccl r = [] {
+    Rccl x;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    x.h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);             // a copy already in the process (torch) wins
+    for (const char* n : names) {
+      if (x.h) break;
+      x.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!x.h) return x;
+    x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.h, "ncclGetUniqueId"));
+    x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.h, "ncclCommInitRank"));
+    x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.h, "ncclCommDestroy"));
+    x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.h, "ncclAllGather"));
+    x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(dlsym(x.h, "ncclBroadcast"));
+    x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.h, "ncclGroupStart"));
+    x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.h, "ncclGroupEnd"));
+    x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.h, "ncclGetErrorString"));
+    x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather && x.Broadcast && x.GroupStart && x.GroupEnd;
+    return x;
+  }();
+  return r;
+}
+constexpr int NCCL_UINT8 = 1;      // ncclUint8 (rccl.h)
+int fail_nccl(std::string* err, int rc, const char* what) {
+  if (err) *err = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "nccl error") ;
+  return LCPC_ERR_XCHG;
+}
+// lcpc_allgather_fn on the encoder's communicator: null stream (what collapse_sharded / open_sharded use), host-synchronous
+int rccl_allgather_cb(void* user, uint64_t bytes) {
+  lcpc_commit_t* m = static_cast<lcpc_commit_t*>(user);
+  int rc = rccl().AllGather(m->d_xsend, m->d_xrecv, (size_t)bytes, NCCL_UINT8, m->enc->comm, nullptr);
+  if (rc != 0) { fail_nccl(&m->err, rc, "ncclAllGather"); return 1; }
+  return hipStreamSynchronize(nullptr) == hipSuccess ? 0 : 1;
+}
+}  // namespace
+
+void comm_release(lcpc_ctx* c) {
+  if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+  c->comm = nullptr;
+}
+
+// ---- sharded prove pieces ---------------------------------------------------------------------------------
+// collapse over ALL rows of a sharded commitment: local partial sums, all-gather, sum mod p (lib.rs:1095-1123 split by rows)
+int collapse_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* tensors_full, uint32_t nt, uint64_t* polys) {
+  const lcpc_ctx* c = m->enc;
+  const size_t eb = elem_bytes(c);
+  const int L = c->L;
+  const uint64_t bytes = (uint64_t)nt * c->n_per_row * eb;
+  if (bytes > x.max_bytes) return LCPC_ERR_ARG;
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    HIPCHK(m, hipSetDevice(c->prm.device));
+    if (m->n_rows_local == 0) {
+      HIPCHK(m, hipMemsetAsync(x.send_dev, 0, bytes, nullptr));
+    } else {
+      const size_t row_b = m->n_rows_local * eb;
+      const size_t tb = ((size_t)nt * row_b + 255) & ~(size_t)255;
+      int rc = ensure_scratch(m, tb + collapse_scratch_bytes(m, 2) + 512);
+      if (rc) return rc;
+      uint32_t* d_t = m->d_scratch;
+      for (uint32_t t = 0; t < nt; t++)      // this rank's slice of every tensor, straight from the caller's buffer
+        HIPCHK(m, hipMemcpyAsync(reinterpret_cast<uint8_t*>(d_t) + (size_t)t * row_b, tensors_full + ((size_t)t * m->n_rows + m->row_begin) * L, row_b,
+                                 hipMemcpyHostToDevice, nullptr));
+      if ((rc = collapse_run(m, d_t, nt, nullptr, reinterpret_cast<uint32_t*>(x.send_dev)))) return rc;
+    }
+    HIPCHK(m, hipStreamSynchronize(nullptr));
+  }
+  if (x.fn(x.user, bytes) != 0) return LCPC_ERR_XCHG;
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  HIPCHK(m, launch_field_sum(c->NL, reinterpret_cast<const uint32_t*>(x.recv_dev), std::max<uint32_t>(1, c->prm.shard_count), (uint64_t)nt * c->n_per_row,
+                             reinterpret_cast<uint32_t*>(x.send_dev), nullptr));
+  HIPCHK(m, hipMemcpy(polys, x.send_dev, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// open_column for n columns of a sharded commitment: every rank gathers its rows straight into the send buffer, one
+// all-gather, columns assembled in row order on the host; the Merkle paths come from the (replicated) tree
+int open_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* cols, uint32_t n, uint64_t* vals, uint8_t* paths) {
+  const lcpc_ctx* c = m->enc;
+  const size_t eb = elem_bytes(c);
+  const uint32_t G = std::max<uint32_t>(1, c->prm.shard_count);
+  for (uint32_t i = 0; i < n; i++)
+    if (cols[i] >= c->n_cols) return LCPC_ERR_COLUMN_NUMBER;
+  std::vector<uint64_t> rb(G), re(G);
+  uint64_t max_rows = 0;
+  for (uint32_t g = 0; g < G; g++) {
+    uint64_t cb, ce, nch;
+    shard_layout_of(c, g, m->n_rows, &rb[g], &re[g], &cb, &ce, &nch);
+    max_rows = std::max(max_rows, re[g] - rb[g]);
+  }
+  const uint64_t bytes = (uint64_t)n * max_rows * eb;
+  if (bytes > x.max_bytes) return LCPC_ERR_ARG;
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    HIPCHK(m, hipSetDevice(c->prm.device));
+    const size_t cb = (((size_t)n * 8) + 255) & ~(size_t)255, pb = (((size_t)n * c->path_len * 32) + 255) & ~(size_t)255;
+    int rc = ensure_scratch(m, cb + pb);
+    if (rc) return rc;
+    uint64_t* d_cols = reinterpret_cast<uint64_t*>(m->d_scratch);
+    uint32_t* d_paths = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(m->d_scratch) + cb);
+    HIPCHK(m, hipMemcpyAsync(d_cols, cols, (size_t)n * 8, hipMemcpyHostToDevice, nullptr));
+    if ((rc = open_columns_device(m, d_cols, n, reinterpret_cast<uint32_t*>(x.send_dev), paths ? d_paths : nullptr, nullptr))) return rc;
+    if (paths && c->path_len) HIPCHK(m, hipMemcpyAsync(paths, d_paths, (size_t)n * c->path_len * 32, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(m, hipStreamSynchronize(nullptr));
+  }
+  if (x.fn(x.user, bytes) != 0) return LCPC_ERR_XCHG;
+  std::vector<uint8_t> all((size_t)G * bytes);
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    HIPCHK(m, hipSetDevice(c->prm.device));
+    HIPCHK(m, hipMemcpy(all.data(), x.recv_dev, all.size(), hipMemcpyDeviceToHost));
+  }
+  for (uint32_t g = 0; g < G; g++) {
+    const uint64_t nr_g = re[g] - rb[g];
+    for (uint32_t k = 0; k < n && nr_g; k++)       // rank g's block: [k][its rows], contiguous
+      memcpy(reinterpret_cast<uint8_t*>(vals) + ((size_t)k * m->n_rows + rb[g]) * eb, &all[(size_t)g * bytes + (size_t)k * nr_g * eb], nr_g * eb);
+  }
+  return 0;
+}
+
+// ---- sharded commit phases ----------------------------------------------------------------------------------
+// phase 1: local rows -> comm -> node chaining values at nodes_dev[k][col]
+static int commit_shard_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, hipStream_t st, uint32_t flags,
+                              uint8_t* nodes_dev) {
+  const lcpc_ctx* c = m->enc;
+  uint64_t rb, re, cb, ce, nch;
+  shard_layout_of(c, c->prm.shard_rank, n_rows_total, &rb, &re, &cb, &ce, &nch);
+  m->committed = false;
+  m->comm_t = false; m->comm_rows_valid = false; m->coeffs_view = nullptr;
+  m->n_rows = n_rows_total; m->row_begin = rb; m->n_rows_local = re - rb;
+  m->chunk_begin = cb; m->chunk_end = ce; m->n_chunks = nch;
+  m->launches[0] = m->launches[1] = m->launches[2] = 0;
+  const bool fused = c->prm.encoding == LCPC_ENC_LIGERO || m->n_rows_local >= 16;
+  const bool borrow = (flags & LCPC_COMMIT_BORROW_COEFFS) != 0 && m->n_rows_local > 0;   // local rows are always whole rows
+  int rc = ensure_commit_buffers(m, m->n_rows_local, !borrow);
+  if (rc) return rc;
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[0], st));
+  if (m->n_rows_local) {
+    if (!coeffs_local) return LCPC_ERR_ARG;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(coeffs_local);
+    EncodeJob j;
+    j.src_stride = c->n_per_row; j.n_valid = c->n_per_row; j.dst = m->d_comm; j.n_rows = m->n_rows_local;
+    j.canon_out = c->comm_canon; j.keep_t = true;
+    bool kept = false;
+    j.kept_t = &kept;
+    if (borrow) {
+      j.src = src;
+      m->coeffs_view = src;
+    } else if (fused) {
+      j.src = src; j.copy_dst = m->d_coeffs;       // coeffs copy fused into the first pass / the input transpose
+      m->coeffs_view = m->d_coeffs;
+    } else {
+      HIPCHK(m, hipMemcpyAsync(m->d_coeffs, coeffs_local, (size_t)m->n_rows_local * c->n_per_row * elem_bytes(c), hipMemcpyDeviceToDevice, st));
+      j.src = m->d_coeffs;
+      m->coeffs_view = m->d_coeffs;
+    }
+    if ((rc = encode_rows_device(c, &m->ws, j, st, &m->err, &m->launches[0]))) return rc;
+    m->comm_t = kept;
+  } else {
+    m->coeffs_view = m->d_coeffs;
+  }
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[1], st));
+  if (ce > cb) {
+    uint64_t first[64];
+    uint32_t lg[64];
+    const int n_nodes = shard_nodes(cb, ce, first, lg);
+    bool all_single = true;
+    for (int k = 0; k < n_nodes; k++) all_single = all_single && lg[k] == 0;
+    LeafArgs la{};
+    la.comm = m->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.col_stride = 1; la.n_cols = c->n_cols; la.row_base = (int64_t)rb;
+    if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = 0; la.row_stride = 1; la.col_stride = m->n_rows_local; }
+    la.n_rows_total = n_rows_total; la.chunk_begin = (uint32_t)cb; la.n_chunks_local = (uint32_t)(ce - cb);
+    la.n_chunks_total = (uint32_t)nch;
+    if (all_single) {                       // nothing to pre-merge: chunk CVs are the nodes
+      la.out = reinterpret_cast<uint32_t*>(nodes_dev);
+      HIPCHK(m, launch_leaf_chunks(c->NL, la, st));
+      m->launches[1]++;
+    } else {
+      if ((rc = ensure_cvs(m, ce - cb))) return rc;
+      la.out = m->d_cvs;
+      HIPCHK(m, launch_leaf_chunks(c->NL, la, st));
+      m->launches[1]++;
+      for (int k = 0; k < n_nodes; k++) {   // one subtree CV per aligned block of chunks
+        uint32_t* blk = m->d_cvs + (first[k] - cb) * c->n_cols * 8;
+        uint32_t* out = reinterpret_cast<uint32_t*>(nodes_dev) + (size_t)k * c->n_cols * 8;
+        HIPCHK(m, launch_leaf_finish_nodes(blk, nullptr, nullptr, 1u << lg[k], c->n_cols, out, false, st));
+        m->launches[1]++;
+      }
+    }
+  }
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], st));
+  return 0;
+}
+
+// phase 2: gathered node CVs -> leaf digests -> Merkle tree.  Slot of rank g's node k in `gathered`: padded layout
+// (slots_per_rank > 0) g * slots_per_rank + k; compact layout (slots_per_rank == 0, the native exchange) g for k = 0 and
+// G + (running index over ranks of their nodes k >= 1) otherwise
+static int commit_finish_phase(lcpc_commit_t* m, uint8_t* gathered, uint64_t n_rows_total, uint32_t slots_per_rank, hipStream_t st, uint8_t* root) {
+  const lcpc_ctx* c = m->enc;
+  const uint64_t nch = leaf_chunks(c, n_rows_total);
+  const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
+  // node table over all ranks, in chunk order: slot in the gathered buffer + log2(size); cached per shape
+  const uint64_t key = (nch << 24) ^ ((uint64_t)slots_per_rank << 8) ^ G;
+  if (!m->d_node_tab || m->node_tab_key != key) {
+    m->node_slot_h.clear(); m->node_log_h.clear();
+    uint32_t extra = G;
+    for (uint32_t r = 0; r < G; r++) {
+      uint64_t first[64];
+      uint32_t lg[64];
+      const int n = shard_nodes(nch * r / G, nch * (r + 1) / G, first, lg);
+      if (slots_per_rank && (uint32_t)n > slots_per_rank) return LCPC_ERR_ARG;
+      for (int k = 0; k < n; k++) {
+        m->node_slot_h.push_back(slots_per_rank ? r * slots_per_rank + (uint32_t)k : (k == 0 ? r : extra++));
+        m->node_log_h.push_back(lg[k]);
+      }
+    }
+    const uint32_t nn = (uint32_t)m->node_slot_h.size();
+    dev_free(m->d_node_tab);
+    m->d_node_tab = nullptr;
+    int rc = dev_alloc(&m->err, &m->d_node_tab, (size_t)nn * 8);
+    if (rc) return rc;
+    HIPCHK(m, hipMemcpyAsync(m->d_node_tab, m->node_slot_h.data(), nn * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(m, hipMemcpyAsync(m->d_node_tab + nn, m->node_log_h.data(), nn * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(m, hipStreamSynchronize(st));      // one-off per shape (pageable sources)
+    m->node_tab_key = key;
+  }
+  const uint32_t n_nodes = (uint32_t)m->node_slot_h.size();
+  if (nch == 1) {   // single-chunk message: the one "node" already carries ROOT (leaf_chunk_kernel)
+    HIPCHK(m, hipMemcpyAsync(m->d_hashes, gathered + (size_t)m->node_slot_h[0] * c->n_cols * 32, (size_t)c->n_cols * 32, hipMemcpyDeviceToDevice, st));
+  } else {
+    HIPCHK(m, launch_leaf_finish_nodes(reinterpret_cast<uint32_t*>(gathered), m->d_node_tab, m->d_node_tab + n_nodes, n_nodes, c->n_cols,
+                                       m->d_hashes, true, st));
+    m->launches[1]++;
+  }
+  int rc = merkle_top(m, st);
+  if (rc) return rc;
+  if (m->timing) {
+    HIPCHK(m, hipEventRecord(m->ev[3], st));
+    HIPCHK(m, hipEventSynchronize(m->ev[3]));
+    (void)hipEventElapsedTime(&m->last.encode_ms, m->ev[0], m->ev[1]);
+    (void)hipEventElapsedTime(&m->last.hash_ms, m->ev[1], m->ev[2]);
+    (void)hipEventElapsedTime(&m->last.merkle_ms, m->ev[2], m->ev[3]);   // includes the exchange
+    (void)hipEventElapsedTime(&m->last.total_ms, m->ev[0], m->ev[3]);
+    m->last.encode_launches = m->launches[0]; m->last.hash_launches = m->launches[1]; m->last.merkle_launches = m->launches[2];
+  }
+  m->committed = true;
+  if (root) {
+    HIPCHK(m, hipMemcpyAsync(root, m->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(m, hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
+}  // namespace lcpc
+
+extern "C" {
+
+int lcpc_shard_layout(const lcpc_ctx* c, uint64_t n_rows_total, uint64_t* rb, uint64_t* re, uint64_t* cb, uint64_t* ce, uint64_t* nch) {
+  if (!c || n_rows_total == 0) return LCPC_ERR_ARG;
+  uint64_t a, b, x, y, z;
+  shard_layout_of(c, c->prm.shard_rank, n_rows_total, &a, &b, &x, &y, &z);
+  if (rb) *rb = a;
+  if (re) *re = b;
+  if (cb) *cb = x;
+  if (ce) *ce = y;
+  if (nch) *nch = z;
+  return 0;
+}
+
+int lcpc_shard_nodes(uint64_t n_chunks, uint32_t G, uint32_t g, uint32_t* n_nodes, uint64_t* first, uint32_t* lg) {
+  if (!n_nodes || !first || !lg || n_chunks == 0) return LCPC_ERR_ARG;
+  if (G <= 1) { G = 1; g = 0; }
+  if (g >= G) return LCPC_ERR_ARG;
+  *n_nodes = (uint32_t)shard_nodes(n_chunks * g / G, n_chunks * (g + 1) / G, first, lg);
+  return 0;
+}
+
+int lcpc_commit_shard_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint32_t flags,
+                             uint8_t* nodes_dev) {
+  if (!m || n_rows_total == 0 || !nodes_dev) return LCPC_ERR_ARG;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  return commit_shard_phase(m, coeffs_local, n_rows_total, (hipStream_t)stream, flags, nodes_dev);
+  LCPC_CATCH(m)
+}
+
+int lcpc_commit_finish_device(lcpc_commit_t* m, uint8_t* gathered, uint64_t n_rows_total, uint32_t slots_per_rank, void* stream, uint8_t* root) {
+  if (!m || !gathered || n_rows_total != m->n_rows || slots_per_rank == 0) return LCPC_ERR_ARG;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  return commit_finish_phase(m, gathered, n_rows_total, slots_per_rank, (hipStream_t)stream, root);
+  LCPC_CATCH(m)
+}
+
+// ---- native exchange (RCCL) -------------------------------------------------------------------------------
+int lcpc_comm_unique_id(uint8_t id[128]) {
+  if (!id) return LCPC_ERR_ARG;
+  if (!rccl().ok) return LCPC_ERR_NO_RCCL;
+  NcclUniqueId u;
+  if (rccl().GetUniqueId(&u) != 0) return LCPC_ERR_XCHG;
+  memcpy(id, u.internal, 128);
+  return 0;
+}
+
+int lcpc_comm_init(lcpc_ctx* c, const uint8_t id[128], uint32_t rank, uint32_t world) {
+  if (!c || !id || world == 0 || rank >= world) return LCPC_ERR_ARG;
+  const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
+  if (world != G || rank != (G > 1 ? c->prm.shard_rank : 0)) return LCPC_ERR_ARG;
+  if (!rccl().ok) return LCPC_ERR_NO_RCCL;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  comm_release(c);
+  NcclUniqueId u;
+  memcpy(u.internal, id, 128);
+  void* comm = nullptr;
+  const int rc = rccl().CommInitRank(&comm, (int)world, u, (int)rank);
+  if (rc != 0) return fail_nccl(&c->err, rc, "ncclCommInitRank");
+  c->comm = comm;
+  return 0;
+}
+
+int lcpc_comm_destroy(lcpc_ctx* c) {
+  if (!c) return LCPC_ERR_ARG;
+  std::lock_guard<std::mutex> g(c->mu);
+  (void)hipSetDevice(c->prm.device);
+  comm_release(c);
+  return 0;
+}
+
+int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint32_t flags, uint8_t* root) {
+  if (!m || n_rows_total == 0) return LCPC_ERR_ARG;
+  lcpc_ctx* c = m->enc;
+  if (!c->comm) return LCPC_ERR_STATE;             // lcpc_comm_init first
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
+  const uint32_t me = G > 1 ? c->prm.shard_rank : 0;
+  const uint64_t nch = leaf_chunks(c, n_rows_total);
+  // one slot = n_cols chaining values.  What crosses the wire: node 0 of every rank (one all-gather of one slot each)
+  // plus the few second / third nodes some ranks own (one broadcast each: at the headline only the last rank has one),
+  // instead of padding every rank to the largest node count.
+  // [ this rank's nodes ][ gathered: G slots of node 0, then the extra nodes in rank order ]
+  uint32_t n_nodes_of[256], extras = 0, my_slots = 1;
+  if (G > 256) return LCPC_ERR_ARG;
+  for (uint32_t r = 0; r < G; r++) {
+    uint64_t first[64];
+    uint32_t lg[64];
+    n_nodes_of[r] = (uint32_t)shard_nodes(nch * r / G, nch * (r + 1) / G, first, lg);
+    if (n_nodes_of[r] > 1) extras += n_nodes_of[r] - 1;
+    if (r == me && n_nodes_of[r] > 1) my_slots = n_nodes_of[r];
+  }
+  const uint64_t slot_bytes = c->n_cols * 32;
+  int rc = ensure_dev(&m->err, &m->d_gather, &m->gather_cap, slot_bytes * ((uint64_t)my_slots + G + extras));
+  if (rc) return rc;
+  uint8_t* send = m->d_gather;
+  uint8_t* recv = m->d_gather + slot_bytes * my_slots;
+  if ((rc = commit_shard_phase(m, coeffs_local, n_rows_total, st, flags, send))) return rc;
+  int nrc = rccl().GroupStart();
+  if (nrc == 0) nrc = rccl().AllGather(send, recv, (size_t)slot_bytes, NCCL_UINT8, c->comm, st);
+  uint32_t x = G;
+  for (uint32_t r = 0; r < G && nrc == 0; r++)
+    for (uint32_t k = 1; k < n_nodes_of[r] && nrc == 0; k++, x++) {
+      uint8_t* dst = recv + slot_bytes * x;
+      nrc = rccl().Broadcast(r == me ? send + slot_bytes * k : dst, dst, (size_t)slot_bytes, NCCL_UINT8, (int)r, c->comm, st);
+    }
+  const int erc = rccl().GroupEnd();
+  if (nrc == 0) nrc = erc;
+  if (nrc != 0) return fail_nccl(&m->err, nrc, "ncclAllGather / ncclBroadcast");
+  return commit_finish_phase(m, recv, n_rows_total, 0, st, root);
+  LCPC_CATCH(m)
+}
+
+uint64_t lcpc_prove_sharded_bytes(const lcpc_ctx* c, uint64_t n_rows_total) {
+  if (!c || n_rows_total == 0) return 0;
+  const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
+  uint64_t max_rows = 0;
+  for (uint32_t g = 0; g < G; g++) {
+    uint64_t rb, re, cb, ce, nch;
+    shard_layout_of(c, g, n_rows_total, &rb, &re, &cb, &ce, &nch);
+    max_rows = std::max(max_rows, re - rb);
+  }
+  const uint64_t eb = elem_bytes(c);
+  return std::max<uint64_t>(2 * c->n_per_row * eb, lcpc_get_n_col_opens(c) * max_rows * eb);
+}
+
+int lcpc_prove_sharded(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t* send_dev, uint8_t* recv_dev,
+                       uint64_t max_bytes, lcpc_allgather_fn fn, void* user, uint8_t** proof, uint64_t* proof_len,
+                       uint64_t* cols_opened) {
+  if (!m || !send_dev || !recv_dev || !fn) return LCPC_ERR_ARG;
+  if (m->enc->prm.shard_count <= 1) return LCPC_ERR_STATE;
+  if (m->committed && max_bytes < lcpc_prove_sharded_bytes(m->enc, m->n_rows)) return LCPC_ERR_ARG;
+  LCPC_TRY
+  const ShardXchg x{send_dev, recv_dev, max_bytes, fn, user};
+  return prove_impl(m, outer, n_outer, trw, proof, proof_len, cols_opened, &x);
+  LCPC_CATCH(m)
+}
+
+int lcpc_prove_sharded_rccl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t** proof,
+                            uint64_t* proof_len, uint64_t* cols_opened) {
+  if (!m) return LCPC_ERR_ARG;
+  lcpc_ctx* c = m->enc;
+  if (!c->comm || !m->committed) return LCPC_ERR_STATE;
+  LCPC_TRY
+  const uint64_t nb = lcpc_prove_sharded_bytes(c, m->n_rows);
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    HIPCHK(m, hipSetDevice(c->prm.device));
+    if (nb > m->xchg_cap || !m->d_xsend) {
+      dev_free(m->d_xsend); dev_free(m->d_xrecv);
+      m->d_xsend = m->d_xrecv = nullptr; m->xchg_cap = 0;
+      int rc = dev_alloc(&m->err, &m->d_xsend, (size_t)nb);
+      if (!rc) rc = dev_alloc(&m->err, &m->d_xrecv, (size_t)nb * std::max<uint32_t>(1, c->prm.shard_count));
+      if (rc) return rc;
+      m->xchg_cap = nb;
+    }
+  }
+  const ShardXchg x{m->d_xsend, m->d_xrecv, m->xchg_cap, rccl_allgather_cb, m};
+  return prove_impl(m, outer, n_outer, trw, proof, proof_len, cols_opened, &x);
+  LCPC_CATCH(m)
+}
+
+}  // extern "C"

@@ -49,58 +49,118 @@ def slots_per_rank(n_chunks, world):
     return max(1, max(len(aligned_nodes(b, e)) for b, e in chunk_split(n_chunks, world)))
 
 
+_xchg_cache = {}
+
+
 def exchange_nodes(local_nodes, n_chunks_total, group=None):
     """all-gather of per-rank [k_g, n_cols, 32] uint8 node CVs, padded to `slots` per rank; returns the raw
-    gather buffer [world * slots, n_cols, 32] (rank g's nodes at rows g*slots ...) and `slots`."""
+    gather buffer [world * slots, n_cols, 32] (rank g's nodes at rows g*slots ...) and `slots`.  The pad / gather
+    buffers are allocated once per shape and reused (the finish phase clobbers the gather buffer, nothing keeps it)."""
     world = dist.get_world_size(group)
     slots = slots_per_rank(n_chunks_total, world)
     n_cols = local_nodes.shape[1]
-    if local_nodes.shape[0] == slots:
-        pad = local_nodes.contiguous()
+    key = (world, slots, n_cols, str(local_nodes.device), dist.get_backend(group))
+    bufs = _xchg_cache.get(key)
+    if bufs is None:
+        _xchg_cache.clear()
+        host = local_nodes.is_cuda and dist.get_backend(group) == "gloo"
+        bufs = {"pad": torch.zeros((slots, n_cols, 32), dtype=torch.uint8, device=local_nodes.device),
+                "flat": torch.empty((world * slots, n_cols, 32), dtype=torch.uint8, device=local_nodes.device),
+                "host": torch.empty((world * slots, n_cols, 32), dtype=torch.uint8) if host else None}
+        _xchg_cache[key] = bufs
+    if local_nodes.shape[0] == slots and local_nodes.is_contiguous():
+        pad = local_nodes
     else:
-        pad = torch.zeros((slots, n_cols, 32), dtype=torch.uint8, device=local_nodes.device)
+        pad = bufs["pad"]
         pad[:local_nodes.shape[0]] = local_nodes
-    if dist.get_backend(group) == "gloo" and pad.is_cuda:
+    flat = bufs["flat"]
+    if bufs["host"] is not None:
         # debugging path (several ranks sharing one GPU, where RCCL refuses duplicate devices): stage through host
-        host = torch.empty((world * slots, n_cols, 32), dtype=torch.uint8)
-        dist.all_gather_into_tensor(host, pad.cpu(), group=group)
-        flat = host.to(local_nodes.device)
+        dist.all_gather_into_tensor(bufs["host"], pad.cpu(), group=group)
+        flat.copy_(bufs["host"])
     else:
-        flat = torch.empty((world * slots, n_cols, 32), dtype=torch.uint8, device=local_nodes.device)
         dist.all_gather_into_tensor(flat, pad, group=group)  # rank g's block lands at rows [g*slots, (g+1)*slots)
     return flat, slots
 
 
 class HipShardEngine:
-    """product engine: lcpc_commit_shard_device / lcpc_commit_finish_device of include/lcpc_hip.h."""
+    """product engine: one sharded encoder context + one LcCommit object (include/lcpc_hip.h).  Two exchange modes:
+    `commit_shard` / `commit_finish` around a caller-side all-gather (torch.distributed; gloo in the CPU tests), or, after
+    `comm_init`, `commit_native`: shard -> ncclAllGather -> finish inside the library on one stream."""
 
     def __init__(self, enc):
+        from . import LcCommit
         self.enc = enc
+        self.cm = LcCommit(enc)
         self.rank, self.world = enc.params.shard_rank, max(1, enc.params.shard_count)
+        self._layout = {}
+        self._nodes = None
 
     def layout(self, n_rows_total):
-        v = [C.c_uint64() for _ in range(5)]
-        self.enc._check(_lib.lib().lcpc_shard_layout(self.enc._h, n_rows_total, *[C.byref(x) for x in v]))
-        return tuple(x.value for x in v)
+        if n_rows_total not in self._layout:
+            v = [C.c_uint64() for _ in range(5)]
+            self.enc._check(_lib.lib().lcpc_shard_layout(self.enc._h, n_rows_total, *[C.byref(x) for x in v]))
+            self._layout[n_rows_total] = tuple(x.value for x in v)
+        return self._layout[n_rows_total]
 
-    def commit_shard(self, local_coeffs, n_rows_total):
+    def commit_shard(self, local_coeffs, n_rows_total, borrow=False):
         rb, re, cb, ce, _ = self.layout(n_rows_total)
         n_nodes = len(aligned_nodes(cb, ce))
-        nodes = torch.empty((n_nodes, self.enc.n_cols, 32), dtype=torch.uint8, device=local_coeffs.device)
+        if self._nodes is None or self._nodes.shape[0] != max(n_nodes, 1) or self._nodes.device != local_coeffs.device:
+            # (a rank that owns no chunk still passes a valid, unused, output pointer)
+            self._nodes = torch.empty((max(n_nodes, 1), self.enc.n_cols, 32), dtype=torch.uint8, device=local_coeffs.device)
         st = torch.cuda.current_stream().cuda_stream
         ptr = local_coeffs.data_ptr() if re > rb else None
-        # a rank that owns no chunk still passes a valid (unused) output pointer
-        out = nodes if nodes.numel() else torch.zeros(64, dtype=torch.uint8, device=local_coeffs.device)
-        self.enc._check(_lib.lib().lcpc_commit_shard_device(self.enc._h, C.c_void_p(ptr), n_rows_total, C.c_void_p(st),
-                                                            C.c_void_p(out.data_ptr())))
-        return nodes
+        self.cm._check(_lib.lib().lcpc_commit_shard_device(self.cm._h, C.c_void_p(ptr), n_rows_total, C.c_void_p(st),
+                                                           1 if borrow else 0, C.c_void_p(self._nodes.data_ptr())))
+        return self._nodes[:n_nodes]
 
     def commit_finish(self, gathered, n_rows_total, slots, want_root=True):
         st = torch.cuda.current_stream().cuda_stream
         root = (C.c_uint8 * 32)() if want_root else None
-        self.enc._check(_lib.lib().lcpc_commit_finish_device(self.enc._h, C.c_void_p(gathered.data_ptr()), n_rows_total, slots,
-                                                             C.c_void_p(st), root))
+        self.cm._check(_lib.lib().lcpc_commit_finish_device(self.cm._h, C.c_void_p(gathered.data_ptr()), n_rows_total, slots,
+                                                            C.c_void_p(st), root))
+        if want_root:
+            self.cm._refresh()
         return bytes(root) if want_root else None
+
+    # ---- native RCCL exchange (lcpc_comm_init / lcpc_commit_sharded_device / lcpc_prove_sharded_rccl) ----
+    def comm_init(self, group=None):
+        """bring up the library's own RCCL communicator: rank 0 draws an ncclUniqueId, torch.distributed carries the 128
+        bytes to the other ranks (control plane only), every rank calls lcpc_comm_init."""
+        lib = _lib.lib()
+        idb = (C.c_uint8 * 128)()
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if rank == 0:
+            self.enc._check(lib.lcpc_comm_unique_id(idb))
+        if world > 1:
+            box = [bytes(idb)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            idb = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        self.enc._check(lib.lcpc_comm_init(self.enc._h, idb, rank, world))
+
+    def commit_native(self, local_coeffs, n_rows_total, want_root=True, borrow=False):
+        rb, re, _, _, _ = self.layout(n_rows_total)
+        st = torch.cuda.current_stream().cuda_stream
+        root = (C.c_uint8 * 32)() if want_root else None
+        ptr = local_coeffs.data_ptr() if re > rb else None
+        self.cm._check(_lib.lib().lcpc_commit_sharded_device(self.cm._h, C.c_void_p(ptr), n_rows_total, C.c_void_p(st),
+                                                             1 if borrow else 0, root))
+        if want_root:
+            self.cm._refresh()
+        return bytes(root) if want_root else None
+
+    def prove_native(self, outer_tensor, tr):
+        import numpy as np
+        t = np.ascontiguousarray(outer_tensor, np.uint64).reshape(-1, self.enc.L)
+        pp, plen = C.c_void_p(), C.c_uint64()
+        cols = np.zeros(self.enc.get_n_col_opens(), np.uint64)
+        self.cm._check(_lib.lib().lcpc_prove_sharded_rccl(self.cm._h, t.ctypes.data_as(C.c_void_p), t.shape[0], tr._h, C.byref(pp),
+                                                          C.byref(plen), cols.ctypes.data_as(C.c_void_p)))
+        data = C.string_at(pp, plen.value)
+        _lib.lib().lcpc_free(pp)
+        return data, cols
 
 
 def allgather_bytes(send, recv, nbytes, group=None):
@@ -118,12 +178,13 @@ def allgather_bytes(send, recv, nbytes, group=None):
         torch.cuda.synchronize()
 
 
-def sharded_prove(enc, outer_tensor, tr, group=None, allgather=None):
-    """LcCommit::prove on the row-sharded commitment held by `enc`'s context (lcpc_prove_sharded).  Collective: every
+def sharded_prove(engine, outer_tensor, tr, group=None, allgather=None):
+    """LcCommit::prove on the row-sharded commitment held by `engine` (lcpc_prove_sharded).  Collective: every
     rank calls it with the same outer_tensor (n_rows_total x L) and an identical transcript; returns (proof bytes,
     opened columns), identical on every rank.  `allgather(send, recv, nbytes)` defaults to torch.distributed."""
     import numpy as np
     lib = _lib.lib()
+    enc, cm = engine.enc, engine.cm
     t = np.ascontiguousarray(outer_tensor, np.uint64).reshape(-1, enc.L)
     world = max(1, enc.params.shard_count)
     nb = int(lib.lcpc_prove_sharded_bytes(enc._h, t.shape[0]))
@@ -144,12 +205,12 @@ def sharded_prove(enc, outer_tensor, tr, group=None, allgather=None):
     fn = _lib.ALLGATHER_FN(cb)
     pp, plen = C.c_void_p(), C.c_uint64()
     cols = np.zeros(enc.get_n_col_opens(), np.uint64)
-    rc = lib.lcpc_prove_sharded(enc._h, t.ctypes.data_as(C.c_void_p), t.shape[0], tr._h, C.c_void_p(send.data_ptr()),
+    rc = lib.lcpc_prove_sharded(cm._h, t.ctypes.data_as(C.c_void_p), t.shape[0], tr._h, C.c_void_p(send.data_ptr()),
                                 C.c_void_p(recv.data_ptr()), send.numel(), fn, None, C.byref(pp), C.byref(plen),
                                 cols.ctypes.data_as(C.c_void_p))
     if err:
         raise err[0]
-    enc._check(rc)
+    cm._check(rc)
     data = C.string_at(pp, plen.value)
     lib.lcpc_free(pp)
     return data, cols

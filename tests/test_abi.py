@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "missing export: " + s
     assert sorted(_lib.SYMBOLS) == syms, "ctypes table and header disagree"
-    assert L.lcpc_abi_version() == 1
+    assert L.lcpc_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_no_cpu_fallback():
@@ -37,12 +37,34 @@ def test_no_cpu_fallback():
 
 
 def test_product_never_imports_oracle():
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "lcpc_amd")):
-        for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h")):
+    """the product (lcpc_amd/, include/) must not import, link, load or even name the CPU oracle: no file mentions it,
+    no Python module imports anything outside the package / stdlib / numpy / torch, and the shared library neither
+    needs nor dlopen()s it."""
+    import ast
+    import subprocess
+    allowed_mods = {"ctypes", "os", "subprocess", "numpy", "torch", "lcpc_amd", ""}
+    for top in ("lcpc_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if not f.endswith((".py", ".cpp", ".hip", ".h", ".c")) and f != "Makefile":
+                    continue
                 txt = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in txt.replace("no CPU fallback", "") or f == "_lib.py" or "imports oracle" in txt, f
-                assert "lcpc_oracle" not in txt and "pyref" not in txt, f
+                for word in ("oracle", "pyref", "tests/golden"):
+                    assert word not in txt.lower(), "%s mentions %r" % (f, word)
+                if f.endswith(".py"):
+                    for node in ast.walk(ast.parse(txt)):
+                        mods = []
+                        if isinstance(node, ast.Import):
+                            mods = [a.name for a in node.names]
+                        elif isinstance(node, ast.ImportFrom):
+                            mods = [node.module or ""] if node.level == 0 else []
+                        for m in mods:
+                            assert m.split(".")[0] in allowed_mods, "%s imports %s" % (f, m)
+    out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert needed and not any("oracle" in n for n in needed), needed
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"liblcpc_oracle" not in blob and b"lcpc_oracle" not in blob
 
 
 def test_static_dims_match_oracle(oracle):

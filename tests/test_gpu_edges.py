@@ -102,9 +102,12 @@ def test_state_and_argument_errors(oracle):
     O = oracle
     E = lcpc_amd.LcpcError
     enc = LigeroEncoding.new_from_dims(0, 64, 128)
-    with pytest.raises(E) as e:                                  # no commitment yet
-        LcCommit(enc)
-    assert e.value.code == lcpc_amd.ERR_STATE
+    empty = LcCommit(enc)                                        # lcpc_commit_create: bound to enc, nothing committed yet
+    for call in (empty.get_root, empty.hashes, lambda: empty.open_columns([0]),
+                 lambda: empty.prove(O.random_elems(0, 1, 2), enc, Transcript(b"t"))):
+        with pytest.raises(E) as e:
+            call()
+        assert e.value.code == lcpc_amd.ERR_STATE
     with pytest.raises(E) as e:                                  # empty input (the reference asserts n_rows >= 1, lib.rs:630-631)
         LcCommit.commit(np.zeros((0, 1), np.uint64), enc)
     assert e.value.code == lcpc_amd.ERR_ARG

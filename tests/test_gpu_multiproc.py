@@ -1,7 +1,9 @@
-"""Row-sharded commit + prove with REAL process groups on the GPU box: `world` processes (one shard context each,
-all on GPU 0 because the test box has one GPU; gloo carries the exchange since RCCL refuses duplicate devices) run
-lcpc_amd.distributed.sharded_commit and sharded_prove through torch.distributed, and every rank must end with the
-oracle's root and the oracle's proof bytes.  On an 8-GPU node the same code runs with backend "nccl" (bench.py)."""
+"""Row-sharded commit + prove with REAL process groups on the GPU box: `world` processes, one shard context each.
+With fewer GPUs than ranks (the test box has one) all ranks share GPU 0 and gloo carries the exchange, since RCCL refuses
+duplicate devices: lcpc_amd.distributed.sharded_commit / sharded_prove through torch.distributed.  With >= `world`
+GPUs visible every rank takes its own GPU, the process group is "nccl" and the commit + prove additionally run through
+the library's native RCCL exchange (lcpc_comm_init / lcpc_commit_sharded_device / lcpc_prove_sharded_rccl).  Either
+way every rank must end with the oracle's root and the oracle's proof bytes."""
 import os
 import socket
 
@@ -28,21 +30,32 @@ def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    real = torch.cuda.device_count() >= world          # one GPU per rank: RCCL; else all ranks on GPU 0 over gloo
+    dev = rank if real else 0
+    torch.cuda.set_device(dev)
+    if real:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import oracle_lib as O
         from common import mk_transcript
         from lcpc_amd import LigeroEncoding, Transcript
         from lcpc_amd.distributed import HipShardEngine, sharded_commit, sharded_prove
-        torch.cuda.set_device(0)
-        enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=0, shard=(rank, world))
+        enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=dev, shard=(rank, world))
         eng = HipShardEngine(enc)
         rb, re, _, _, _ = eng.layout(n_rows)
         coeffs = O.random_elems(fid, n_rows * n_per_row, 41).reshape(n_rows, n_per_row, -1)
         local = torch.from_numpy(coeffs[rb:re].copy().view(np.int64)).cuda()
         root = sharded_commit(eng, local, n_rows)
         outer = O.random_elems(fid, n_rows, 43)
-        proof, cols = sharded_prove(enc, outer, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+        proof, cols = sharded_prove(eng, outer, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+        if real:      # the same through the library's own communicator
+            eng.comm_init()
+            root2 = eng.commit_native(local, n_rows)
+            proof2, _ = eng.prove_native(outer, mk_transcript(Transcript, root2, enc.get_n_col_opens()))
+            if root2 != root or proof2 != proof:
+                raise RuntimeError("native RCCL exchange disagrees with the torch.distributed exchange")
         q.put((rank, root, proof))
     except Exception as e:      # surface the failure instead of a queue timeout
         q.put((rank, repr(e), b""))

@@ -295,15 +295,52 @@ def test_commit_is_codeword(oracle):
     assert nat[:c.n_per_row] == O.to_canon_ints(0, c.eval_outer(tensor))
 
 
-def test_recommit_same_context(oracle):
-    """a context is reusable: a second commit of different length replaces the first (bench loop pattern)."""
+def test_recommit_same_object(oracle):
+    """an LcCommit object is refillable: a second commit of different length replaces the first and reuses its buffers
+    (bench loop pattern); a failed refill leaves the object empty, not half-updated."""
     O = oracle
     enc = LigeroEncoding.new_from_dims(3, 256, 512)
     oenc = O.Encoding.ligero_from_dims(3, 256, 512)
+    c = None
     for n in (256 * 9, 256 * 3 - 5, 256 * 20 + 1):
         coeffs = O.random_elems(3, n, n & 0xff)
-        c = LcCommit.commit(coeffs, enc)
+        c = LcCommit.commit(coeffs, enc, into=c)
         assert c.get_root() == O.Commit.commit(coeffs, oenc).get_root()
+    with pytest.raises(lcpc_amd.LcpcError):
+        LcCommit.commit(np.zeros((0, 4), np.uint64), enc, into=c)
+
+
+def test_two_live_commitments_one_encoder(oracle):
+    """lcpc-2d/src/lib.rs:299-311: commit() borrows `&E` and returns an owned LcCommit, so one encoder serves many live
+    commitments.  Two polynomials under ONE encoder context (one twiddle table), proved alternately, each against the
+    oracle; then the encoder handle is dropped first and the commitments keep working (they hold a reference)."""
+    O = oracle
+    for kind, fid in (("ligero", 3), ("sdig", 3), ("ligero", 0)):
+        if kind == "ligero":
+            enc, oenc = LigeroEncoding.new_from_dims(fid, 1024, 2048), O.Encoding.ligero_from_dims(fid, 1024, 2048)
+        else:
+            enc, oenc = SdigEncoding.new(fid, 40000, 5), O.Encoding.sdig(fid, 40000, 5)
+        na, nb = enc.n_per_row * 20 - 3, enc.n_per_row * 33
+        a, b = O.random_elems(fid, na, 1), O.random_elems(fid, nb, 2)
+        ca, cb = LcCommit.commit(a, enc), LcCommit.commit(b, enc)
+        oa, ob = O.Commit.commit(a, oenc), O.Commit.commit(b, oenc)
+        assert ca.get_root() == oa.get_root() and cb.get_root() == ob.get_root()
+        assert ca.n_rows == 20 and cb.n_rows == 33
+        for rnd in range(2):
+            for c, oc in ((ca, oa), (cb, ob), (ca, oa)):
+                t = O.random_elems(fid, c.n_rows, 10 + rnd)
+                root = c.get_root()
+                pf = c.prove(t, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+                opf, _ = oc.prove(t, oenc, mk_transcript(O.Transcript, root, enc.get_n_col_opens()))
+                assert pf.to_bytes() == opf
+        assert (ca.hashes() == oa.hashes()).all() and (cb.comm(1, 2) == ob.comm()[cb.n_cols:3 * cb.n_cols]).all()
+        n_open = enc.get_n_col_opens()
+        del enc                                  # lcpc_ctx_destroy: the commitments keep the tables alive
+        cols = [0, 7, ca.n_cols - 1]
+        va, _ = ca.open_columns(cols)
+        oa_comm = oa.comm().reshape(ca.n_rows, ca.n_cols, -1)
+        assert (va == oa_comm[:, cols].transpose(1, 0, 2)).all()
+        assert n_open > 0
 
 
 @pytest.mark.parametrize("kind,fid,n,rho", [("ligero", 3, 20000, (1, 4)), ("ligero", 0, 3001, (38, 39)), ("ligero", 1, 12345, (1, 2)),

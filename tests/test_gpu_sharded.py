@@ -54,7 +54,7 @@ def test_sharded_equals_unsharded(oracle, fid, n_rows, n_per_row, n_cols, G):
         assert r == ref.get_root()
     # every rank ends with the full hashes array; its comm holds exactly its own rows
     for g, eng in enumerate(engines):
-        c = LcCommit(eng.enc)
+        c = eng.cm
         assert (c.hashes() == ref.hashes()).all()
         rb, re, _, _, _ = eng.layout(n_rows)
         if re > rb:
@@ -83,7 +83,7 @@ def test_sharded_brakedown_equals_unsharded(oracle, fid, n_per_row, n_rows, G):
     for r in roots:
         assert r == oc.get_root()
     for eng in engines:
-        c = LcCommit(eng.enc)
+        c = eng.cm
         assert (c.hashes() == oc.hashes()).all()
         rb, re, _, _, _ = eng.layout(n_rows)
         if re > rb:
@@ -147,7 +147,7 @@ def test_sharded_prove_equals_unsharded(oracle, kind, fid, n_rows, n_per_row, n_
 
     def work(g):
         try:
-            out[g] = sharded_prove(engines[g].enc, outer, mk_transcript(Transcript, root, n_open), allgather=tag.make(g))
+            out[g] = sharded_prove(engines[g], outer, mk_transcript(Transcript, root, n_open), allgather=tag.make(g))
         except Exception as e:                     # do not leave the other threads stuck at the barrier
             out[g] = e
             tag.bar.abort()

@@ -22,13 +22,14 @@ for rows in (16, 26, 51, 101, 202, 404):
     n = rows * npr
     coeffs = B.rand_coeffs(n, 4, 1)
     st = torch.cuda.current_stream().cuda_stream
+    c = LcCommit(enc)
     for _ in range(2):
-        LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False)
+        LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False, into=c)
     torch.cuda.synchronize()
-    enc.set_timing(True)
-    LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=True)
-    tm = enc.timings()
-    enc.set_timing(False)
+    c.set_timing(True)
+    LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=True, into=c)
+    tm = c.timings()
+    c.set_timing(False)
     print(json.dumps({"rows": rows, "encode_ms": round(tm.encode_ms, 3), "encode_us_per_row": round(tm.encode_ms * 1e3 / rows, 2),
                       "hash_ms": round(tm.hash_ms, 3)}), flush=True)
     del coeffs
