@@ -1,0 +1,665 @@
+// tools/ntt_lab.hip -- timing laboratory for the dominant kernel (ntt_pass_l9_kernel, lcpc_amd/csrc/kernels.hip).
+//
+// Not part of the product.  Runs the two NTT passes of the headline shape (512 rows x 2^17 -> 2^18, Ft255) with the
+// product kernel (through lcpc::launch_ntt_pass of liblcpc_hip.so) and with instrumented COPIES of it in which one cost
+// is removed at a time (results are then wrong on purpose): the differences price the multiplier chains, the twiddle
+// gathers, the normalise / clamp steps and the LDS round trips.  DESIGN.md section 6 quotes the output
+// (profiles/r02_ntt_lab.txt).
+//
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ilcpc_amd/csrc tools/ntt_lab.hip -Llcpc_amd/lib -llcpc_hip \
+//         -Wl,-rpath,$PWD/lcpc_amd/lib -o tools/ntt_lab
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "field_dev.h"
+#include "host_field.h"
+#include "kernels.h"
+
+using namespace lcpc;
+
+#define CHECK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e__), __LINE__); exit(1); } } while (0)
+
+enum { V_NOMUL = 1, V_TW_UNIFORM = 2, V_TW_LINEAR = 4, V_NONORM = 8, V_NOTWLOAD = 16, V_NOGLOBAL = 32 };
+
+template <int LT> struct Lds9 {
+  static constexpr u32 T = 1u << LT;
+  static constexpr u32 WORDS = T * 9 + 64 * 12;
+};
+template <int LT> __device__ __forceinline__ L9 lds9_get(const u32* lds, u32 e) {
+  const uint4 a = *reinterpret_cast<const uint4*>(lds + (size_t)e * 4);
+  const uint4 b = *reinterpret_cast<const uint4*>(lds + ((size_t)Lds9<LT>::T + e) * 4);
+  L9 r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  r.v[8] = lds[(size_t)Lds9<LT>::T * 8 + e];
+  return r;
+}
+template <int LT> __device__ __forceinline__ void lds9_put(u32* lds, u32 e, const L9& x) {
+  *reinterpret_cast<uint4*>(lds + (size_t)e * 4) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+  *reinterpret_cast<uint4*>(lds + ((size_t)Lds9<LT>::T + e) * 4) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+  lds[(size_t)Lds9<LT>::T * 8 + e] = x.v[8];
+}
+__device__ __forceinline__ Fe29 tw29(const u32* tab, u32 widx) {
+  Fe29 t;
+  const uint4* wp = reinterpret_cast<const uint4*>(tab + (size_t)widx * 12);
+  const uint4 w0 = wp[0], w1 = wp[1];
+  const u32 w8 = tab[(size_t)widx * 12 + 8];
+  t.v[0] = w0.x; t.v[1] = w0.y; t.v[2] = w0.z; t.v[3] = w0.w;
+  t.v[4] = w1.x; t.v[5] = w1.y; t.v[6] = w1.z; t.v[7] = w1.w; t.v[8] = w8;
+  return t;
+}
+
+template <int V> __device__ __forceinline__ L9 vmul(const L9& a, const Fe29& w) {
+  if constexpr (V & V_NOMUL) {
+    L9 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.v[k] = (a.v[k] + w.v[k]) & l9::M;
+    return r;
+  } else {
+    return l9::mul(a, w);
+  }
+}
+template <int V> __device__ __forceinline__ void vnorm(L9& a) { if constexpr (!(V & V_NONORM)) l9::normalize(a); }
+template <int V> __device__ __forceinline__ void vclamp(L9& a, const u32* qp) { if constexpr (!(V & V_NONORM)) l9::clamp(a, qp); }
+template <int V> __device__ __forceinline__ Fe29 vtw(const u32* tab, u32 widx, u32 q) {
+  if constexpr (V & V_NOTWLOAD) {
+    Fe29 t;
+#pragma unroll
+    for (int k = 0; k < 9; k++) t.v[k] = (widx * 2654435761u + k * 40503u) & l9::M;
+    return t;
+  }
+  if constexpr (V & V_TW_UNIFORM) return tw29(tab, widx & 1u);
+  if constexpr (V & V_TW_LINEAR) return tw29(tab, (widx & 3u) * 256u + q);
+  return tw29(tab, widx);
+}
+
+// copy of ntt_pass_l9_kernel (generic rounds only matter for timing; the special cases are kept so that V = 0 is bit-exact)
+template <int LT, int V>
+__global__ void __launch_bounds__(256, 4) lab_l9_kernel(NttPassArgs a, u32 stagger, u32 prefetch) {
+  constexpr int NL = 8;
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  u32* qp = lds + (size_t)Lds9<LT>::T * 9;
+  const u32 k = a.log_n, t0 = a.t0, s = a.s, ltj = a.log_tj;
+  const u32 lb = k - t0 - s;
+  const u32 lbt = lb < ltj ? lb : ltj;
+  const u32 T = 1u << (s + ltj);
+  const u32 tiles_per_row = 1u << (k - s - ltj);
+  u64 row;
+  u32 tile;
+  if (tiles_per_row >= 8) {
+    const u32 xcd = blockIdx.x & 7u;
+    const u64 q = blockIdx.x >> 3;
+    tile = (u32)(q / a.n_rows) * 8u + xcd;
+    row = q % a.n_rows;
+  } else {
+    row = blockIdx.x / tiles_per_row;
+    tile = blockIdx.x % tiles_per_row;
+  }
+  const u32 o0 = tile << ltj;
+  const u32 tid = threadIdx.x;
+  const u32 lp_mask = (1u << lbt) - 1, i_mask = (1u << s) - 1;
+  const u32 lo_mask = (1u << lb) - 1;
+  auto gindex = [&](u32 e) -> u32 {
+    const u32 lp = e & lp_mask, i = (e >> lbt) & i_mask, hp = e >> (lbt + s);
+    const u32 outer = o0 | (hp << lbt) | lp;
+    return ((outer >> lb) << (lb + s)) | (i << lb) | (outer & lo_mask);
+  };
+  const bool canon = a.roots29c != nullptr;
+  // experiment: de-phase the first generation of workgroups (later ones inherit the offsets: a slot is refilled when its
+  // predecessor ends).  stagger = (shift << 8) | units of ~3.4 us (8128 cycles) per class, 4 classes
+  if (stagger && blockIdx.x < 1024u) {
+    const u32 cls = (blockIdx.x >> (stagger >> 8)) & 3u;
+    for (u32 z = 0; z < cls * (stagger & 255u); z++) __builtin_amdgcn_s_sleep(127);
+  }
+  for (u32 i = tid; i < 64 * 12; i += 256) qp[i] = a.qp29[i];
+  const u32* src = a.src + row * a.src_stride * NL;
+  // experiment: pull the tile that the successor in this slot will load (blockIdx.x + prefetch) towards the L2:
+  // one dummy dword per 128-byte line, never waited for
+  u32 pf_acc = 0;
+  if (prefetch && blockIdx.x + prefetch < gridDim.x) {
+    const u32 nb = blockIdx.x + prefetch;
+    u64 prow; u32 ptile;
+    if (tiles_per_row >= 8) { const u32 xcd = nb & 7u; const u64 q = nb >> 3; ptile = (u32)(q / a.n_rows) * 8u + xcd; prow = q % a.n_rows; }
+    else { prow = nb / tiles_per_row; ptile = nb % tiles_per_row; }
+    const u32 po0 = ptile << ltj;
+    const u32* psrc = a.src + prow * a.src_stride * NL;
+    for (u32 e = tid * 4; e < T; e += 1024) {      // 4 elements = 128 bytes
+      const u32 lp = e & lp_mask, i = (e >> lbt) & i_mask, hp = e >> (lbt + s);
+      const u32 outer = po0 | (hp << lbt) | lp;
+      const u32 g = ((outer >> lb) << (lb + s)) | (i << lb) | (outer & lo_mask);
+      if (g < a.n_valid) pf_acc ^= __builtin_nontemporal_load(psrc + (size_t)g * NL);
+    }
+  }
+  for (u32 e = tid; e < T; e += 256) {
+    const u32 g = gindex(e);
+    Fe<NL> v;
+    if constexpr (V & V_NOGLOBAL) { v = fe_zero<NL>(); v.v[0] = g; v.v[3] = e * 77u; }
+    else v = (g < a.n_valid && row * a.src_stride + g < a.n_src_total) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
+    lds9_put<LT>(lds, e, l9::from_packed(v));
+    if constexpr (!(V & V_NOGLOBAL))
+      if (a.copy_dst != nullptr && g < a.n_valid) fe_store<NL>(a.copy_dst + (row * a.src_stride + g) * NL, v);
+  }
+  __syncthreads();
+  u32 u = 0;
+  for (; u + 1 < s; u += 2) {
+    const u32 t = t0 + u;
+    const u32 hb = s - u - 1;
+    const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
+    const bool last_two = (t + 2 == k);
+    const bool zero_hi = (t == 0) && !last_two && a.n_valid <= (1ull << (k - 1));
+    const bool zero_3q = zero_hi && a.n_valid <= (1ull << (k - 2));
+    for (u32 q = tid; q < T / 4; q += 256) {
+      const u32 lp = q & lp_mask;
+      const u32 j = (q >> lbt) & (i_mask >> 2);
+      const u32 hp = q >> (lbt + s - 2);
+      const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+      const u32 e0 = (((hp << s) | i0) << lbt) | lp;
+      const u32 dq = 1u << (hb - 1 + lbt);
+      const u32 g0 = gindex(e0), g1 = gindex(e0 + dq);
+      if (zero_hi) {
+        const u32* tc = canon ? a.roots29c : a.roots29;
+        const Fe29 w0 = vtw<V>(tc, g0 & gm0, q);
+        const Fe29 w2c = vtw<V>(tc, (g0 & gm1) << 1, q);
+        const Fe29 w2 = vtw<V>(a.roots29, (g0 & gm1) << 1, q);
+        if (zero_3q) {
+          const L9 x0 = lds9_get<LT>(lds, e0);
+          lds9_put<LT>(lds, e0 + dq, vmul<V>(x0, w2c));
+          const L9 b2 = vmul<V>(x0, w0);
+          lds9_put<LT>(lds, e0 + 2 * dq, b2);
+          lds9_put<LT>(lds, e0 + 3 * dq, vmul<V>(b2, w2));
+          continue;
+        }
+        const Fe29 w1 = vtw<V>(tc, g1 & gm0, q);
+        const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
+        L9 c0 = l9::add(x0, x1);
+        vnorm<V>(c0);
+        lds9_put<LT>(lds, e0, c0);
+        lds9_put<LT>(lds, e0 + dq, vmul<V>(l9::sub(x0, x1), w2c));
+        const L9 b2 = vmul<V>(x0, w0), b3 = vmul<V>(x1, w1);
+        L9 c2 = l9::add(b2, b3);
+        vnorm<V>(c2);
+        lds9_put<LT>(lds, e0 + 2 * dq, c2);
+        lds9_put<LT>(lds, e0 + 3 * dq, vmul<V>(l9::sub(b2, b3), w2));
+        continue;
+      }
+      const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
+      const L9 x2 = lds9_get<LT>(lds, e0 + 2 * dq), x3 = lds9_get<LT>(lds, e0 + 3 * dq);
+      const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);
+      L9 c0 = l9::add(b0, b1);
+      vnorm<V>(c0);
+      if (last_two) {
+        const Fe29 wq = vtw<V>(a.roots29, 1u << (k - 2), q);
+        L9 c1 = l9::sub(b0, b1);
+        const L9 b2 = l9::sub(x0, x2);
+        const L9 b3 = vmul<V>(l9::sub(x1, x3), wq);
+        L9 c2 = l9::add(b2, b3);
+        L9 c3 = l9::sub(b2, b3);
+        vnorm<V>(c1); vnorm<V>(c2); vnorm<V>(c3);
+        lds9_put<LT>(lds, e0, c0);
+        lds9_put<LT>(lds, e0 + dq, c1);
+        lds9_put<LT>(lds, e0 + 2 * dq, c2);
+        lds9_put<LT>(lds, e0 + 3 * dq, c3);
+      } else {
+        const bool blk0c = canon && g0 <= gm1;
+        const u32* t01 = blk0c ? a.roots29c : a.roots29;
+        const Fe29 w0 = vtw<V>(t01, (g0 & gm0) << t, q);
+        const Fe29 w1 = vtw<V>(t01, (g1 & gm0) << t, q);
+        const Fe29 w2 = vtw<V>(a.roots29, (g0 & gm1) << (t + 1), q);
+        vclamp<V>(c0, qp);
+        lds9_put<LT>(lds, e0, c0);
+        const L9 d1 = l9::sub(b0, b1);
+        L9 c1;
+        if (blk0c) c1 = vmul<V>(d1, vtw<V>(a.roots29c, (g0 & gm1) << (t + 1), q));
+        else c1 = vmul<V>(d1, w2);
+        lds9_put<LT>(lds, e0 + dq, c1);
+        const L9 b2 = vmul<V>(l9::sub(x0, x2), w0);
+        const L9 b3 = vmul<V>(l9::sub(x1, x3), w1);
+        L9 c2 = l9::add(b2, b3);
+        vnorm<V>(c2);
+        lds9_put<LT>(lds, e0 + 2 * dq, c2);
+        lds9_put<LT>(lds, e0 + 3 * dq, vmul<V>(l9::sub(b2, b3), w2));
+      }
+    }
+    __syncthreads();
+  }
+  u32* dst = a.dst + row * a.dst_stride * NL;
+  for (u32 e = tid; e < T; e += 256) {
+    const u32 g = gindex(e);
+    Fe<NL> v = l9::to_packed_reduced(lds9_get<LT>(lds, e), qp);
+    if (g < a.mont_prefix) v = fe_canon_r29(v);
+    if constexpr (V & V_NOGLOBAL) { if (v.v[0] == 0x12345u && v.v[5] == 77u) fe_store<NL>(dst + (size_t)g * NL, v); }
+    else fe_store<NL>(dst + (size_t)g * NL, v);
+  }
+  if (pf_acc == 0x9e3779b9u && a.n_rows == 0) dst[0] = pf_acc;      // keeps the prefetch loads alive; never true
+}
+
+
+// =====================================================================================================================
+// v2: the candidate replacement.  Same tiling and arithmetic as ntt_pass_l9_kernel, but
+//   * the pass shape (S stages, 2^LTJ-element runs, first / last pass) is a template parameter: the index math of a
+//     round collapses to a few shifts;
+//   * twiddles come from a per-pass PACK in lane order: for tile class c and round u the three (six with the
+//     converting set) twiddles of quad q sit at [c][u][variant][chunk][q mod period], so a wave reads 1 KiB runs
+//     instead of gathering 64 x 48-byte entries at strides of up to 12 KiB;
+//   * normalise + clamp of the pure-sum output c0 are one carry pass (the q * p row of the table is fetched from LDS
+//     before the multiplier chains start, and stored negated so that the subtraction is a 3-input add);
+//   * a pass that is not the last stores values in [0, p + 2^239) (< 2^256) without the final conditional subtract.
+// Pack layout per (class, round): [6 variants][2 chunks of 16 B][period] uint4, then [6][period] u32 (limb 8);
+// variants: 0 w0, 1 w1, 2 w2 (plain table), 3 w0c, 4 w1c, 5 w2c (converting table).
+// =====================================================================================================================
+struct PackInfo {
+  u32 round_off[8];      // word offset of round u/2 inside a class block
+  u32 class_words;       // words per tile class
+};
+template <int S, int LBT> struct PackShape {
+  static constexpr int NR = S / 2;
+  static constexpr u32 period(int r) { return 1u << (S - 2 * r - 2 + LBT); }     // hb - 1 + LBT, hb = S - 2r - 1
+};
+
+__device__ __forceinline__ Fe29 pk_load(const u32* blk, u32 period, u32 variant, u32 jl) {
+  const uint4 a = *reinterpret_cast<const uint4*>(blk + ((size_t)(variant * 2 + 0) * period + jl) * 4);
+  const uint4 b = *reinterpret_cast<const uint4*>(blk + ((size_t)(variant * 2 + 1) * period + jl) * 4);
+  const u32 c = blk[(size_t)12 * period * 4 + (size_t)variant * period + jl];
+  Fe29 t;
+  t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w; t.v[4] = b.x; t.v[5] = b.y; t.v[6] = b.z; t.v[7] = b.w; t.v[8] = c;
+  return t;
+}
+
+// builds the pack of one pass from the plain tables: one thread per (class, round, jl)
+template <int S, int LBT>
+__global__ void pack_kernel(NttPassArgs a, PackInfo pi, u32 n_classes, u32* pack) {
+  const u32 k = a.log_n, t0 = a.t0;
+  const u32 lb = k - t0 - S;
+  const u32 per_class = 256 + 64 + 16 + 4 + 1;      // generous bound on sum of periods (S <= 10, LBT <= 2)
+  (void)per_class;
+  for (u32 id = blockIdx.x * 256 + threadIdx.x; id < n_classes * (S / 2) * 256; id += gridDim.x * 256) {
+    const u32 jl = id & 255u, r = (id >> 8) % (S / 2), cls = (id >> 8) / (S / 2);
+    const u32 u = 2 * r, hb = S - u - 1, period = 1u << (hb - 1 + LBT);
+    if (jl >= period) continue;
+    const u32 t = t0 + u;
+    const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
+    if (t + 2 == k) continue;                         // last_two round: one uniform twiddle, not packed
+    // quad q = jl (block 0 representative): lp, j, i0, e0 as in the kernel; tile class -> o0
+    const u32 lp = jl & ((1u << LBT) - 1), j = jl >> LBT;
+    const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+    const u32 o0 = cls << LBT;                        // first pass: class = tile; last pass: single class (o0 irrelevant: lb = 0)
+    const u32 lo_mask = (1u << lb) - 1;
+    const u32 outer = o0 | lp;
+    const u32 g0 = ((outer >> lb) << (lb + S)) | (i0 << lb) | (outer & lo_mask);
+    const u32 g1 = g0 + (1u << (hb - 1 + lb));
+    const u32 idx[3] = {(g0 & gm0) << t, (g1 & gm0) << t, (g0 & gm1) << (t + 1)};
+    u32* blk = pack + (size_t)cls * pi.class_words + pi.round_off[r];
+    for (u32 v = 0; v < 6; v++) {
+      const u32* tab = v < 3 ? a.roots29 : a.roots29c;
+      const u32* e = tab + (size_t)idx[v % 3] * 12;
+      for (u32 c = 0; c < 2; c++)
+        for (u32 w = 0; w < 4; w++) blk[((size_t)(v * 2 + c) * period + jl) * 4 + w] = e[c * 4 + w];
+      blk[(size_t)12 * period * 4 + (size_t)v * period + jl] = e[8];
+    }
+  }
+}
+
+namespace l9x {
+// quotient for the clamp from an UN-normalised top limb (carries from below still missing, <= 3): see l9::clamp
+LCPC_DEV u32 clamp_q(u32 top) {
+  constexpr u32 PTOP1 = (u32)(P29::limb(8)) + 1;
+  constexpr u64 MAGIC = (((u64)1 << 52) + PTOP1 - 1) / PTOP1;
+  const u32 n = top + (u32)(l9::QOFF * PTOP1 - l9::QBIAS);
+  return (u32)(((u64)n * MAGIC) >> 52);
+}
+struct Row { u32 v[9]; };
+LCPC_DEV Row row_load(const u32* nqp, u32 q) {       // nqp: NEGATED q*p rows, 12-word stride
+  const uint4 a = *reinterpret_cast<const uint4*>(nqp + q * 12), b = *reinterpret_cast<const uint4*>(nqp + q * 12 + 4);
+  Row r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w; r.v[8] = nqp[q * 12 + 8];
+  return r;
+}
+// a: limbs 0..7 in [0, 2^31) (sum of <= 4 normalised values), top signed; nt = -(q*p) limb-wise.  One carry pass:
+// limbs 0..7 -> [0, 2^29), value = a - q*p exactly, in [0, p + 2^239) (the carries the estimate did not see add < 4 * 2^232)
+LCPC_DEV void clamp_apply(L9& a, const Row& nt) {
+  int32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int32_t d = (int32_t)(a.v[k] + nt.v[k] + (u32)c);
+    a.v[k] = (u32)d & l9::M;
+    c = d >> 29;
+  }
+  a.v[8] = a.v[8] + nt.v[8] + (u32)c;
+}
+}  // namespace l9x
+
+template <int S, int LTJ, bool FIRST, bool LAST>
+__global__ void __launch_bounds__(256, 4) v2_kernel(NttPassArgs a, const u32* __restrict__ pack, PackInfo pi) {
+  constexpr int NL = 8, LT = S + LTJ, LBT = LTJ;
+  static_assert(LT == 10 && S % 2 == 0, "lab: 1024-element tiles, radix-4 rounds only");
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  u32* nqp = lds + (size_t)Lds9<LT>::T * 9;                  // negated q*p rows
+  const u32 k = a.log_n, t0 = a.t0;
+  const u32 lb = k - t0 - S;                                 // FIRST: k - S (>= LTJ); LAST: 0
+  constexpr u32 T = 1u << LT;
+  const u32 tiles_per_row = 1u << (k - LT);
+  u64 row;
+  u32 tile;
+  if (tiles_per_row >= 8) {
+    const u32 xcd = blockIdx.x & 7u;
+    const u64 qq = blockIdx.x >> 3;
+    tile = (u32)(qq / a.n_rows) * 8u + xcd;
+    row = qq % a.n_rows;
+  } else {
+    row = blockIdx.x / tiles_per_row;
+    tile = blockIdx.x % tiles_per_row;
+  }
+  const u32 tid = threadIdx.x;
+  const u32 o0 = tile << LTJ;
+  // memory index of LDS slot e = (i << LBT) | lp:  FIRST: (i << lb) | o0 | lp;  LAST (lb = 0, LTJ = 0): tile * 2^S + i
+  auto gindex = [&](u32 e) -> u32 {
+    if constexpr (LTJ == 0) return (tile << S) | e;
+    else return ((e >> LBT) << lb) | o0 | (e & ((1u << LBT) - 1));
+  };
+  const bool canon = a.roots29c != nullptr;
+  for (u32 i = tid; i < 64 * 12; i += 256) nqp[i] = 0u - a.qp29[i];
+  const u32* src = a.src + row * a.src_stride * NL;
+#pragma unroll
+  for (u32 e = tid; e < T; e += 256) {
+    const u32 g = gindex(e);
+    const Fe<NL> v = (g < a.n_valid && row * a.src_stride + g < a.n_src_total) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
+    lds9_put<LT>(lds, e, l9::from_packed(v));
+    if (a.copy_dst != nullptr && g < a.n_valid) fe_store<NL>(a.copy_dst + (row * a.src_stride + g) * NL, v);
+  }
+  __syncthreads();
+  const u32 q = tid;                                         // one quad per thread per round (T / 4 == 256)
+  const u32* cls_pack = pack + (size_t)(FIRST ? tile : 0u) * pi.class_words;
+  const bool blk0_tile = FIRST || tile == 0;
+#pragma unroll
+  for (int r = 0; r < S / 2; r++) {
+    constexpr int dummy = 0; (void)dummy;
+    const int u = 2 * r, hb = S - u - 1;
+    const u32 t = t0 + u;
+    const bool last_two = LAST && (r == S / 2 - 1);
+    const u32 lp = q & ((1u << LBT) - 1), j = q >> LBT;
+    const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+    const u32 e0 = (i0 << LBT) | lp;
+    const u32 dq = 1u << (hb - 1 + LBT);
+    const u32 period = 1u << (hb - 1 + LBT);
+    const u32 jl = q & (period - 1);
+    const u32* blk = cls_pack + pi.round_off[r];
+    if (FIRST && r == 0 && a.n_valid <= (1ull << (k - 1))) {
+      // zero-padded first round (rate <= 1/2): x2 = x3 = 0; everything is block 0
+      const u32 vb = canon ? 3u : 0u;
+      const Fe29 w0 = pk_load(blk, period, vb + 0, jl), w2c = pk_load(blk, period, vb + 2, jl), w2 = pk_load(blk, period, 2, jl);
+      if (a.n_valid <= (1ull << (k - 2))) {
+        const L9 x0 = lds9_get<LT>(lds, e0);
+        lds9_put<LT>(lds, e0 + dq, l9::mul(x0, w2c));
+        const L9 b2 = l9::mul(x0, w0);
+        lds9_put<LT>(lds, e0 + 2 * dq, b2);
+        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(b2, w2));
+      } else {
+        const Fe29 w1 = pk_load(blk, period, vb + 1, jl);
+        const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
+        L9 c0 = l9::add(x0, x1);
+        l9::normalize(c0);
+        lds9_put<LT>(lds, e0, c0);
+        lds9_put<LT>(lds, e0 + dq, l9::mul(l9::sub(x0, x1), w2c));
+        const L9 b2 = l9::mul(x0, w0), b3 = l9::mul(x1, w1);
+        L9 c2 = l9::add(b2, b3);
+        l9::normalize(c2);
+        lds9_put<LT>(lds, e0 + 2 * dq, c2);
+        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2));
+      }
+      __syncthreads();
+      continue;
+    }
+    const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
+    const L9 x2 = lds9_get<LT>(lds, e0 + 2 * dq), x3 = lds9_get<LT>(lds, e0 + 3 * dq);
+    const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);
+    L9 c0 = l9::add(b0, b1);                                 // limbs [0, 2^31), |value| < 16p
+    if (last_two) {
+      l9::normalize(c0);
+      const Fe29 wq = tw29(a.roots29, 1u << (k - 2));
+      L9 c1 = l9::sub(b0, b1);
+      const L9 b2 = l9::sub(x0, x2);
+      const L9 b3 = l9::mul(l9::sub(x1, x3), wq);
+      L9 c2 = l9::add(b2, b3);
+      L9 c3 = l9::sub(b2, b3);
+      l9::normalize(c1); l9::normalize(c2); l9::normalize(c3);
+      lds9_put<LT>(lds, e0, c0);
+      lds9_put<LT>(lds, e0 + dq, c1);
+      lds9_put<LT>(lds, e0 + 2 * dq, c2);
+      lds9_put<LT>(lds, e0 + 3 * dq, c3);
+    } else {
+      const l9x::Row nt = l9x::row_load(nqp, l9x::clamp_q(c0.v[8]));        // in flight while the multipliers run
+      const bool blk0c = canon && blk0_tile && q < period;
+      const u32 vb = blk0c ? 3u : 0u;
+      const Fe29 w0 = pk_load(blk, period, vb + 0, jl), w1 = pk_load(blk, period, vb + 1, jl);
+      const Fe29 w2 = pk_load(blk, period, 2, jl);
+      const L9 d1 = l9::sub(b0, b1);
+      L9 c1;
+      if (blk0c) c1 = l9::mul(d1, pk_load(blk, period, 5, jl));
+      else c1 = l9::mul(d1, w2);
+      lds9_put<LT>(lds, e0 + dq, c1);
+      const L9 b2 = l9::mul(l9::sub(x0, x2), w0);
+      const L9 b3 = l9::mul(l9::sub(x1, x3), w1);
+      L9 c2 = l9::add(b2, b3);
+      l9::normalize(c2);
+      lds9_put<LT>(lds, e0 + 2 * dq, c2);
+      lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2));
+      l9x::clamp_apply(c0, nt);
+      lds9_put<LT>(lds, e0, c0);
+    }
+    __syncthreads();
+  }
+  u32* dst = a.dst + row * a.dst_stride * NL;
+#pragma unroll
+  for (u32 e = tid; e < T; e += 256) {
+    const u32 g = gindex(e);
+    L9 x = lds9_get<LT>(lds, e);
+    // exact clamp (normalised input): [0, p + 2^239)
+    l9x::clamp_apply(x, l9x::row_load(nqp, l9x::clamp_q(x.v[8])));
+    u32 w[8];
+    fe_from29(w, x.v);
+    Fe<NL> v;
+    if constexpr (LAST) {
+      v = fe_reduce_once8(w);
+      if (g < a.mont_prefix) v = fe_canon_r29(v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) v.v[i] = w[i];                // < 2^256, == value mod p: the next pass takes it as it is
+    }
+    fe_store<NL>(dst + (size_t)g * NL, v);
+  }
+}
+
+template <int S, int LTJ, bool FIRST, bool LAST>
+static void launch_v2(const NttPassArgs& a, const u32* pack, const PackInfo& pi, hipStream_t st) {
+  constexpr int LT = S + LTJ;
+  const u64 tiles = ((u64)1 << (a.log_n - LT)) * a.n_rows;
+  const size_t lds_bytes = (size_t)Lds9<LT>::WORDS * 4;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&v2_kernel<S, LTJ, FIRST, LAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((v2_kernel<S, LTJ, FIRST, LAST>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a, pack, pi);
+}
+template <int S, int LBT> static PackInfo make_pack_info() {
+  PackInfo pi{};
+  u32 off = 0;
+  for (int r = 0; r < S / 2; r++) {
+    pi.round_off[r] = off;
+    const u32 period = 1u << (S - 2 * r - 2 + LBT);
+    off += 6 * period * 9;
+    off = (off + 3) & ~3u;
+  }
+  pi.class_words = off;
+  return pi;
+}
+
+__global__ void fill_kernel(u32* p, u64 n_elems, u32 seed) {
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (u64)gridDim.x * 256) {
+    u32 x = (u32)i * 2654435761u + seed;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; p[i * 8 + k] = x; }
+    p[i * 8 + 7] &= 0x3fffffffu;                     // < p (top limb of p is 0x663c799b)
+  }
+}
+__global__ void diff_kernel(const u32* a, const u32* b, u64 n_words, unsigned long long* out) {
+  unsigned long long bad = 0;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (u64)gridDim.x * 256) bad += (a[i] != b[i]);
+  if (bad) atomicAdd(out, bad);
+}
+
+template <int V> static void launch_lab(const NttPassArgs& a, hipStream_t st, u32 stagger = 0, u32 prefetch = 0) {
+  constexpr int LT = 10;
+  const u64 tiles = ((u64)1 << (a.log_n - a.s - a.log_tj)) * a.n_rows;
+  const size_t lds_bytes = (size_t)Lds9<LT>::WORDS * 4;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_l9_kernel<LT, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((lab_l9_kernel<LT, V>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a, stagger, prefetch);
+}
+
+struct Bench {
+  NttPassArgs pa, pb;
+  hipEvent_t e0, e1, e2;
+};
+
+template <typename FA, typename FB> static void time_variant(const char* name, Bench& B, FA fa, FB fb, int iters = 6) {
+  float ta = 1e30f, tb = 1e30f, sa = 0, sb = 0;
+  for (int it = 0; it < iters + 1; it++) {
+    CHECK(hipEventRecord(B.e0));
+    fa(B.pa);
+    CHECK(hipEventRecord(B.e1));
+    fb(B.pb);
+    CHECK(hipEventRecord(B.e2));
+    CHECK(hipEventSynchronize(B.e2));
+    float a, b;
+    CHECK(hipEventElapsedTime(&a, B.e0, B.e1));
+    CHECK(hipEventElapsedTime(&b, B.e1, B.e2));
+    if (it == 0) continue;
+    sa += a; sb += b;
+    if (a < ta) ta = a;
+    if (b < tb) tb = b;
+  }
+  printf("%-44s passA %7.3f ms (min %7.3f)  passB %7.3f ms (min %7.3f)  sum %7.3f\n", name, sa / iters, ta, sb / iters, tb, (sa + sb) / iters);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const unsigned log_n = 18, log_rows = argc > 1 ? atoi(argv[1]) : 9;
+  const u64 n = (u64)1 << log_n, n_rows = (u64)1 << log_rows, n_valid = n / 2;
+  const FieldDesc& f = *field_desc(3);
+  // tables, as lcpc_ctx_create builds them
+  const unsigned log_half = log_n - 1;
+  std::vector<uint64_t> pw((size_t)(log_half + 1) * 4);
+  uint64_t w[4];
+  memcpy(w, f.rou, 32);
+  for (unsigned i = 0; i < f.S - log_n; i++) h_mul(f, w, w, w);
+  for (unsigned j = 0; j <= log_half; j++) { memcpy(&pw[(size_t)j * 4], w, 32); h_mul(f, w, w, w); }
+  u32 *d_pw, *d_one, *d_roots, *d_roots29, *d_roots29c, *d_qp;
+  CHECK(hipMalloc(&d_pw, pw.size() * 8)); CHECK(hipMalloc(&d_one, 32));
+  CHECK(hipMalloc(&d_roots, (n / 2) * 32)); CHECK(hipMalloc(&d_roots29, (n / 2) * 48)); CHECK(hipMalloc(&d_roots29c, (n / 2) * 48));
+  CHECK(hipMemcpy(d_pw, pw.data(), pw.size() * 8, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_one, f.r, 32, hipMemcpyHostToDevice));
+  CHECK(launch_roots(8, d_pw, log_half, d_one, d_roots, d_roots29, d_roots29c, nullptr));
+  std::vector<uint32_t> tab(64 * 12, 0);
+  for (int i = 0; i < 64; i++) {
+    const int q = i - 24;
+    uint64_t mag[5] = {0, 0, 0, 0, 0};
+    unsigned __int128 cy = 0;
+    for (int x = 0; x < 5; x++) { cy += (unsigned __int128)(x < 4 ? f.p[x] : 0) * (uint64_t)(q < 0 ? -q : q); mag[x] = (uint64_t)cy; cy >>= 64; }
+    if (q < 0) { unsigned __int128 c2 = 1; for (int x = 0; x < 5; x++) { c2 += (unsigned __int128)(~mag[x]); mag[x] = (uint64_t)c2; c2 >>= 64; } }
+    for (int k = 0; k < 9; k++) {
+      const int b = 29 * k, x = b / 64, sh = b % 64;
+      uint64_t y = mag[x] >> sh;
+      if (sh > 35) y |= mag[x + 1] << (64 - sh);
+      tab[i * 12 + k] = k < 8 ? (uint32_t)(y & ((1u << 29) - 1)) : (uint32_t)y;
+    }
+  }
+  CHECK(hipMalloc(&d_qp, tab.size() * 4));
+  CHECK(hipMemcpy(d_qp, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  u32 *d_src, *d_dst, *d_ref;
+  CHECK(hipMalloc(&d_src, n_rows * n_valid * 32));
+  CHECK(hipMalloc(&d_dst, n_rows * n * 32));
+  CHECK(hipMalloc(&d_ref, n_rows * n * 32));
+  unsigned long long* d_bad;
+  CHECK(hipMalloc(&d_bad, 8));
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, d_src, n_rows * n_valid, 17u);
+  CHECK(hipDeviceSynchronize());
+
+  Bench B;
+  CHECK(hipEventCreate(&B.e0)); CHECK(hipEventCreate(&B.e1)); CHECK(hipEventCreate(&B.e2));
+  NttPassArgs a{};
+  a.roots = d_roots; a.roots29 = d_roots29; a.qp29 = d_qp; a.roots29c = d_roots29c;
+  a.n_rows = n_rows; a.log_n = log_n; a.dst_stride = n; a.n_src_total = ~(u64)0; a.copy_dst = nullptr;
+  B.pa = a; B.pa.src = d_src; B.pa.dst = d_dst; B.pa.src_stride = n_valid; B.pa.n_valid = n_valid; B.pa.t0 = 0; B.pa.s = 8; B.pa.log_tj = 2; B.pa.mont_prefix = 0;
+  B.pb = a; B.pb.src = d_dst; B.pb.dst = d_dst; B.pb.src_stride = n; B.pb.n_valid = n; B.pb.t0 = 8; B.pb.s = 10; B.pb.log_tj = 0; B.pb.mont_prefix = 4;
+
+  auto prod = [&](const NttPassArgs& x) { CHECK(launch_ntt_pass(8, 10, x, nullptr)); };
+  // reference output from the product kernel
+  {
+    NttPassArgs ra = B.pa, rb = B.pb;
+    ra.dst = d_ref; rb.src = d_ref; rb.dst = d_ref;
+    prod(ra); prod(rb);
+    CHECK(hipDeviceSynchronize());
+  }
+  auto check = [&](const char* what) {
+    CHECK(hipMemset(d_bad, 0, 8));
+    hipLaunchKernelGGL(diff_kernel, dim3(4096), dim3(256), 0, 0, d_dst, d_ref, n_rows * n * 8, d_bad);
+    unsigned long long bad = 0;
+    CHECK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
+    printf("    %s: %llu differing words vs the product kernel%s\n", what, bad, bad ? "" : " (bit-exact)");
+  };
+  printf("shape: %llu rows x 2^%u (n_valid 2^%u), Ft255; pass A = stages 0-7 on 256x4 tiles, pass B = stages 8-17 on 1024 tiles\n",
+         (unsigned long long)n_rows, log_n, log_n - 1);
+  time_variant("product ntt_pass_l9_kernel", B, prod, prod);
+  check("product");
+  time_variant("lab copy, V=0", B, [&](const NttPassArgs& x) { launch_lab<0>(x, nullptr); }, [&](const NttPassArgs& x) { launch_lab<0>(x, nullptr); });
+  check("lab V=0");
+  // v2: packs for both passes
+  const PackInfo piA = make_pack_info<8, 2>(), piB = make_pack_info<10, 0>();
+  const u32 n_cls_A = 1u << (log_n - 10);
+  u32 *d_packA, *d_packB;
+  CHECK(hipMalloc(&d_packA, (size_t)n_cls_A * piA.class_words * 4));
+  CHECK(hipMalloc(&d_packB, (size_t)piB.class_words * 4));
+  hipLaunchKernelGGL((pack_kernel<8, 2>), dim3(1024), dim3(256), 0, 0, B.pa, piA, n_cls_A, d_packA);
+  hipLaunchKernelGGL((pack_kernel<10, 0>), dim3(8), dim3(256), 0, 0, B.pb, piB, 1u, d_packB);
+  CHECK(hipDeviceSynchronize());
+  printf("packs: pass A %.1f MB (%u classes x %u B), pass B %.1f KB\n", n_cls_A * piA.class_words * 4 / 1e6, n_cls_A, piA.class_words * 4, piB.class_words * 4 / 1e3);
+  CHECK(hipMemset(d_dst, 0, n_rows * n * 32));
+  time_variant("v2 (specialised, packed twiddles, merged clamp)", B, [&](const NttPassArgs& x) { launch_v2<8, 2, true, false>(x, d_packA, piA, nullptr); },
+               [&](const NttPassArgs& x) { launch_v2<10, 0, false, true>(x, d_packB, piB, nullptr); });
+  check("v2");
+  time_variant("product again", B, prod, prod);
+#define RUN(V, NAME) time_variant(NAME, B, [&](const NttPassArgs& x) { launch_lab<V>(x, nullptr); }, [&](const NttPassArgs& x) { launch_lab<V>(x, nullptr); })
+  const bool brief = argc > 2;
+  if (brief) {
+    RUN(V_NOTWLOAD, "no twiddle loads (synthesised in regs)");
+    RUN(V_NOMUL, "multiplies replaced by 9 adds");
+    RUN(V_NOGLOBAL, "no global tile loads / stores");
+    RUN(V_NOGLOBAL | V_NOTWLOAD | V_NOMUL | V_NONORM, "LDS round trips + index math only");
+    return 0;
+  }
+  RUN(V_TW_LINEAR, "twiddle index lane-linear (AoS 48 B)");
+  RUN(V_TW_UNIFORM, "twiddle index uniform (broadcast)");
+  RUN(V_NOTWLOAD, "no twiddle loads (synthesised in regs)");
+  RUN(V_NONORM, "no normalize / clamp");
+  RUN(V_NOMUL, "multiplies replaced by 9 adds");
+  RUN(V_NOMUL | V_NOTWLOAD, "no multiplies, no twiddle loads");
+  RUN(V_NOMUL | V_NOTWLOAD | V_NONORM, "no mul, no tw loads, no normalize");
+  RUN(V_NOGLOBAL, "no global tile loads / stores");
+  RUN(V_NOGLOBAL | V_NOTWLOAD, "no global, no twiddle loads");
+  RUN(V_NOGLOBAL | V_NOTWLOAD | V_NOMUL | V_NONORM, "LDS round trips + index math only");
+  for (u32 shift : {8u})
+    for (u32 units : {2u}) {
+      char nm[64];
+      snprintf(nm, sizeof nm, "stagger class=(b>>%u)&3, %u x 3.4us", shift, units);
+      const u32 sg = (shift << 8) | units;
+      time_variant(nm, B, [&](const NttPassArgs& x) { launch_lab<0>(x, nullptr, sg); }, [&](const NttPassArgs& x) { launch_lab<0>(x, nullptr, sg); });
+    }
+  check("staggered");
+  for (u32 pf : {1024u, 2048u, 512u}) {
+    char nm[64];
+    snprintf(nm, sizeof nm, "L2 prefetch of tile b+%u", pf);
+    time_variant(nm, B, [&](const NttPassArgs& x) { launch_lab<0>(x, nullptr, 0, pf); }, [&](const NttPassArgs& x) { launch_lab<0>(x, nullptr, 0, pf); });
+  }
+  check("prefetch");
+  time_variant("stagger (b>>3)&3 x5 + prefetch 1024", B, [&](const NttPassArgs& x) { launch_lab<0>(x, nullptr, (3u << 8) | 5u, 1024); },
+               [&](const NttPassArgs& x) { launch_lab<0>(x, nullptr, (3u << 8) | 5u, 1024); });
+  return 0;
+}
