@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-KERNEL_SOURCES = ("kernels.hip", "field_dev.h", "field_r29_gen.h", "blake3_dev.h", "kernels.h")
+KERNEL_SOURCES = ("kernels.hip", "ntt_l9s.hip", "ntt_l9_dev.h", "field_dev.h", "field_r29_gen.h", "blake3_dev.h", "kernels.h")
 
 
 def kernel_stamp():

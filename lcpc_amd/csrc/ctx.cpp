@@ -52,6 +52,7 @@ void ctx_ref(lcpc_ctx* c) { c->refs.fetch_add(1); }
 static void ctx_free(lcpc_ctx* c) {
   (void)hipSetDevice(c->prm.device);
   comm_release(c);
+  dev_free(c->d_pack[0]); dev_free(c->d_pack[1]);
   dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
   dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->d_scratch);
   for (auto* v : {&c->d_pre, &c->d_post})
@@ -124,7 +125,8 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.copy_dst = first ? j.copy_dst : nullptr;
       a.n_rows = n_rows;
       a.log_n = c->log_n; a.t0 = p.t0; a.s = p.s; a.log_tj = p.log_tj;
-      ECHK(launch_ntt_pass(c->NL, p.log_tile, a, st));
+      if (c->l9s) ECHK(launch_ntt_pass_l9s(a, first, c->d_pack[first ? 0 : 1], c->pack_info[first ? 0 : 1], st));
+      else ECHK(launch_ntt_pass(c->NL, p.log_tile, a, st));
       nl++;
       first = false;
     }
@@ -378,6 +380,21 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
     if ((rc = dev_alloc(err, &c->d_r2, 8 * f->L))) return rc;
     HIPCHK(c, hipMemcpy(c->d_r2, f->r2, 8 * f->L, hipMemcpyHostToDevice));
     plan_passes(c);
+    if (c->d_qp29 && !getenv("LCPC_NTT_GENERAL") && ntt_l9s_supported(c->log_n, (uint32_t)c->passes.size(), c->passes[0].log_tile)) {
+      // two passes on 1024-element tiles: the shape-specialised kernel with its lane-order twiddle packs
+      for (int i = 0; i < 2; i++) {
+        const Pass& ps = c->passes[i];
+        const bool first = i == 0;
+        NttPassArgs a{};
+        a.roots29 = c->d_roots29; a.roots29c = c->d_roots29c; a.log_n = c->log_n; a.t0 = ps.t0; a.s = ps.s; a.log_tj = ps.log_tj;
+        c->pack_info[i] = ntt_l9s_pack_info(ps.s, first);
+        const uint32_t n_classes = first ? 1u << (c->log_n - 10) : 1u;
+        if ((rc = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return rc;
+        HIPCHK(c, launch_ntt_l9s_pack(a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
+      }
+      HIPCHK(c, hipDeviceSynchronize());
+      c->l9s = true;
+    }
     return 0;
   }
   if (p->encoding != LCPC_ENC_SDIG) return LCPC_ERR_ARG;

@@ -441,6 +441,40 @@ LCPC_DEV void clamp(L9& a, const u32* qp) {
   }
   a.v[8] = (u32)d[8];
 }
+// ---- normalise + clamp in ONE carry pass (ntt_pass_l9s_kernel) ----------------------------------------------------
+// The pure-sum output of a radix-4 butterfly, c0 = x0 + x1 + x2 + x3 of four normalised values, has limbs 0..7 in
+// [0, 2^31 - 4] and a signed top limb; |value| < 16p.  clamp_q() estimates the quotient from that UN-normalised top limb
+// (the carries still sitting in the lower limbs, at most 3 units of 2^232, are not in it yet), the row q*p is fetched from
+// the NEGATED table nqp[i] = -(i - QOFF) * p (limb-wise; the kernel negates the l9::clamp table when it copies it to
+// LDS), and clamp_apply() adds row and carries in one sweep.  With t' = t - c (c in [0, 3] the unseen carry) the
+// derivation above l9::clamp gives  V - q p = q (2^232 - plow) + (rem + QBIAS + c) 2^232 + low:  still >= 0 and
+// < (ptop + 1 + QBIAS + |q| + 1 + 3) 2^232 < p + 2^239.  Per limb: d = a_k - t_k + carry in (-2^29 - 1, 2^31) fits i32.
+struct Row9 {
+  u32 v[9];
+};
+LCPC_DEV u32 clamp_q(u32 top) {
+  constexpr u32 PTOP1 = (u32)(P29::limb(8)) + 1;
+  constexpr u64 MAGIC = (((u64)1 << 52) + PTOP1 - 1) / PTOP1;
+  const u32 n = top + (u32)(QOFF * PTOP1 - QBIAS);                       // in [0, 2^29) for |value| < 16p
+  return (u32)(((u64)n * MAGIC) >> 52);
+}
+LCPC_DEV Row9 clamp_row(const u32* nqp, u32 q) {
+  const uint4 a = *reinterpret_cast<const uint4*>(nqp + q * 12), b = *reinterpret_cast<const uint4*>(nqp + q * 12 + 4);
+  Row9 r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  r.v[8] = nqp[q * 12 + 8];
+  return r;
+}
+LCPC_DEV void clamp_apply(L9& a, const Row9& nt) {
+  int32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int32_t d = (int32_t)(a.v[k] + nt.v[k] + (u32)c);
+    a.v[k] = (u32)d & M;
+    c = d >> 29;
+  }
+  a.v[8] = a.v[8] + nt.v[8] + (u32)c;
+}
 // (a * w) * 2^-261 mod p, loosely: a limbs in (-2^30, 2^30), |value| < 16p; w normalised, in [0, p) (2^261-Montgomery
 // form).  Column sums stay inside i64: 9 * 2^59 + 8 * 2^58 + 2^34 < 2^63.  Result: normalised, in (-1.2p, 0.2p].
 LCPC_DEV L9 mul(const L9& a, const Fe29& w) {

@@ -65,6 +65,9 @@ struct lcpc_ctx {
   bool comm_canon = false;         // d_comm of a commit holds canonical values (x * R^-1), not Montgomery form: the column
                                    // hash reads them as they are; every read-out (get_comm, open_columns) converts back
   std::vector<lcpc::Pass> passes;
+  uint32_t* d_pack[2] = {nullptr, nullptr};   // Ft255 two-pass plans: lane-order twiddle packs of the specialised kernel (ntt_l9s.hip)
+  lcpc::NttPackInfo pack_info[2]{};
+  bool l9s = false;
   // Brakedown
   lcpc::SdigSpec spec{};
   std::vector<lcpc::LevelDims> pre_dims, post_dims;

@@ -25,6 +25,18 @@ struct NttPassArgs {
 };
 hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream_t st);
 
+// ---- shape-specialised Ft255 NTT for two-pass plans on 1024-element tiles (ntt_l9s.hip) ----
+// twiddle pack of one pass: per tile class, per round, the table entries in lane order (layout: ntt_l9s.hip)
+struct NttPackInfo {
+  uint32_t round_off[8];    // word offset of round slot r inside a class block
+  uint32_t class_words;     // words per tile class
+};
+bool ntt_l9s_supported(uint32_t log_n, uint32_t n_passes, int log_tile);
+NttPackInfo ntt_l9s_pack_info(uint32_t s, bool first);
+// a: the pass (log_n, t0, s, log_tj, roots29, roots29c); first pass: n_classes = tiles per row, last pass: 1
+hipError_t launch_ntt_l9s_pack(const NttPassArgs& a, bool first, const NttPackInfo& pi, uint32_t n_classes, uint32_t* pack, hipStream_t st);
+hipError_t launch_ntt_pass_l9s(const NttPassArgs& a, bool first, const uint32_t* pack, const NttPackInfo& pi, hipStream_t st);
+
 // device-side precomp_fft: roots[i] = w^i (i < 2^log_half) from pw[j] = w^(2^j); roots29 (Ft255) may be null
 hipError_t launch_roots(int nl, const uint32_t* pw, uint32_t log_half, const uint32_t* one, uint32_t* roots, uint32_t* roots29,
                         uint32_t* roots29c, hipStream_t st);

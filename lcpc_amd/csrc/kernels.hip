@@ -13,6 +13,7 @@
 // fully-reduced results; the kernels are free to re-associate (multi-pass NTT, split sums).
 #include "kernels.h"
 #include "field_dev.h"
+#include "ntt_l9_dev.h"
 #include "blake3_dev.h"
 #include <algorithm>
 
@@ -240,24 +241,6 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
 // per row), reduced explicitly at the store.  comm then holds canonical values (LcCommit.coeffs, copied from the
 // loads, stays in Montgomery form); the hash kernel reads them as they are.
 // -------------------------------------------------------------------------------------------------
-template <int LT> struct Lds9 {
-  static constexpr u32 T = 1u << LT;
-  static constexpr u32 WORDS = T * 9 + 64 * 12;              // tile + q*p table (64 entries, 12-word stride)
-};
-template <int LT> __device__ __forceinline__ L9 lds9_get(const u32* lds, u32 e) {
-  const uint4 a = *reinterpret_cast<const uint4*>(lds + (size_t)e * 4);
-  const uint4 b = *reinterpret_cast<const uint4*>(lds + ((size_t)Lds9<LT>::T + e) * 4);
-  L9 r;
-  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-  r.v[8] = lds[(size_t)Lds9<LT>::T * 8 + e];
-  return r;
-}
-template <int LT> __device__ __forceinline__ void lds9_put(u32* lds, u32 e, const L9& x) {
-  *reinterpret_cast<uint4*>(lds + (size_t)e * 4) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-  *reinterpret_cast<uint4*>(lds + ((size_t)Lds9<LT>::T + e) * 4) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
-  lds[(size_t)Lds9<LT>::T * 8 + e] = x.v[8];
-}
-
 template <int LT>
 __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
   constexpr int NL = 8;

@@ -1,0 +1,338 @@
+// lcpc_amd/csrc/ntt_l9s.hip -- K1s: the shape-specialised Ft255 row NTT (LcEncoding::encode for Ligero,
+// lcpc-ligero-pc/src/lib.rs:162-164 = fffft fft_io_pc [3P]) for the two-pass plans on 1024-element tiles
+// (2^11 <= n_cols <= 2^18, which covers BASELINE.json's Ligero configs).
+//
+// Same tiling, same lazy signed 9 x 29-bit arithmetic and the same canonical-output trick as ntt_pass_l9_kernel
+// (kernels.hip, which stays the general kernel: one pass, three passes, 2048-element tiles); what differs is where the
+// non-multiplier instructions went (profiles/r02_ntt_lab_*.txt: the kernel is VALU-issue bound, every instruction counts):
+//   * the pass shape -- S stages on 2^S x 2^LTJ tiles, first or last pass -- is a template parameter, so the index
+//     math of a round is a handful of shifts instead of ~40 instructions on run-time shifts and masks;
+//   * twiddles come from a per-pass PACK in lane order: for tile class c (first pass: the tile's position in the row;
+//     last pass: one class) and round r the twiddles of quad q sit at [c][r][variant][chunk][q mod period], so a wave
+//     reads 1 KiB runs instead of gathering 64 x 48-byte table entries at strides of up to 12 KiB;
+//   * normalise + clamp of the pure-sum output are one carry pass (l9::clamp_apply), the q*p row is fetched from LDS
+//     before the multiplier chains start;
+//   * the first pass stores values in [0, p + 2^239) (< 2^256, what its successor reads as limbs anyway) without the
+//     final conditional subtract; the last pass does that subtract only for the rare waves that need it;
+//   * an odd stage count is peeled as a radix-2 round at stage 0, where a zero-padded row (rate <= 1/2) needs no
+//     additions at all: (x, 0) -> (x, x w).
+// Exact modular arithmetic: any stage grouping gives the same fully-reduced bits as the reference's radix-2 loop.
+#include "kernels.h"
+#include "ntt_l9_dev.h"
+
+namespace lcpc {
+
+namespace {
+
+// pack block of one (class, round): [NV variants][2 chunks of 16 B][period] uint4, then [NV][period] u32 (limb 8).
+// radix-4 rounds: variants 0 w0, 1 w1, 2 w2 (plain table, w^i * 2^261) and 3, 4, 5 the same from the converting table
+// (w^i * 2^5); the radix-2 round: 0 w, 1 converting w.
+template <u32 NV> LCPC_DEV Fe29 pk_load(const u32* blk, u32 period, u32 variant, u32 jl) {
+  const uint4 a = *reinterpret_cast<const uint4*>(blk + ((size_t)(variant * 2 + 0) * period + jl) * 4);
+  const uint4 b = *reinterpret_cast<const uint4*>(blk + ((size_t)(variant * 2 + 1) * period + jl) * 4);
+  const u32 c = blk[(size_t)NV * 2 * period * 4 + (size_t)variant * period + jl];
+  Fe29 t;
+  t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w; t.v[4] = b.x; t.v[5] = b.y; t.v[6] = b.z; t.v[7] = b.w; t.v[8] = c;
+  return t;
+}
+
+// round structure of a pass with S stages on tiles of 2^S x 2^LBT slots: an odd S peels stage 0 as a radix-2 round
+// (slot 0 of the pack), the radix-4 rounds r = 0, 1, .. then cover stages (U0 + 2r, U0 + 2r + 1)
+template <int S, int LBT> struct Shape {
+  static constexpr int U0 = S & 1;
+  static constexpr int NR4 = S / 2;
+  static constexpr u32 period2 = 1u << (S - 1 + LBT);                     // radix-2 round: all 512 pairs differ
+  static constexpr u32 period4(int r) { return 1u << (S - U0 - 2 * r - 2 + LBT); }
+};
+
+template <int S, int LTJ, bool FIRST>
+__global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, const u32* __restrict__ pack, NttPackInfo pi) {
+  constexpr int NL = 8, LT = S + LTJ, LBT = LTJ;
+  constexpr bool LAST = !FIRST;
+  static_assert(LT == 10, "1024-element tiles: one radix-4 quad (two radix-2 pairs) per thread and round");
+  static_assert(FIRST || (LTJ == 0 && S % 2 == 0), "the last pass works on contiguous tiles and ends with the trivial stages k-2, k-1");
+  using SH = Shape<S, LBT>;
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  u32* nqp = lds + (size_t)Lds9<LT>::T * 9;                  // NEGATED q*p rows (l9::clamp_apply)
+  const u32 k = a.log_n;
+  constexpr u32 T = 1u << LT;
+  const u32 tiles_per_row = 1u << (k - LT);
+  u64 row;
+  u32 tile;
+  if (tiles_per_row >= 8) {                                  // XCD-aware order, as in ntt_pass_kernel
+    const u32 xcd = blockIdx.x & 7u;
+    const u64 qq = blockIdx.x >> 3;
+    tile = (u32)(qq / a.n_rows) * 8u + xcd;
+    row = qq % a.n_rows;
+  } else {
+    row = blockIdx.x / tiles_per_row;
+    tile = blockIdx.x % tiles_per_row;
+  }
+  const u32 tid = threadIdx.x;
+  const u32 lb = FIRST ? k - S : 0u;                         // index bits below the pass's stage field
+  // element index of LDS slot e = (i << LBT) | lp.  First pass: (i << lb) | (tile << LTJ) | lp; last pass: tile * 2^S + i
+  auto gindex = [&](u32 e) -> u32 {
+    if constexpr (FIRST) return ((e >> LBT) << lb) | (tile << LTJ) | (e & ((1u << LBT) - 1));
+    else return (tile << S) | e;
+  };
+  const bool canon = a.roots29c != nullptr;
+  for (u32 i = tid; i < 64 * 12; i += 256) nqp[i] = 0u - a.qp29[i];
+  const u32* src = a.src + row * a.src_stride * NL;
+#pragma unroll
+  for (u32 e = tid; e < T; e += 256) {
+    const u32 g = gindex(e);
+    Fe<NL> v;
+    if constexpr (FIRST) {        // zero padding, the ragged tail of the caller's vector and the coeffs copy exist here only
+      v = (g < a.n_valid && row * a.src_stride + g < a.n_src_total) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
+      if (a.copy_dst != nullptr && g < a.n_valid) fe_store<NL>(a.copy_dst + (row * a.src_stride + g) * NL, v);
+    } else {
+      v = fe_load<NL>(src + (size_t)g * NL);                 // < 2^256 (the first pass's store), not necessarily < p
+    }
+    lds9_put<LT>(lds, e, l9::from_packed(v));
+  }
+  __syncthreads();
+  const u32* cls_pack = pack + (size_t)(FIRST ? tile : 0u) * pi.class_words;
+  const bool blk0_tile = FIRST || tile == 0;                 // tiles that hold elements of "block 0" (never multiplied so far)
+  const bool zero_hi = FIRST && a.n_valid <= (1ull << (k - 1));
+
+  if constexpr (SH::U0 == 1) {
+    // ---- radix-2 round at stage 0 (odd S): pairs (e1, e1 + half), twiddle w^(index of e1).  Inputs straight from the
+    //      loads (< p).  Stage 0 is all block 0: with canonical output the product takes the converting table.
+    constexpr u32 half = 1u << (S - 1 + LBT);
+    const u32* blk = cls_pack + pi.round_off[0];
+#pragma unroll
+    for (u32 pp = 0; pp < 2; pp++) {
+      const u32 e1 = tid + 256u * pp;                        // slots with the top stage bit clear are [0, half)
+      const Fe29 w = pk_load<2>(blk, SH::period2, canon ? 1u : 0u, e1);
+      const L9 x = lds9_get<LT>(lds, e1);
+      if (zero_hi) {
+        lds9_put<LT>(lds, e1 + half, l9::mul(x, w));         // (x, 0) -> (x, x w)
+      } else {
+        const L9 y = lds9_get<LT>(lds, e1 + half);
+        L9 sum = l9::add(x, y);                              // [0, 2p)
+        l9::normalize(sum);
+        lds9_put<LT>(lds, e1, sum);
+        lds9_put<LT>(lds, e1 + half, l9::mul(l9::sub(x, y), w));
+      }
+    }
+    __syncthreads();
+  }
+
+  const u32 q = tid;                                         // one quad per thread per radix-4 round (T / 4 == 256)
+#pragma unroll
+  for (int r = 0; r < SH::NR4; r++) {
+    const int u = SH::U0 + 2 * r, hb = S - u - 1;            // stages (u, u + 1) of this pass; pair bit of stage u
+    const bool last_two = LAST && (r == SH::NR4 - 1);        // stages k-2, k-1: twiddles 1, w^(n/4), 1
+    const u32 lp = q & ((1u << LBT) - 1), j = q >> LBT;
+    const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+    const u32 e0 = (i0 << LBT) | lp;
+    constexpr u32 one = 1u;
+    const u32 dq = one << (hb - 1 + LBT);
+    const u32 period = one << (hb - 1 + LBT);                // quads q and q + period share their twiddles
+    const u32 jl = q & (period - 1);
+    const u32* blk = cls_pack + pi.round_off[SH::U0 + r];
+    if (u == 0 && zero_hi) {
+      // zero-padded first round (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x w); inputs < p; everything
+      // is block 0, so with canonical output the multiplies leaving it (w0, w1, and w2 for c1) take the converting set
+      const u32 vb = canon ? 3u : 0u;
+      const Fe29 w0 = pk_load<6>(blk, period, vb + 0, jl), w2c = pk_load<6>(blk, period, vb + 2, jl), w2 = pk_load<6>(blk, period, 2, jl);
+      if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
+        const L9 x0 = lds9_get<LT>(lds, e0);
+        lds9_put<LT>(lds, e0 + dq, l9::mul(x0, w2c));
+        const L9 b2 = l9::mul(x0, w0);
+        lds9_put<LT>(lds, e0 + 2 * dq, b2);
+        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(b2, w2));
+      } else {
+        const Fe29 w1 = pk_load<6>(blk, period, vb + 1, jl);
+        const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
+        L9 c0 = l9::add(x0, x1);                                                           // [0, 2p)
+        l9::normalize(c0);
+        lds9_put<LT>(lds, e0, c0);
+        lds9_put<LT>(lds, e0 + dq, l9::mul(l9::sub(x0, x1), w2c));
+        const L9 b2 = l9::mul(x0, w0), b3 = l9::mul(x1, w1);                               // (-1.2p, 0.2p]
+        L9 c2 = l9::add(b2, b3);
+        l9::normalize(c2);
+        lds9_put<LT>(lds, e0 + 2 * dq, c2);
+        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2));
+      }
+      __syncthreads();
+      continue;
+    }
+    const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
+    const L9 x2 = lds9_get<LT>(lds, e0 + 2 * dq), x3 = lds9_get<LT>(lds, e0 + 3 * dq);     // I: normalised, |value| < 4p
+    const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);                                   // limbs [0, 2^30), |value| < 8p
+    L9 c0 = l9::add(b0, b1);                                                               // limbs [0, 2^31), |value| < 16p
+    if (last_two) {
+      // outputs go straight to the store path (normalised, |value| < 16p)
+      l9::normalize(c0);
+      const Fe29 wq = tw_entry29(a.roots29, 1u << (k - 2));                                // wave-uniform
+      L9 c1 = l9::sub(b0, b1);
+      const L9 b2 = l9::sub(x0, x2);
+      const L9 b3 = l9::mul(l9::sub(x1, x3), wq);
+      L9 c2 = l9::add(b2, b3);
+      L9 c3 = l9::sub(b2, b3);
+      l9::normalize(c1); l9::normalize(c2); l9::normalize(c3);
+      lds9_put<LT>(lds, e0, c0);
+      lds9_put<LT>(lds, e0 + dq, c1);
+      lds9_put<LT>(lds, e0 + 2 * dq, c2);
+      lds9_put<LT>(lds, e0 + 3 * dq, c3);
+    } else {
+      const l9::Row9 nt = l9::clamp_row(nqp, l9::clamp_q(c0.v[8]));                        // in flight while the multipliers run
+      // block 0 of stages (u, u + 1) = the quads whose elements all lie below n / 2^(t + 2): here exactly q < period in the
+      // tiles that hold block 0.  Their three multiplies that leave block 0 take the converting set; c0 stays a pure sum;
+      // c3's inputs b2, b3 are already canonical
+      const bool blk0c = canon && blk0_tile && q < period;
+      const u32 vb = blk0c ? 3u : 0u;
+      const Fe29 w0 = pk_load<6>(blk, period, vb + 0, jl), w1 = pk_load<6>(blk, period, vb + 1, jl);
+      const Fe29 w2 = pk_load<6>(blk, period, 2, jl);
+      const L9 d1 = l9::sub(b0, b1);                                                       // limbs (-2^30, 2^30), |value| < 16p
+      L9 c1;
+      if (blk0c) c1 = l9::mul(d1, pk_load<6>(blk, period, 5, jl));
+      else c1 = l9::mul(d1, w2);
+      lds9_put<LT>(lds, e0 + dq, c1);                                                      // normalised, (-1.2p, 0.2p]
+      const L9 b2 = l9::mul(l9::sub(x0, x2), w0);                                          // in: |value| < 8p
+      const L9 b3 = l9::mul(l9::sub(x1, x3), w1);
+      L9 c2 = l9::add(b2, b3);                                                             // (-2.4p, 0.4p]
+      l9::normalize(c2);
+      lds9_put<LT>(lds, e0 + 2 * dq, c2);
+      lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2));
+      l9::clamp_apply(c0, nt);                                                             // [0, p + 2^239)
+      lds9_put<LT>(lds, e0, c0);
+    }
+    __syncthreads();
+  }
+
+  u32* dst = a.dst + row * a.dst_stride * NL;
+#pragma unroll
+  for (u32 e = tid; e < T; e += 256) {
+    const u32 g = gindex(e);
+    L9 x = lds9_get<LT>(lds, e);                                        // normalised, |value| < 16p
+    l9::clamp_apply(x, l9::clamp_row(nqp, l9::clamp_q(x.v[8])));        // [0, p + 2^239) < 2^256
+    u32 w[8];
+    fe_from29(w, x.v);
+    Fe<NL> v;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v.v[i] = w[i];
+    if constexpr (LAST) {
+      // -> [0, p): after the clamp, value >= p needs the top limb to reach floor(p / 2^232) -- about one element in 2^17;
+      // the conditional subtract runs only in the waves that hold such an element
+      if (__any((int)(x.v[8] >= (u32)P29::limb(8)))) v = fe_reduce_once8(w);
+      if (tile == 0 && g < a.mont_prefix) v = fe_canon_r29(v);          // canonical output: the never-multiplied prefix
+    }
+    fe_store<NL>(dst + (size_t)g * NL, v);
+  }
+}
+
+// one thread per (class, round slot, position): copies the table entries a quad / pair will ask for into lane order
+template <int S, int LBT>
+__global__ void __launch_bounds__(256) ntt_pack_kernel(NttPassArgs a, NttPackInfo pi, u32 n_classes, bool first, u32* pack) {
+  using SH = Shape<S, LBT>;
+  constexpr u32 n_slots = SH::U0 + SH::NR4;
+  constexpr u32 PMAX = 1u << (S - 1 + LBT);                  // >= every period
+  const u32 k = a.log_n, t0 = a.t0;
+  const u32 lb = first ? k - S : 0u;
+  const u64 total = (u64)n_classes * n_slots * PMAX;
+  for (u64 id = (u64)blockIdx.x * 256 + threadIdx.x; id < total; id += (u64)gridDim.x * 256) {
+    const u32 jl = (u32)(id % PMAX), slot = (u32)((id / PMAX) % n_slots), cls = (u32)(id / PMAX / n_slots);
+    u32* blk = pack + (size_t)cls * pi.class_words + pi.round_off[slot];
+    const u32 lo = first ? (cls << LBT) : 0u;                // first pass: the tile's own low index bits
+    if (SH::U0 == 1 && slot == 0) {                          // radix-2 round at stage t0: w^((g1 & gm) << t0), g1 = index of e1 = jl
+      const u32 lp = jl & ((1u << LBT) - 1), i = jl >> LBT;
+      const u32 g1 = (i << lb) | lo | lp;
+      const u32 gm = (1u << (k - t0 - 1)) - 1;
+      const u32 idx = (g1 & gm) << t0;
+      for (u32 v = 0; v < 2; v++) {
+        const u32* e = (v == 0 ? a.roots29 : a.roots29c) + (size_t)idx * 12;
+        for (u32 c = 0; c < 2; c++)
+          for (u32 w = 0; w < 4; w++) blk[((size_t)(v * 2 + c) * SH::period2 + jl) * 4 + w] = e[c * 4 + w];
+        blk[(size_t)2 * 2 * SH::period2 * 4 + (size_t)v * SH::period2 + jl] = e[8];
+      }
+      continue;
+    }
+    const u32 r = slot - SH::U0, u = SH::U0 + 2 * r, hb = S - u - 1, period = 1u << (hb - 1 + LBT);
+    const u32 t = t0 + u;
+    if (jl >= period || t + 2 == k) continue;                // (stages k-2, k-1: one wave-uniform twiddle, not packed)
+    const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
+    const u32 lp = jl & ((1u << LBT) - 1), j = jl >> LBT;
+    const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+    const u32 g0 = (i0 << lb) | lo | lp;                     // (last pass: the tile's high bits do not reach these twiddles)
+    const u32 g1 = g0 + (1u << (hb - 1 + lb));
+    const u32 idx[3] = {(g0 & gm0) << t, (g1 & gm0) << t, (g0 & gm1) << (t + 1)};
+    for (u32 v = 0; v < 6; v++) {
+      const u32* e = (v < 3 ? a.roots29 : a.roots29c) + (size_t)idx[v % 3] * 12;
+      for (u32 c = 0; c < 2; c++)
+        for (u32 w = 0; w < 4; w++) blk[((size_t)(v * 2 + c) * period + jl) * 4 + w] = e[c * 4 + w];
+      blk[(size_t)6 * 2 * period * 4 + (size_t)v * period + jl] = e[8];
+    }
+  }
+}
+
+template <int S, int LBT> NttPackInfo pack_info_t() {
+  using SH = Shape<S, LBT>;
+  NttPackInfo pi{};
+  u32 off = 0, slot = 0;
+  if (SH::U0) { pi.round_off[slot++] = off; off += 2 * SH::period2 * 9; off = (off + 3) & ~3u; }
+  for (int r = 0; r < SH::NR4; r++) { pi.round_off[slot++] = off; off += 6 * SH::period4(r) * 9; off = (off + 3) & ~3u; }
+  pi.class_words = off;
+  return pi;
+}
+
+template <int S, int LTJ, bool FIRST>
+hipError_t launch_t(const NttPassArgs& a, const u32* pack, const NttPackInfo& pi, hipStream_t st) {
+  constexpr int LT = S + LTJ;
+  const u64 tiles = ((u64)1 << (a.log_n - LT)) * a.n_rows;
+  const size_t lds_bytes = (size_t)Lds9<LT>::WORDS * 4;
+  // hipFuncSetAttribute is idempotent and cheap; calling it on every launch keeps this free of unsynchronised caches
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_l9s_kernel<S, LTJ, FIRST>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((ntt_pass_l9s_kernel<S, LTJ, FIRST>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a, pack, pi);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool ntt_l9s_supported(uint32_t log_n, uint32_t n_passes, int log_tile) { return n_passes == 2 && log_tile == 10 && log_n >= 11 && log_n <= 18; }
+
+#define L9S_FIRST_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+
+NttPackInfo ntt_l9s_pack_info(uint32_t s, bool first) {
+  if (!first) return pack_info_t<10, 0>();
+  switch (s) {
+#define X(SV) case SV: return pack_info_t<SV, 10 - SV>();
+    L9S_FIRST_CASES(X)
+#undef X
+  }
+  return NttPackInfo{};
+}
+
+hipError_t launch_ntt_l9s_pack(const NttPassArgs& a, bool first, const NttPackInfo& pi, uint32_t n_classes, uint32_t* pack, hipStream_t st) {
+  const unsigned grid = 2048;
+  if (!first) {
+    hipLaunchKernelGGL((ntt_pack_kernel<10, 0>), dim3(64), dim3(256), 0, st, a, pi, n_classes, false, pack);
+    return hipGetLastError();
+  }
+  switch (a.s) {
+#define X(SV) case SV: hipLaunchKernelGGL((ntt_pack_kernel<SV, 10 - SV>), dim3(grid), dim3(256), 0, st, a, pi, n_classes, true, pack); break;
+    L9S_FIRST_CASES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_ntt_pass_l9s(const NttPassArgs& a, bool first, const uint32_t* pack, const NttPackInfo& pi, hipStream_t st) {
+  if (!first) {
+    if (a.s != 10 || a.log_tj != 0 || a.t0 + a.s != a.log_n) return hipErrorInvalidValue;
+    return launch_t<10, 0, false>(a, pack, pi, st);
+  }
+  if (a.t0 != 0 || a.s + a.log_tj != 10 || a.s + 10 != a.log_n) return hipErrorInvalidValue;
+  switch (a.s) {
+#define X(SV) case SV: return launch_t<SV, 10 - SV, true>(a, pack, pi, st);
+    L9S_FIRST_CASES(X)
+#undef X
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace lcpc

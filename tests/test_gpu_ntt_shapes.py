@@ -1,0 +1,53 @@
+"""Every shape of the specialised Ft255 row NTT (ntt_l9s.hip): two-pass plans, n_cols = 2^11 .. 2^18, i.e. first passes of
+1 .. 8 stages (odd counts peel a radix-2 round at stage 0) on 2 .. 512-element runs, last pass of 10 stages.  For each:
+commit (canonical-output path, coeffs copy fused into pass 1, ragged last row) and encode_rows (Montgomery path) against
+the oracle, at the rates the reference uses (1/2 default, 1/4 timing test, 38/39 and 3/4: no zero half / partly zero).
+The general kernel (LCPC_NTT_GENERAL=1) must give the same bytes."""
+import os
+
+import numpy as np
+import pytest
+
+from lcpc_amd import LcCommit, LigeroEncoding
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("log_n", list(range(11, 19)))
+@pytest.mark.parametrize("rate", ["1/2", "1/4", "38/39", "3/4", "1/2-"])
+def test_commit_all_two_pass_shapes(oracle, log_n, rate):
+    O, fid = oracle, 3
+    n_cols = 1 << log_n
+    n_per_row, rho = {"1/2": (n_cols // 2, (1, 2)), "1/4": (n_cols // 4, (1, 4)), "38/39": (n_cols * 38 // 39, (38, 39)),
+                      "3/4": (n_cols * 3 // 4, (3, 4)), "1/2-": (n_cols // 2 - 3, (1, 2))}[rate]
+    n = 2 * n_per_row + max(1, n_per_row // 3)               # 3 rows, ragged
+    coeffs = O.random_elems(fid, n, log_n * 7 + len(rate))
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, rho=rho)
+    oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols, rho=rho)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+    assert c.get_root() == oc.get_root()
+    assert (c.hashes() == oc.hashes()).all()
+    assert (c.comm() == oc.comm()).all()
+    assert (c.coeffs() == oc.coeffs()).all()
+    # LcEncoding::encode on its own (no canonical-output conversion), rows 1 and 2
+    rows = np.zeros((2 * n_cols, 4), np.uint64)
+    rows[:n_per_row] = coeffs[n_per_row:2 * n_per_row]
+    rows[n_cols:n_cols + (n - 2 * n_per_row)] = coeffs[2 * n_per_row:]
+    assert (enc.encode(rows) == oc.comm()[n_cols:]).all()
+
+
+@pytest.mark.parametrize("log_n", [11, 14, 17, 18])
+def test_general_kernel_agrees(oracle, log_n):
+    O, fid = oracle, 3
+    n_cols, n_per_row = 1 << log_n, 1 << (log_n - 1)
+    coeffs = O.random_elems(fid, 5 * n_per_row - 9, 3 + log_n)
+    c = LcCommit.commit(coeffs, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols))
+    os.environ["LCPC_NTT_GENERAL"] = "1"
+    try:
+        enc_g = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    finally:
+        del os.environ["LCPC_NTT_GENERAL"]
+    g = LcCommit.commit(coeffs, enc_g)
+    assert (g.comm() == c.comm()).all() and (g.hashes() == c.hashes()).all()
+    assert g.get_root() == O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4).get_root()

@@ -364,9 +364,14 @@ __global__ void __launch_bounds__(256, 4) v2_kernel(NttPassArgs a, const u32* __
 #pragma unroll
   for (u32 e = tid; e < T; e += 256) {
     const u32 g = gindex(e);
-    const Fe<NL> v = (g < a.n_valid && row * a.src_stride + g < a.n_src_total) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
+    Fe<NL> v;
+    if constexpr (FIRST) {      // zero padding and the ragged tail of the caller's vector exist in the first pass only
+      v = (g < a.n_valid && row * a.src_stride + g < a.n_src_total) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
+      if (a.copy_dst != nullptr && g < a.n_valid) fe_store<NL>(a.copy_dst + (row * a.src_stride + g) * NL, v);
+    } else {
+      v = fe_load<NL>(src + (size_t)g * NL);
+    }
     lds9_put<LT>(lds, e, l9::from_packed(v));
-    if (a.copy_dst != nullptr && g < a.n_valid) fe_store<NL>(a.copy_dst + (row * a.src_stride + g) * NL, v);
   }
   __syncthreads();
   const u32 q = tid;                                         // one quad per thread per round (T / 4 == 256)
@@ -461,8 +466,14 @@ __global__ void __launch_bounds__(256, 4) v2_kernel(NttPassArgs a, const u32* __
     fe_from29(w, x.v);
     Fe<NL> v;
     if constexpr (LAST) {
-      v = fe_reduce_once8(w);
-      if (g < a.mont_prefix) v = fe_canon_r29(v);
+      // [0, p + 2^239) -> [0, p): the clamp leaves value >= p only when the top limb reaches floor(p / 2^232), about one
+      // element in 2^17 -- the conditional subtract runs for the (rare) waves that hold such an element
+      if (__any((int)(x.v[8] >= (u32)P29::limb(8)))) v = fe_reduce_once8(w);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v.v[i] = w[i];
+      }
+      if (tile == 0 && g < a.mont_prefix) v = fe_canon_r29(v);
     } else {
 #pragma unroll
       for (int i = 0; i < 8; i++) v.v[i] = w[i];                // < 2^256, == value mod p: the next pass takes it as it is
