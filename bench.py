@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power-sample", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--lean", action="store_true", help="the timed loop and the instrumented step only (what tools/profile_round.sh wraps in "
+                    "rocprofv3, so that per-kernel averages are not diluted by the secondary legs)")
     ap.add_argument("--cpu-sample-log-len", type=int, default=None, help="default: the full 2^log-len if host memory allows, else one less")
     ap.add_argument("--exchange", choices=["native", "torch"], default="native",
                     help="N > 1: native = RCCL inside the library (lcpc_commit_sharded_device); torch = torch.distributed all-gather "
@@ -162,6 +164,8 @@ def main():
     ap.add_argument("--check", action="store_true", help="debug: compare the sharded root with an unsharded commit of the same data")
     args = ap.parse_args()
 
+    if args.lean:
+        args.no_cpu_baseline = args.no_power_sample = args.no_e2e = True
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
     import torch
     import torch.distributed as dist
@@ -299,13 +303,13 @@ def main():
         # (tools/profile_round.sh); quoted only while the file was taken from exactly these kernel sources
         pmc = json.load(open(pmc_path))
         if pmc.get("kernel_stamp") == stamp and pmc.get("borrow_coeffs", False) == borrow:
-            for kname, v in pmc["kernels"].items():
-                if kname.startswith("ntt_pass"):
-                    traffic = round((2.0 * v["FETCH_KB"] + v["WRITE_KB"]) * 1024 / 1e9, 3)
-                    traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc, kernel stamp %s; GB per launch = 2*FETCH_SIZE + WRITE_SIZE)" % stamp
+            per = [(2.0 * v["FETCH_KB"] + v["WRITE_KB"]) * 1024 / 1e9 for kname, v in pmc["kernels"].items() if kname.startswith("ntt_pass")]
+            if per:         # the NTT passes are separate kernel instantiations, one launch each per commit: mean per launch
+                traffic = round(sum(per) / len(per), 3)
+                traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc, kernel stamp %s; GB per launch = 2*FETCH_SIZE + WRITE_SIZE, mean over the %d NTT passes)" % (stamp, len(per))
         else:
             traffic_src = "profiles/pmc_latest.json is stale for these kernels (stamp %s != %s): not quoted" % (pmc.get("kernel_stamp"), stamp)
-    roofline = {"bound": "hbm", "kernel": "ntt_pass_l9_kernel (row NTT, Ft255 signed lazy-limb variant; %d launches per commit)" % ntt_launches,
+    roofline = {"bound": "hbm", "kernel": "ntt_pass_l9s_kernel (row NTT, Ft255 signed lazy-limb arithmetic, shape-specialised; %d pass launches per commit)" % ntt_launches,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_unit": "GB/launch", "traffic_source": traffic_src,
                 "algorithmic_GB_per_launch": round(enc_bytes / ntt_launches / 1e9, 3),
@@ -323,7 +327,7 @@ def main():
 
     # secondary figures, N = 1, untimed region: the other LcCommit.coeffs mode and the end-to-end commit from host memory
     other_mode, e2e = None, None
-    if not distributed:
+    if not distributed and not args.lean:
         for _ in range(2):
             step(borrow_=not borrow)
         torch.cuda.synchronize()

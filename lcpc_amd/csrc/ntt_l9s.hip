@@ -10,8 +10,8 @@
 //   * twiddles come from a per-pass PACK in lane order: for tile class c (first pass: the tile's position in the row;
 //     last pass: one class) and round r the twiddles of quad q sit at [c][r][variant][chunk][q mod period], so a wave
 //     reads 1 KiB runs instead of gathering 64 x 48-byte table entries at strides of up to 12 KiB;
-//   * normalise + clamp of the pure-sum output are one carry pass (l9::clamp_apply), the q*p row is fetched from LDS
-//     before the multiplier chains start;
+//   * normalise + clamp of the pure-sum output are one carry pass (l9::clamp_apply), done before the multiplier
+//     chains start so that the sum does not occupy registers across them (no scratch spills at 128 VGPRs);
 //   * the first pass stores values in [0, p + 2^239) (< 2^256, what its successor reads as limbs anyway) without the
 //     final conditional subtract; the last pass does that subtract only for the rare waves that need it;
 //   * an odd stage count is peeled as a radix-2 round at stage 0, where a zero-padded row (rate <= 1/2) needs no
@@ -177,7 +177,10 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       lds9_put<LT>(lds, e0 + 2 * dq, c2);
       lds9_put<LT>(lds, e0 + 3 * dq, c3);
     } else {
-      const l9::Row9 nt = l9::clamp_row(nqp, l9::clamp_q(c0.v[8]));                        // in flight while the multipliers run
+      // clamp the pure sum at once: c0 leaves the registers before the multiplier chains start (holding it and its
+      // q*p row across them spills at 128 VGPRs: +1 GB of scratch writes per pass, profiles/r02b)
+      l9::clamp_apply(c0, l9::clamp_row(nqp, l9::clamp_q(c0.v[8])));                       // [0, p + 2^239)
+      lds9_put<LT>(lds, e0, c0);
       // block 0 of stages (u, u + 1) = the quads whose elements all lie below n / 2^(t + 2): here exactly q < period in the
       // tiles that hold block 0.  Their three multiplies that leave block 0 take the converting set; c0 stays a pure sum;
       // c3's inputs b2, b3 are already canonical
@@ -196,8 +199,6 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       l9::normalize(c2);
       lds9_put<LT>(lds, e0 + 2 * dq, c2);
       lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2));
-      l9::clamp_apply(c0, nt);                                                             // [0, p + 2^239)
-      lds9_put<LT>(lds, e0, c0);
     }
     __syncthreads();
   }

@@ -330,7 +330,7 @@ LCPC_DEV void clamp_apply(L9& a, const Row& nt) {
 }
 }  // namespace l9x
 
-template <int S, int LTJ, bool FIRST, bool LAST>
+template <int S, int LTJ, bool FIRST, bool LAST, int X>
 __global__ void __launch_bounds__(256, 4) v2_kernel(NttPassArgs a, const u32* __restrict__ pack, PackInfo pi) {
   constexpr int NL = 8, LT = S + LTJ, LBT = LTJ;
   static_assert(LT == 10 && S % 2 == 0, "lab: 1024-element tiles, radix-4 rounds only");
@@ -434,7 +434,13 @@ __global__ void __launch_bounds__(256, 4) v2_kernel(NttPassArgs a, const u32* __
       lds9_put<LT>(lds, e0 + 2 * dq, c2);
       lds9_put<LT>(lds, e0 + 3 * dq, c3);
     } else {
-      const l9x::Row nt = l9x::row_load(nqp, l9x::clamp_q(c0.v[8]));        // in flight while the multipliers run
+      l9x::Row nt;
+      if constexpr (X & 1) {                                 // X&1: clamp at once, c0 leaves the registers before the multipliers start
+        l9x::clamp_apply(c0, l9x::row_load(nqp, l9x::clamp_q(c0.v[8])));
+        lds9_put<LT>(lds, e0, c0);
+      } else {
+        nt = l9x::row_load(nqp, l9x::clamp_q(c0.v[8]));      // in flight while the multipliers run
+      }
       const bool blk0c = canon && blk0_tile && q < period;
       const u32 vb = blk0c ? 3u : 0u;
       const Fe29 w0 = pk_load(blk, period, vb + 0, jl), w1 = pk_load(blk, period, vb + 1, jl);
@@ -450,8 +456,10 @@ __global__ void __launch_bounds__(256, 4) v2_kernel(NttPassArgs a, const u32* __
       l9::normalize(c2);
       lds9_put<LT>(lds, e0 + 2 * dq, c2);
       lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2));
-      l9x::clamp_apply(c0, nt);
-      lds9_put<LT>(lds, e0, c0);
+      if constexpr (!(X & 1)) {
+        l9x::clamp_apply(c0, nt);
+        lds9_put<LT>(lds, e0, c0);
+      }
     }
     __syncthreads();
   }
@@ -482,13 +490,13 @@ __global__ void __launch_bounds__(256, 4) v2_kernel(NttPassArgs a, const u32* __
   }
 }
 
-template <int S, int LTJ, bool FIRST, bool LAST>
+template <int S, int LTJ, bool FIRST, bool LAST, int X = 0>
 static void launch_v2(const NttPassArgs& a, const u32* pack, const PackInfo& pi, hipStream_t st) {
   constexpr int LT = S + LTJ;
   const u64 tiles = ((u64)1 << (a.log_n - LT)) * a.n_rows;
   const size_t lds_bytes = (size_t)Lds9<LT>::WORDS * 4;
-  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&v2_kernel<S, LTJ, FIRST, LAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((v2_kernel<S, LTJ, FIRST, LAST>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a, pack, pi);
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&v2_kernel<S, LTJ, FIRST, LAST, X>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((v2_kernel<S, LTJ, FIRST, LAST, X>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a, pack, pi);
 }
 template <int S, int LBT> static PackInfo make_pack_info() {
   PackInfo pi{};
@@ -636,7 +644,21 @@ int main(int argc, char** argv) {
   time_variant("v2 (specialised, packed twiddles, merged clamp)", B, [&](const NttPassArgs& x) { launch_v2<8, 2, true, false>(x, d_packA, piA, nullptr); },
                [&](const NttPassArgs& x) { launch_v2<10, 0, false, true>(x, d_packB, piB, nullptr); });
   check("v2");
-  time_variant("product again", B, prod, prod);
+  time_variant("v2 X=1 (clamp before the multipliers)", B, [&](const NttPassArgs& x) { launch_v2<8, 2, true, false, 1>(x, d_packA, piA, nullptr); },
+               [&](const NttPassArgs& x) { launch_v2<10, 0, false, true, 1>(x, d_packB, piB, nullptr); });
+  check("v2 X=1");
+  {
+    // the library's specialised kernel (ntt_l9s.hip) through its own packs
+    const NttPackInfo qa = ntt_l9s_pack_info(8, true), qb = ntt_l9s_pack_info(10, false);
+    u32 *pa, *pb;
+    CHECK(hipMalloc(&pa, (size_t)n_cls_A * qa.class_words * 4)); CHECK(hipMalloc(&pb, (size_t)qb.class_words * 4));
+    CHECK(launch_ntt_l9s_pack(B.pa, true, qa, n_cls_A, pa, nullptr)); CHECK(launch_ntt_l9s_pack(B.pb, false, qb, 1, pb, nullptr));
+    CHECK(hipDeviceSynchronize());
+    time_variant("library ntt_pass_l9s_kernel", B, [&](const NttPassArgs& x) { CHECK(launch_ntt_pass_l9s(x, true, pa, qa, nullptr)); },
+                 [&](const NttPassArgs& x) { CHECK(launch_ntt_pass_l9s(x, false, pb, qb, nullptr)); });
+    check("library l9s");
+  }
+  time_variant("general kernel again", B, prod, prod);
 #define RUN(V, NAME) time_variant(NAME, B, [&](const NttPassArgs& x) { launch_lab<V>(x, nullptr); }, [&](const NttPassArgs& x) { launch_lab<V>(x, nullptr); })
   const bool brief = argc > 2;
   if (brief) {

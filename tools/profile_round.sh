@@ -11,18 +11,18 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 5 --warmup 1 --lean"
 python $R/bench.py > $O/bench_line.json 2> $O/bench_stderr.log
 db() { find $1 -name '*.db' | head -1; }
 rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- $BENCH > $O/kt.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/kt) > $O/bench_kernel_stats.txt
-rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench -- python $R/bench.py --steps 2 --warmup 1 --lean > $O/fetch.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/fetch) --pmc > $O/bench_pmc_fetch.txt
-rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench -- python $R/bench.py --steps 2 --warmup 1 --lean > $O/write.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/write) --pmc > $O/bench_pmc_write.txt
-python $R/tools/pmc_to_json.py $(db $O/fetch) $(db $O/write) $O/pmc.json > /dev/null
+python $R/tools/pmc_to_json.py $(db $O/fetch) $(db $O/write) $O/pmc.json > /dev/null      # -> copy to profiles/pmc_latest.json
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
-  -d $O/sq -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/sq.log 2>&1
+  -d $O/sq -o bench -- python $R/bench.py --steps 2 --warmup 1 --lean > $O/sq.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/sq) --pmc > $O/bench_pmc_sq.txt
 # clocks / power while the bench loops
 python $R/bench.py --steps 1200 --warmup 2 --no-cpu-baseline > $O/clk_bench.log 2>&1 &

@@ -11,7 +11,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"\(.*", "", name)
+    name = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
     name = name.replace("void ", "").replace("lcpc::", "")
     return name[:70]
 
