@@ -161,6 +161,9 @@ int  lcpc_open_columns(lcpc_commit_t *cm, const uint64_t *cols, uint32_t n, uint
 lcpc_transcript *lcpc_transcript_new(const uint8_t *label, size_t len);
 lcpc_transcript *lcpc_transcript_clone(const lcpc_transcript *);
 void lcpc_transcript_append_message(lcpc_transcript *, const uint8_t *label, size_t llen, const uint8_t *msg, size_t mlen);
+/* n calls of append_message(label, msgs + i * mlen) in one: the shape of prove / verify's per-coefficient absorbs
+ * (lib.rs:1045-1047); same transcript state as the loop, with the sponge kept in vector registers in between */
+void lcpc_transcript_append_messages(lcpc_transcript *, const uint8_t *label, size_t llen, const uint8_t *msgs, size_t mlen, size_t n);
 void lcpc_transcript_challenge_bytes(lcpc_transcript *, const uint8_t *label, size_t llen, uint8_t *out, size_t n);
 void lcpc_transcript_free(lcpc_transcript *);
 

@@ -51,6 +51,11 @@ class Transcript:
     def append_message(self, label, message):
         _lib.lib().lcpc_transcript_append_message(self._h, label, len(label), bytes(message), len(message))
 
+    def append_messages(self, label, messages, mlen):
+        """append_message(label, m) for every mlen-byte slice m of `messages`."""
+        messages = bytes(messages)
+        _lib.lib().lcpc_transcript_append_messages(self._h, label, len(label), messages, mlen, len(messages) // mlen)
+
     def challenge_bytes(self, label, n):
         out = C.create_string_buffer(n)
         _lib.lib().lcpc_transcript_challenge_bytes(self._h, label, len(label), out, n)
@@ -316,9 +321,7 @@ class LcCommit:
         pp, plen = C.c_void_p(), C.c_uint64()
         cols = np.zeros(enc.get_n_col_opens(), np.uint64)
         self._check(_lib.lib().lcpc_prove(self._h, _ptr(t), t.size // enc.L, tr._h, C.byref(pp), C.byref(plen), _ptr(cols)))
-        data = C.string_at(pp, plen.value)
-        _lib.lib().lcpc_free(pp)
-        return LcEvalProof(data, enc.L, cols)
+        return LcEvalProof(_OwnedBuffer(pp, plen.value), enc.L, cols)
 
     def set_timing(self, on=True):
         self._check(_lib.lib().lcpc_set_timing(self._h, 1 if on else 0))
@@ -335,14 +338,35 @@ class LcCommit:
             pass
 
 
+class _OwnedBuffer:
+    """a malloc'ed buffer handed out by the library (lcpc_prove): viewed in place, released with lcpc_free"""
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = ptr, n
+        self.view = (C.c_uint8 * n).from_address(ptr.value)
+
+    def __del__(self):
+        try:
+            _lib.lib().lcpc_free(self.ptr)
+        except Exception:
+            pass
+
+
 class LcEvalProof:
     """LcEvalProof<D, E> (lib.rs:490-500) held in the reference's bincode wire layout (lib.rs:550-609)."""
 
     def __init__(self, data, L, cols_opened=None):
-        self.data, self.L, self.cols_opened = bytes(data), L, cols_opened
-        self.n_cols, n_per_row = np.frombuffer(self.data[:16], np.uint64)
-        self._n_per_row = int(n_per_row)
-        self.n_cols = int(self.n_cols)
+        self._own = data if isinstance(data, _OwnedBuffer) else None
+        self._bytes = None if self._own else bytes(data)
+        self.L, self.cols_opened = L, cols_opened
+        hdr = np.frombuffer(self._own.view if self._own else self._bytes, np.uint64, 2)
+        self.n_cols, self._n_per_row = int(hdr[0]), int(hdr[1])
+
+    @property
+    def data(self):
+        if self._bytes is None:
+            self._bytes = bytes(self._own.view)
+        return self._bytes
 
     def get_n_cols(self):
         return self.n_cols
@@ -361,10 +385,10 @@ class LcEvalProof:
         """LcEvalProof::verify (lib.rs:518-527); returns the evaluation (L limbs) or raises LcpcError(VERR_*)."""
         o, i = _elems(outer_tensor, enc.L), _elems(inner_tensor, enc.L)
         out = np.zeros(enc.L, np.uint64)
-        buf = np.frombuffer(self.data, np.uint8)
+        buf = np.frombuffer(self._own.view if self._own else self._bytes, np.uint8)
         rootb = np.frombuffer(bytes(root), np.uint8)
         rc = _lib.lib().lcpc_verify(enc._h, _ptr(rootb), _ptr(o), o.size // enc.L, _ptr(i), i.size // enc.L,
-                                    _ptr(buf), len(self.data), tr._h, _ptr(out))
+                                    _ptr(buf), buf.size, tr._h, _ptr(out))
         if rc:
             raise LcpcError(rc)
         return out

@@ -58,6 +58,7 @@ SYMBOLS = {
     "lcpc_transcript_new": (_vp, [C.c_char_p, _sz]),
     "lcpc_transcript_clone": (_vp, [_vp]),
     "lcpc_transcript_append_message": (None, [_vp, C.c_char_p, _sz, C.c_char_p, _sz]),
+    "lcpc_transcript_append_messages": (None, [_vp, C.c_char_p, _sz, C.c_char_p, _sz, _sz]),
     "lcpc_transcript_challenge_bytes": (None, [_vp, C.c_char_p, _sz, _vp, _sz]),
     "lcpc_transcript_free": (None, [_vp]),
     "lcpc_prove": (_i32, [_vp, _vp, _u64, _vp, _vp, _vp, _vp]),

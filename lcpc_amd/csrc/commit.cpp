@@ -186,6 +186,33 @@ int collapse_run(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors
   return 0;
 }
 
+// collapse_columns for tensors in host memory; polys_canon (optional): the same polynomials as canonical values
+// (PrimeField::to_repr limbs, what the transcript absorbs, lib.rs:47-57), converted on the device
+int collapse_host(lcpc_commit_t* m, const uint64_t* tensors, uint32_t n_tensors, uint64_t* polys, uint64_t* polys_canon) {
+  if (!m || !tensors || !polys || n_tensors == 0) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  const lcpc_ctx* c = m->enc;
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  const size_t tb = ((size_t)n_tensors * m->n_rows_local * eb + 255) & ~(size_t)255;
+  const size_t pbytes = (size_t)n_tensors * c->n_per_row * eb;
+  const size_t pb = (pbytes + 255) & ~(size_t)255;
+  int rc = ensure_scratch(m, tb + 2 * pb + collapse_scratch_bytes(m, 2) + 512);
+  if (rc) return rc;
+  uint8_t* base = reinterpret_cast<uint8_t*>(m->d_scratch);
+  uint32_t* d_t = reinterpret_cast<uint32_t*>(base);
+  uint32_t* d_p = reinterpret_cast<uint32_t*>(base + tb);
+  uint32_t* d_pc = reinterpret_cast<uint32_t*>(base + tb + pb);
+  HIPCHK(m, hipMemcpyAsync(d_t, tensors, (size_t)n_tensors * m->n_rows_local * eb, hipMemcpyHostToDevice, nullptr));
+  if ((rc = collapse_run(m, d_t, n_tensors, nullptr, d_p))) return rc;
+  if (polys_canon) HIPCHK(m, launch_to_canon(c->NL, d_p, (uint64_t)n_tensors * c->n_per_row, d_pc, nullptr));
+  HIPCHK(m, hipMemcpyAsync(polys, d_p, pbytes, hipMemcpyDeviceToHost, nullptr));
+  if (polys_canon) HIPCHK(m, hipMemcpyAsync(polys_canon, d_pc, pbytes, hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(m, hipStreamSynchronize(nullptr));
+  return 0;
+}
+
 int open_columns_device(lcpc_commit_t* m, const uint64_t* d_cols, uint32_t n, uint32_t* d_vals, uint32_t* d_paths, hipStream_t st) {
   const lcpc_ctx* c = m->enc;
   if (d_vals && m->n_rows_local) {
@@ -195,6 +222,51 @@ int open_columns_device(lcpc_commit_t* m, const uint64_t* d_cols, uint32_t n, ui
       HIPCHK(m, launch_gather_columns(c->NL, m->d_comm, m->n_rows_local, c->n_cols, 1, d_cols, n, d_vals, c->comm_canon ? c->d_r2 : nullptr, st));
   }
   if (d_paths && c->path_len) HIPCHK(m, launch_gather_paths(m->d_hashes, c->np2, c->path_len, d_cols, n, d_paths, st));
+  return 0;
+}
+
+// open_column (lib.rs:788-825) for n columns into host memory.  vals_pitch: bytes between the values of consecutive
+// columns (0 = packed, n_rows * F): prove lets the device-to-host copy drop them straight into the bincode layout
+int open_columns_host(lcpc_commit_t* m, const uint64_t* cols, uint32_t n, uint64_t* col_vals, size_t vals_pitch, uint8_t* paths) {
+  if (!m || !cols || (!col_vals && !paths)) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  const lcpc_ctx* c = m->enc;
+  for (uint32_t i = 0; i < n; i++)
+    if (cols[i] >= c->n_cols) return LCPC_ERR_COLUMN_NUMBER;        // lib.rs:797-799
+  if (n == 0) return 0;
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  const size_t col_b = (size_t)m->n_rows_local * eb;
+  const size_t vb = (((size_t)n * col_b) + 255) & ~(size_t)255, pb = (((size_t)n * c->path_len * 32) + 255) & ~(size_t)255;
+  const size_t cb = (((size_t)n * 8) + 255) & ~(size_t)255;
+  int rc = ensure_scratch(m, vb + pb + cb);
+  if (rc) return rc;
+  uint8_t* base = reinterpret_cast<uint8_t*>(m->d_scratch);
+  uint64_t* d_cols = reinterpret_cast<uint64_t*>(base);
+  uint32_t* d_vals = reinterpret_cast<uint32_t*>(base + cb);
+  uint32_t* d_paths = reinterpret_cast<uint32_t*>(base + cb + vb);
+  HIPCHK(m, hipMemcpyAsync(d_cols, cols, (size_t)n * 8, hipMemcpyHostToDevice, nullptr));
+  if ((rc = open_columns_device(m, d_cols, n, col_vals ? d_vals : nullptr, paths ? d_paths : nullptr, nullptr))) return rc;
+  if (col_vals && m->n_rows_local) {
+    if (vals_pitch == 0 || vals_pitch == col_b)
+      HIPCHK(m, hipMemcpyAsync(col_vals, d_vals, (size_t)n * col_b, hipMemcpyDeviceToHost, nullptr));
+    else
+      HIPCHK(m, hipMemcpy2DAsync(col_vals, vals_pitch, d_vals, col_b, col_b, n, hipMemcpyDeviceToHost, nullptr));
+  }
+  if (paths && c->path_len) HIPCHK(m, hipMemcpyAsync(paths, d_paths, (size_t)n * c->path_len * 32, hipMemcpyDeviceToHost, nullptr));
+  HIPCHK(m, hipStreamSynchronize(nullptr));
+  return 0;
+}
+
+// pinned host memory that lives with the commitment (prove's tensors / polynomials: no page faults, full-speed D2H)
+int ensure_pinned(lcpc_commit_t* m, uint64_t bytes) {
+  if (bytes > m->h_pin_cap || !m->h_pin) {
+    if (m->h_pin) (void)hipHostFree(m->h_pin);
+    m->h_pin = nullptr; m->h_pin_cap = 0;
+    HIPCHK(m, hipHostMalloc(reinterpret_cast<void**>(&m->h_pin), (size_t)bytes, hipHostMallocDefault));
+    m->h_pin_cap = bytes;
+  }
   return 0;
 }
 
@@ -226,6 +298,7 @@ void lcpc_commit_destroy(lcpc_commit_t* m) {
   dev_free(m->d_t29); dev_free(m->ws.d_tmp); dev_free(m->ws.d_t); dev_free(m->d_gather); dev_free(m->d_xsend); dev_free(m->d_xrecv);
   for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : m->ev_batch) if (e) (void)hipEventDestroy(e);
+  if (m->h_pin) (void)hipHostFree(m->h_pin);
   if (m->s_copy) (void)hipStreamDestroy(m->s_copy);
   if (m->s_comp) (void)hipStreamDestroy(m->s_comp);
   ctx_unref(m->enc);
@@ -448,52 +521,14 @@ int lcpc_collapse_device(lcpc_commit_t* m, const uint64_t* tensors_dev, uint32_t
 }
 
 int lcpc_collapse(lcpc_commit_t* m, const uint64_t* tensors, uint32_t n_tensors, uint64_t* polys) {
-  if (!m || !tensors || !polys || n_tensors == 0) return LCPC_ERR_ARG;
-  if (!m->committed) return LCPC_ERR_STATE;
-  const lcpc_ctx* c = m->enc;
   LCPC_TRY
-  std::lock_guard<std::mutex> g(m->mu);
-  HIPCHK(m, hipSetDevice(c->prm.device));
-  const size_t eb = elem_bytes(c);
-  const size_t tb = ((size_t)n_tensors * m->n_rows_local * eb + 255) & ~(size_t)255;
-  const size_t pb = ((size_t)n_tensors * c->n_per_row * eb + 255) & ~(size_t)255;
-  int rc = ensure_scratch(m, tb + pb + collapse_scratch_bytes(m, 2) + 512);
-  if (rc) return rc;
-  uint8_t* base = reinterpret_cast<uint8_t*>(m->d_scratch);
-  uint32_t* d_t = reinterpret_cast<uint32_t*>(base);
-  uint32_t* d_p = reinterpret_cast<uint32_t*>(base + tb);
-  HIPCHK(m, hipMemcpyAsync(d_t, tensors, (size_t)n_tensors * m->n_rows_local * eb, hipMemcpyHostToDevice, nullptr));
-  if ((rc = collapse_run(m, d_t, n_tensors, nullptr, d_p))) return rc;
-  HIPCHK(m, hipMemcpy(polys, d_p, (size_t)n_tensors * c->n_per_row * eb, hipMemcpyDeviceToHost));
-  return 0;
+  return collapse_host(m, tensors, n_tensors, polys, nullptr);
   LCPC_CATCH(m)
 }
 
 int lcpc_open_columns(lcpc_commit_t* m, const uint64_t* cols, uint32_t n, uint64_t* col_vals, uint8_t* paths) {
-  if (!m || !cols || (!col_vals && !paths)) return LCPC_ERR_ARG;
-  if (!m->committed) return LCPC_ERR_STATE;
-  const lcpc_ctx* c = m->enc;
-  for (uint32_t i = 0; i < n; i++)
-    if (cols[i] >= c->n_cols) return LCPC_ERR_COLUMN_NUMBER;        // lib.rs:797-799
-  if (n == 0) return 0;
   LCPC_TRY
-  std::lock_guard<std::mutex> g(m->mu);
-  HIPCHK(m, hipSetDevice(c->prm.device));
-  const size_t eb = elem_bytes(c);
-  const size_t vb = (((size_t)n * m->n_rows_local * eb) + 255) & ~(size_t)255, pb = (((size_t)n * c->path_len * 32) + 255) & ~(size_t)255;
-  const size_t cb = (((size_t)n * 8) + 255) & ~(size_t)255;
-  int rc = ensure_scratch(m, vb + pb + cb);
-  if (rc) return rc;
-  uint8_t* base = reinterpret_cast<uint8_t*>(m->d_scratch);
-  uint64_t* d_cols = reinterpret_cast<uint64_t*>(base);
-  uint32_t* d_vals = reinterpret_cast<uint32_t*>(base + cb);
-  uint32_t* d_paths = reinterpret_cast<uint32_t*>(base + cb + vb);
-  HIPCHK(m, hipMemcpyAsync(d_cols, cols, (size_t)n * 8, hipMemcpyHostToDevice, nullptr));
-  if ((rc = open_columns_device(m, d_cols, n, col_vals ? d_vals : nullptr, paths ? d_paths : nullptr, nullptr))) return rc;
-  if (col_vals && m->n_rows_local) HIPCHK(m, hipMemcpyAsync(col_vals, d_vals, (size_t)n * m->n_rows_local * eb, hipMemcpyDeviceToHost, nullptr));
-  if (paths && c->path_len) HIPCHK(m, hipMemcpyAsync(paths, d_paths, (size_t)n * c->path_len * 32, hipMemcpyDeviceToHost, nullptr));
-  HIPCHK(m, hipStreamSynchronize(nullptr));
-  return 0;
+  return open_columns_host(m, cols, n, col_vals, 0, paths);
   LCPC_CATCH(m)
 }
 

@@ -507,6 +507,34 @@ int lcpc_encode_rows(lcpc_ctx* c, uint64_t* rows, uint64_t n_rows) {
   LCPC_CATCH(c)
 }
 
+}  // extern "C"
+
+namespace lcpc {
+// LcEncoding::encode for messages given WITHOUT their zero padding (msgs[i] = n_per_row elements): the padding is
+// produced on the device (fused into the first NTT pass / the Brakedown input copy), only n_per_row elements per row
+// cross PCIe.  out: n_rows x n_cols.  The verifier's 1 + n_degree_tests row encodes (lib.rs:886, 918).
+int encode_msgs_host(lcpc_ctx* c, const uint64_t* const* msgs, uint64_t n_rows, uint64_t* out) {
+  if (n_rows == 0) return 0;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  const size_t in_b = ((size_t)n_rows * c->n_per_row * eb + 255) & ~(size_t)255, out_b = (size_t)n_rows * c->n_cols * eb;
+  int rc = ensure_dev(&c->err, &c->d_scratch, &c->scratch_cap, in_b + out_b);
+  if (rc) return rc;
+  uint8_t* base = reinterpret_cast<uint8_t*>(c->d_scratch);
+  for (uint64_t i = 0; i < n_rows; i++)
+    HIPCHK(c, hipMemcpyAsync(base + i * c->n_per_row * eb, msgs[i], c->n_per_row * eb, hipMemcpyHostToDevice, nullptr));
+  EncodeJob j;
+  j.src = reinterpret_cast<uint32_t*>(base); j.src_stride = c->n_per_row; j.n_valid = c->n_per_row;
+  j.dst = reinterpret_cast<uint32_t*>(base + in_b); j.n_rows = n_rows;
+  if ((rc = encode_rows_device(c, &c->ws, j, nullptr, &c->err, nullptr))) return rc;
+  HIPCHK(c, hipMemcpy(out, base + in_b, out_b, hipMemcpyDeviceToHost));
+  return 0;
+}
+}  // namespace lcpc
+
+extern "C" {
+
 int lcpc_field_sum_device(lcpc_ctx* c, const uint64_t* parts, uint32_t n_parts, uint64_t n_elems, void* stream, uint64_t* out) {
   if (!c || !parts || !out || n_parts == 0) return LCPC_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->prm.device));

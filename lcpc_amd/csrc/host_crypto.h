@@ -10,7 +10,8 @@
 
 namespace lcpc {
 
-void keccak_f1600(uint64_t a[25]);
+void keccak_f1600(uint64_t a[25]);            // AVX-512 when the CPU has it (run-time check), else the portable form
+void keccak_f1600_portable(uint64_t a[25]);   // the scalar form, always (tests compare the two)
 
 // merlin 2.0 Transcript [3P]
 class Transcript {

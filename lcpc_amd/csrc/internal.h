@@ -111,6 +111,8 @@ struct lcpc_commit_s {
   uint64_t scratch_cap = 0;
   uint32_t* d_t29 = nullptr;       // collapse: tensors in the 29-bit-limb form
   uint64_t t29_cap = 0;
+  uint8_t* h_pin = nullptr;        // pinned host arena of prove (tensors, polynomials, their canonical forms)
+  uint64_t h_pin_cap = 0;
   // timing
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -228,6 +230,8 @@ struct EncodeJob {
 };
 int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipStream_t st, std::string* err, uint32_t* launches);
 
+int encode_msgs_host(lcpc_ctx* c, const uint64_t* const* msgs, uint64_t n_rows, uint64_t* out);
+
 // ---- commit.cpp -------------------------------------------------------------------------------------
 int ensure_scratch(lcpc_commit_t* m, uint64_t bytes);
 int ensure_cvs(lcpc_commit_t* m, uint64_t n_chunks);
@@ -236,7 +240,10 @@ int merkle_top(lcpc_commit_t* m, hipStream_t st);       // zero padding leaves +
 int finish_timing(lcpc_commit_t* m, hipStream_t st);
 int collapse_run(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_polys);
 size_t collapse_scratch_bytes(const lcpc_commit_t* m, uint32_t n_tensors);
+int collapse_host(lcpc_commit_t* m, const uint64_t* tensors, uint32_t n_tensors, uint64_t* polys, uint64_t* polys_canon);
 // open_column values / paths into device buffers (either may be null)
+int open_columns_host(lcpc_commit_t* m, const uint64_t* cols, uint32_t n, uint64_t* col_vals, size_t vals_pitch, uint8_t* paths);
+int ensure_pinned(lcpc_commit_t* m, uint64_t bytes);
 int open_columns_device(lcpc_commit_t* m, const uint64_t* d_cols, uint32_t n, uint32_t* d_vals, uint32_t* d_paths, hipStream_t st);
 
 // ---- shard.cpp --------------------------------------------------------------------------------------

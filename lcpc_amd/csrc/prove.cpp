@@ -13,15 +13,23 @@ namespace lcpc {
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// tr.append_message(label, to_repr(poly[i])) for every coefficient (lib.rs:1045-1047, 1066-1068): to_repr
-// (Montgomery -> canonical little-endian, lib.rs:47-57) is independent per element and done in parallel; only the
-// STROBE absorb itself is serial
-static void absorb_poly(Transcript& tr, const uint8_t* label, const FieldDesc& f, const uint64_t* poly, uint64_t n) {
+// tr.append_message(label, to_repr(poly[i])) for every coefficient (lib.rs:1045-1047, 1066-1068).  to_repr (Montgomery ->
+// canonical little-endian, lib.rs:47-57) is independent per element: prove gets it from the device with the polynomial,
+// verify converts in parallel on the host; only the STROBE absorb itself is serial.
+static void to_canon_host(const FieldDesc& f, const uint64_t* poly, uint64_t n, uint64_t* canon) {
   const int L = f.L;
-  std::vector<uint64_t> canon(n * L);
-  parallel_for(n, 4096, [&](uint64_t b, uint64_t e) { for (uint64_t i = b; i < e; i++) h_canon(f, &canon[i * L], poly + i * L); });
-  tr.append_messages(label, 6, reinterpret_cast<const uint8_t*>(canon.data()), 8 * L, n);
+  parallel_for(n, 4096, [&](uint64_t b, uint64_t e) { for (uint64_t i = b; i < e; i++) h_canon(f, canon + i * L, poly + i * L); });
 }
+static void absorb_canon(Transcript& tr, const uint8_t* label, const FieldDesc& f, const uint64_t* canon, uint64_t n) {
+  tr.append_messages(label, 6, reinterpret_cast<const uint8_t*>(canon), 8 * f.L, n);
+}
+
+namespace {
+struct JoinGuard {          // a joinable std::thread must never be destroyed (std::terminate): join on every exit path
+  std::thread& t;
+  ~JoinGuard() { if (t.joinable()) t.join(); }
+};
+}  // namespace
 
 int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t** proof, uint64_t* proof_len,
                uint64_t* cols_opened, const ShardXchg* xchg) {
@@ -29,21 +37,48 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
   if (!m->committed) return LCPC_ERR_STATE;
   lcpc_ctx* c = m->enc;
   if (c->prm.shard_count > 1 && !xchg) return LCPC_ERR_STATE;   // sharded commitments prove through lcpc_prove_sharded*
-  auto collapse = [&](const uint64_t* tensors, uint32_t nt, uint64_t* polys) -> int {
-    return xchg ? collapse_sharded(m, *xchg, tensors, nt, polys) : lcpc_collapse(m, tensors, nt, polys);
+  const FieldDesc& f = *c->f;
+  const int L = f.L;
+  // polynomials in Montgomery form (what the proof carries) and as canonical values (what the transcript absorbs)
+  auto collapse = [&](const uint64_t* tensors, uint32_t nt, uint64_t* polys, uint64_t* canon) -> int {
+    if (!xchg) return collapse_host(m, tensors, nt, polys, canon);
+    int rc = collapse_sharded(m, *xchg, tensors, nt, polys);
+    if (!rc) to_canon_host(f, polys, (uint64_t)nt * c->n_per_row, canon);
+    return rc;
   };
   if (!lcpc_dims_ok(c, c->n_per_row, c->n_cols)) return LCPC_ERR_COMMIT;      // check_comm lib.rs:1015
   if (n_outer != m->n_rows) return LCPC_ERR_OUTER_TENSOR;                     // lib.rs:1016-1018
-  const FieldDesc& f = *c->f;
-  const int L = f.L;
   Transcript& tr = trw->t;
   const uint64_t n_deg = lcpc_get_n_degree_tests(c), n_open = lcpc_get_n_col_opens(c);
   const uint64_t np = c->n_per_row, nr = m->n_rows;
   const bool dbg = getenv("LCPC_DEBUG_TIMING") != nullptr;
   double tp[8] = {now_ms(), 0, 0, 0, 0, 0, 0, 0};
   double t_collapse = 0, t_absorb = 0;
-  std::vector<uint64_t> tensors(2 * nr * L), polys(2 * np * L), p_eval(np * L);
-  std::vector<std::vector<uint64_t>> p_random(n_deg);
+  // bincode 1.3 of WrappedLcEvalProof (lib.rs:550-560): n_cols, p_eval, p_random_vec, columns.  The size is known up
+  // front, so the proof is written once, straight into the buffer the caller receives: the polynomials by a helper
+  // thread while this one runs the (serial) transcript, the opened columns by the device-to-host copy itself.
+  const size_t pbytes = np * L * 8;
+  const size_t col_bytes = 8 + nr * L * 8 + 8 + (size_t)c->path_len * 40;
+  const size_t off_eval = 8 + 8, off_rand0 = off_eval + pbytes + 8 + 8;      // first element of p_eval / of p_random_vec[0]
+  const size_t head = 8 + (8 + pbytes) + 8 + n_deg * (8 + pbytes) + 8;
+  const size_t total = head + n_open * col_bytes;
+  struct Buf { uint8_t* p = nullptr; ~Buf() { free(p); } } out;
+  out.p = static_cast<uint8_t*>(malloc(total ? total : 1));
+  if (!out.p) return LCPC_ERR_NOMEM;
+  // pinned arena that stays with the commitment: [tensors 2 nr][polys 2 np][canon 2 np] elements
+  const size_t a_t = 2 * nr * L, a_p = 2 * np * L;
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    int rc = ensure_pinned(m, (a_t + 2 * a_p) * 8);
+    if (rc) return rc;
+  }
+  uint64_t* tensors = reinterpret_cast<uint64_t*>(m->h_pin);
+  uint64_t* polys = tensors + a_t;
+  uint64_t* canon = polys + a_p;
+  std::vector<uint64_t> p_eval_canon;                                         // only when the eval tensor could not be fused
+  auto put64 = [&](size_t off, uint64_t v) { memcpy(out.p + off, &v, 8); };
+  std::thread filler;
+  JoinGuard join{filler};
   bool have_eval = false;
   for (uint64_t i = 0; i < n_deg; i++) {                                      // lib.rs:1024-1050
     uint8_t key[32];
@@ -56,21 +91,34 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
       nt = 2;
     }
     double t0 = now_ms();
-    int rc = collapse(tensors.data(), nt, polys.data());
+    if (filler.joinable()) filler.join();                                     // the arena is about to be overwritten
+    int rc = collapse(tensors, nt, polys, canon);
     if (rc) return rc;
     t_collapse += now_ms() - t0;
-    p_random[i].assign(polys.begin(), polys.begin() + np * L);
-    if (nt == 2) { memcpy(p_eval.data(), &polys[np * L], np * L * 8); have_eval = true; }
+    if (nt == 2) {
+      have_eval = true;
+      if (n_deg > 1) { p_eval_canon.assign(canon + np * L, canon + 2 * np * L); }
+    }
+    // the helper copies this round's polynomial(s) into the proof (and thereby faults the fresh pages in) meanwhile
+    filler = std::thread([=, &out] {
+      memcpy(out.p + off_rand0 + i * (8 + pbytes), polys, pbytes);
+      if (nt == 2) memcpy(out.p + off_eval, polys + np * L, pbytes);
+      if (i + 1 == n_deg) memset(out.p + head, 0, total - head);              // touch the column area before the copies land in it
+    });
     t0 = now_ms();
-    absorb_poly(tr, LBL_PR, f, p_random[i].data(), np);
+    absorb_canon(tr, LBL_PR, f, canon, np);
     t_absorb += now_ms() - t0;
   }
-  if (!have_eval) {                                                           // lib.rs:1053-1064
-    int rc = collapse(outer, 1, p_eval.data());
-    if (rc) return rc;
-  }
   tp[1] = now_ms();
-  absorb_poly(tr, LBL_PE, f, p_eval.data(), np);                              // lib.rs:1066-1068
+  if (!have_eval) {                                                           // lib.rs:1053-1064 (n_degree_tests == 0 cannot happen: >= 1)
+    if (filler.joinable()) filler.join();
+    int rc = collapse(outer, 1, polys, canon);
+    if (rc) return rc;
+    memcpy(out.p + off_eval, polys, pbytes);
+    absorb_canon(tr, LBL_PE, f, canon, np);
+  } else {
+    absorb_canon(tr, LBL_PE, f, n_deg > 1 ? p_eval_canon.data() : canon + np * L, np);   // lib.rs:1066-1068
+  }
   tp[2] = now_ms();
   uint8_t key[32];
   tr.challenge_bytes(LBL_CO, 6, key, 32);                                     // lib.rs:1071-1080
@@ -78,43 +126,42 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
   std::vector<uint64_t> cols(n_open);
   for (auto& x : cols) x = rng.uniform(c->n_cols);
   if (cols_opened) memcpy(cols_opened, cols.data(), n_open * 8);
-  // (uninitialised buffers: a Brakedown proof opens 6593 columns, tens of MB that are overwritten anyway)
-  std::unique_ptr<uint64_t[]> vals(new uint64_t[(size_t)n_open * nr * L + 1]);
   std::unique_ptr<uint8_t[]> paths(new uint8_t[(size_t)n_open * c->path_len * 32 + 32]);
+  if (filler.joinable()) filler.join();
   tp[3] = now_ms();
-  int rc = xchg ? open_sharded(m, *xchg, cols.data(), (uint32_t)n_open, vals.get(), paths.get())
-                : lcpc_open_columns(m, cols.data(), (uint32_t)n_open, vals.get(), paths.get());   // lib.rs:1081-1084
+  int rc;
+  uint64_t* vals0 = reinterpret_cast<uint64_t*>(out.p + head + 8);           // values of column 0; column k at + k * col_bytes
+  if (xchg) {
+    std::unique_ptr<uint64_t[]> vals(new uint64_t[(size_t)n_open * nr * L + 1]);
+    rc = open_sharded(m, *xchg, cols.data(), (uint32_t)n_open, vals.get(), paths.get());
+    if (!rc)
+      parallel_for(n_open, 64, [&](uint64_t b, uint64_t e) {
+        for (uint64_t k = b; k < e; k++) memcpy(out.p + head + k * col_bytes + 8, &vals[k * nr * L], nr * L * 8);
+      });
+  } else {
+    rc = open_columns_host(m, cols.data(), (uint32_t)n_open, vals0, col_bytes, paths.get());      // lib.rs:1081-1084
+  }
   if (rc) return rc;
   tp[4] = now_ms();
-  // bincode 1.3 of WrappedLcEvalProof (lib.rs:550-560): n_cols, p_eval, p_random_vec, columns -- the size is known
-  // up front, so the proof is written once, straight into the buffer the caller receives
-  const size_t pbytes = np * L * 8;
-  const size_t col_bytes = 8 + nr * L * 8 + 8 + (size_t)c->path_len * 40;
-  const size_t head = 8 + (8 + pbytes) + 8 + n_deg * (8 + pbytes) + 8;
-  const size_t total = head + n_open * col_bytes;
-  uint8_t* out = static_cast<uint8_t*>(malloc(total ? total : 1));
-  if (!out) return LCPC_ERR_NOMEM;
-  uint8_t* w = out;
-  auto w64 = [&](uint64_t v) { memcpy(w, &v, 8); w += 8; };
-  auto wbytes = [&](const void* d, size_t n) { memcpy(w, d, n); w += n; };
-  w64(c->n_cols);
-  w64(np); wbytes(p_eval.data(), pbytes);
-  w64(n_deg);
-  for (auto& pr : p_random) { w64(np); wbytes(pr.data(), pbytes); }
-  w64(n_open);
-  if ((size_t)(w - out) != head) { free(out); return LCPC_ERR_STATE; }
-  parallel_for(n_open, 64, [&](uint64_t b, uint64_t e) {
+  put64(0, c->n_cols);
+  put64(8, np);
+  put64(off_eval + pbytes, n_deg);
+  for (uint64_t i = 0; i < n_deg; i++) put64(off_rand0 - 8 + i * (8 + pbytes), np);
+  put64(head - 8, n_open);
+  parallel_for(n_open, 256, [&](uint64_t b, uint64_t e) {
     for (uint64_t k = b; k < e; k++) {
-      uint8_t* q = out + head + k * col_bytes;
+      uint8_t* q = out.p + head + k * col_bytes;
       auto q64 = [&](uint64_t v) { memcpy(q, &v, 8); q += 8; };
-      q64(nr); memcpy(q, &vals[k * nr * L], nr * L * 8); q += nr * L * 8;
+      q64(nr);
+      q += nr * L * 8;                                                        // the values are already there
       q64(c->path_len);
       for (uint32_t l = 0; l < c->path_len; l++) { q64(32); memcpy(q, &paths[((size_t)k * c->path_len + l) * 32], 32); q += 32; }
     }
   });
-  *proof = out; *proof_len = total;
+  *proof = out.p; *proof_len = total;
+  out.p = nullptr;
   if (dbg)
-    fprintf(stderr, "[lcpc_prove] collapse %.2f ms, absorb p_random %.2f, absorb p_eval %.2f, challenges+alloc %.2f, open %.2f, bincode %.2f, total %.2f\n",
+    fprintf(stderr, "[lcpc_prove] collapse %.2f ms, absorb p_random %.2f, absorb p_eval %.2f, challenges %.2f, open %.2f, bincode %.2f, total %.2f\n",
             t_collapse, t_absorb, tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3], now_ms() - tp[4], now_ms() - tp[0]);
   return 0;
 }
@@ -147,10 +194,6 @@ bool all_reduced(const FieldDesc& f, const uint64_t* v, uint64_t n) {
   });
   return ok.load();
 }
-struct JoinGuard {          // a joinable std::thread must never be destroyed (std::terminate): join on every exit path
-  std::thread& t;
-  ~JoinGuard() { if (t.joinable()) t.join(); }
-};
 }  // namespace
 
 }  // namespace lcpc
@@ -162,6 +205,9 @@ lcpc_transcript* lcpc_transcript_new(const uint8_t* label, size_t len) { return 
 lcpc_transcript* lcpc_transcript_clone(const lcpc_transcript* t) { return t ? new (std::nothrow) lcpc_transcript(*t) : nullptr; }
 void lcpc_transcript_append_message(lcpc_transcript* t, const uint8_t* label, size_t llen, const uint8_t* msg, size_t mlen) {
   if (t) t->t.append_message(label, llen, msg, mlen);
+}
+void lcpc_transcript_append_messages(lcpc_transcript* t, const uint8_t* label, size_t llen, const uint8_t* msgs, size_t mlen, size_t n) {
+  if (t) t->t.append_messages(label, llen, msgs, mlen, n);
 }
 void lcpc_transcript_challenge_bytes(lcpc_transcript* t, const uint8_t* label, size_t llen, uint8_t* out, size_t n) {
   if (t) t->t.challenge_bytes(label, llen, out, n);
@@ -243,95 +289,133 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
   if (n_deg_pf < n_deg) return LCPC_VERR_MALFORMED;                            // reference indexes p_random_vec[i] (would panic)
   for (uint64_t i = 0; i < n_deg; i++) if (p_random[i].size() != n_per_row * L) return LCPC_VERR_MALFORMED;
   for (auto& cv : cols) if (cv.size() != n_rows * L) return LCPC_VERR_MALFORMED;
-  // untrusted limbs: nothing >= p reaches the host or device arithmetic
+  // untrusted limbs: nothing >= p reaches the device arithmetic (the polynomials are checked before they are sent; the
+  // columns, which only meet host arithmetic, are checked by the side thread below)
   if (!all_reduced(f, p_eval.data(), n_per_row)) return LCPC_VERR_MALFORMED;
   for (uint64_t i = 0; i < n_deg_pf; i++) if (!all_reduced(f, p_random[i].data(), p_random[i].size() / L)) return LCPC_VERR_MALFORMED;
-  {
-    std::atomic<bool> ok{true};
-    parallel_for(n_columns, 16, [&](uint64_t b, uint64_t e) {
-      for (uint64_t i = b; i < e; i++)
-        for (uint64_t k = 0; k < n_rows; k++)
-          if (h_ge_p(f, cols[i].data() + k * L)) { ok.store(false); return; }
-    });
-    if (!ok.load()) return LCPC_VERR_MALFORMED;
-  }
-  // step 2 first: the 1 + n_deg row encodes (lib.rs:886, 918) depend only on the proof, not on the transcript, so they
-  // run on the GPU (own thread: upload, kernels, download) while this thread does step 1, the serial transcript work
-  std::vector<uint64_t> enc((n_deg + 1) * n_cols * L, 0);
-  for (uint64_t i = 0; i < n_deg; i++) memcpy(&enc[i * n_cols * L], p_random[i].data(), n_per_row * F);
-  memcpy(&enc[n_deg * n_cols * L], p_eval.data(), n_per_row * F);
+  // The transcript (step 1, lib.rs:868-920) is serial and takes almost all of the time; everything that does not need its
+  // outcome runs beside it:
+  //   enc thread   step 2, the 1 + n_deg row encodes (lib.rs:886, 918), on the GPU: the messages go up without their zero
+  //                padding, straight out of the proof buffer, the encoded rows come back whole;
+  //   side thread  to_repr of the polynomials the transcript absorbs (published one by one), the limb check of the
+  //                columns, and the part of step 3 (lib.rs:923-944) that does not depend on WHICH columns were drawn:
+  //                the tensor . column dot products and the leaf hash of every opened column, and <inner, p_eval>.
+  std::unique_ptr<uint64_t[]> enc(new uint64_t[(size_t)(n_deg + 1) * n_cols * L]);
+  std::vector<const uint64_t*> enc_msgs(n_deg + 1);
+  for (uint64_t i = 0; i < n_deg; i++) enc_msgs[i] = p_random[i].data();
+  enc_msgs[n_deg] = p_eval.data();
   std::vector<std::vector<uint64_t>> rand_tensors(n_deg, std::vector<uint64_t>(n_rows * L));
   std::vector<uint64_t> cols_to_open(n_columns);
-  std::vector<int> status(n_columns, 0);
+  std::vector<uint64_t> vcanon((n_deg + 1) * n_per_row * L);
+  std::vector<uint64_t> dots((n_deg + 1) * n_columns * MAXL);                 // dots[d][i] = <tensor_d, column i>
+  std::vector<uint8_t> leaf(n_columns * 32);
+  uint64_t eval_acc[MAXL] = {0, 0, 0, 0};
+  std::atomic<uint64_t> canon_ready{0};
+  std::atomic<bool> tensors_ready{false}, cols_bad{false}, side_failed{false};
   int enc_rc = 0;
-  double t_enc = 0;
+  double t_enc = 0, t_side = 0;
   tv[1] = now_ms();
-  std::thread enc_thread;
-  JoinGuard join{enc_thread};
-  enc_thread = std::thread([&] { const double t0 = now_ms(); enc_rc = lcpc_encode_rows(c, enc.data(), n_deg + 1); t_enc = now_ms() - t0; });
-  // step 1: random tensors, transcript (lib.rs:868-920)
+  std::thread enc_thread, side_thread;
+  JoinGuard join_enc{enc_thread}, join_side{side_thread};
+  struct Release { std::atomic<bool>& flag; ~Release() { flag.store(true); } } release{tensors_ready};   // (runs before the joins on every exit path)
+  enc_thread = std::thread([&] { const double t0 = now_ms(); enc_rc = encode_msgs_host(c, enc_msgs.data(), n_deg + 1, enc.get()); t_enc = now_ms() - t0; });
+  side_thread = std::thread([&] {
+    try {
+      const double t0 = now_ms();
+      for (uint64_t pi_ = 0; pi_ <= n_deg; pi_++) {
+        to_canon_host(f, pi_ < n_deg ? p_random[pi_].data() : p_eval.data(), n_per_row, &vcanon[pi_ * n_per_row * L]);
+        canon_ready.store(pi_ + 1, std::memory_order_release);
+      }
+      parallel_for(n_columns, 16, [&](uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; i++)
+          for (uint64_t k = 0; k < n_rows; k++)
+            if (h_ge_p(f, cols[i].data() + k * L)) { cols_bad.store(true); return; }
+      });
+      // <inner_tensor, p_eval> (lib.rs:947-951): partial sums over blocks of 4096 terms, added in block order
+      const uint64_t n_blk = (n_per_row + 4095) / 4096;
+      std::vector<uint64_t> part(n_blk * MAXL, 0);
+      parallel_for(n_blk, 2, [&](uint64_t b, uint64_t e) {
+        for (uint64_t blk = b; blk < e; blk++) {
+          uint64_t a[MAXL] = {0, 0, 0, 0}, t[MAXL];
+          const uint64_t k1 = std::min<uint64_t>(n_per_row, (blk + 1) * 4096);
+          for (uint64_t k = blk * 4096; k < k1; k++) { h_mul(f, t, inner + k * L, p_eval.data() + k * L); h_add(f, a, a, t); }
+          memcpy(&part[blk * MAXL], a, F);
+        }
+      });
+      for (uint64_t blk = 0; blk < n_blk; blk++) h_add(f, eval_acc, eval_acc, &part[blk * MAXL]);
+      while (!tensors_ready.load(std::memory_order_acquire)) std::this_thread::yield();
+      if (cols_bad.load()) return;
+      parallel_for(n_columns, 4, [&](uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; i++) {
+          for (uint64_t d = 0; d <= n_deg; d++) {
+            const uint64_t* tensor = d < n_deg ? rand_tensors[d].data() : outer;
+            uint64_t acc[MAXL] = {0, 0, 0, 0}, t[MAXL];
+            for (uint64_t k = 0; k < n_rows; k++) { h_mul(f, t, tensor + k * L, cols[i].data() + k * L); h_add(f, acc, acc, t); }
+            memcpy(&dots[(d * n_columns + i) * MAXL], acc, F);
+          }
+          hash_column_host(f, cols[i].data(), n_rows, &leaf[i * 32]);
+        }
+      }, n_columns * n_rows > ((uint64_t)1 << 19) ? 64u : 15u);       // Brakedown opens 6593 columns: ~0.1 s of work single-threaded
+      t_side = now_ms() - t0;
+    } catch (...) {
+      side_failed.store(true);
+      canon_ready.store(n_deg + 1);           // never leave the transcript thread waiting
+    }
+  });
+  // step 1: random tensors, transcript
+  auto wait_canon = [&](uint64_t n) { while (canon_ready.load(std::memory_order_acquire) < n) std::this_thread::yield(); };
   for (uint64_t i = 0; i < n_deg; i++) {
     uint8_t key[32];
     tr.challenge_bytes(LBL_DT, 6, key, 32);
     ChaCha20Rng rng(key);
     for (uint64_t k = 0; k < n_rows; k++) rng.field_random(f, &rand_tensors[i][k * L]);
-    absorb_poly(tr, LBL_PR, f, p_random[i].data(), n_per_row);
+    if (i + 1 == n_deg) tensors_ready.store(true, std::memory_order_release);
+    wait_canon(i + 1);
+    absorb_canon(tr, LBL_PR, f, &vcanon[i * n_per_row * L], n_per_row);
   }
-  absorb_poly(tr, LBL_PE, f, p_eval.data(), n_per_row);
+  tensors_ready.store(true, std::memory_order_release);
+  wait_canon(n_deg + 1);
+  absorb_canon(tr, LBL_PE, f, &vcanon[n_deg * n_per_row * L], n_per_row);
   uint8_t key[32];
   tr.challenge_bytes(LBL_CO, 6, key, 32);
   ChaCha20Rng rng(key);
+  for (auto& x : cols_to_open) x = rng.uniform(n_cols);
   tv[2] = now_ms();
   enc_thread.join();
+  side_thread.join();
   tv[3] = now_ms();
+  if (side_failed.load()) return LCPC_ERR_NOMEM;
+  if (cols_bad.load()) return LCPC_VERR_MALFORMED;
   if (enc_rc) return enc_rc == LCPC_ERR_ENCODE ? LCPC_VERR_ENCODE : enc_rc;
-  // step 3: per-column checks (lib.rs:923-944), in parallel over columns like the reference's par_iter;
-  // the error reported is that of the first failing column, with the reference's precedence degree > eval > path
-  for (auto& x : cols_to_open) x = rng.uniform(n_cols);
-  parallel_for(n_columns, 4, [&](uint64_t b, uint64_t e) {
-    for (uint64_t i = b; i < e; i++) {
-      const uint64_t cn = cols_to_open[i];
-      bool rnd = true, evl = true;
-      for (uint64_t d = 0; d <= n_deg; d++) {
-        const uint64_t* tensor = d < n_deg ? rand_tensors[d].data() : outer;
-        uint64_t acc[MAXL] = {0, 0, 0, 0}, t[MAXL];
-        for (uint64_t k = 0; k < n_rows; k++) { h_mul(f, t, tensor + k * L, cols[i].data() + k * L); h_add(f, acc, acc, t); }
-        const bool ok = h_eq(f, acc, &enc[(d * n_cols + cn) * L]);           // verify_column_value lib.rs:985-1000
-        if (d < n_deg) rnd = rnd && ok; else evl = ok;
-      }
-      uint8_t h[32], blk[64];                                                  // verify_column_path lib.rs:955-982
-      hash_column_host(f, cols[i].data(), n_rows, h);
-      uint64_t cc = cn;
-      for (uint64_t k = 0; k < paths[i].n; k++) {
-        const uint8_t* pk = paths[i].p + 40 * k + 8;
-        if (cc % 2 == 0) { memcpy(blk, h, 32); memcpy(blk + 32, pk, 32); } else { memcpy(blk, pk, 32); memcpy(blk + 32, h, 32); }
-        blake3_host(blk, 64, h);
-        cc >>= 1;
-      }
-      const bool pth = memcmp(h, root, 32) == 0;
-      status[i] = !rnd ? LCPC_VERR_COLUMN_DEGREE : (!evl ? LCPC_VERR_COLUMN_EVAL : (!pth ? LCPC_VERR_COLUMN_PATH : 0));
+  // step 3, the part that needs the drawn column numbers: compare with the encoded rows, fold the Merkle paths.  The error
+  // reported is that of the first failing column, with the reference's precedence degree > eval > path
+  int first_status = 0;
+  for (uint64_t i = 0; i < n_columns && !first_status; i++) {
+    const uint64_t cn = cols_to_open[i];
+    bool rnd = true, evl = true;
+    for (uint64_t d = 0; d <= n_deg; d++) {
+      const bool ok = h_eq(f, &dots[(d * n_columns + i) * MAXL], &enc[(d * n_cols + cn) * L]);   // verify_column_value lib.rs:985-1000
+      if (d < n_deg) rnd = rnd && ok; else evl = ok;
     }
-  }, n_columns * n_rows > ((uint64_t)1 << 19) ? 64u : 16u);       // Brakedown opens 6593 columns: ~0.1 s of work single-threaded
+    uint8_t h[32], blk[64];                                                    // verify_column_path lib.rs:955-982
+    memcpy(h, &leaf[i * 32], 32);
+    uint64_t cc = cn;
+    for (uint64_t k = 0; k < paths[i].n; k++) {
+      const uint8_t* pk = paths[i].p + 40 * k + 8;
+      if (cc % 2 == 0) { memcpy(blk, h, 32); memcpy(blk + 32, pk, 32); } else { memcpy(blk, pk, 32); memcpy(blk + 32, h, 32); }
+      blake3_host(blk, 64, h);
+      cc >>= 1;
+    }
+    const bool pth = memcmp(h, root, 32) == 0;
+    first_status = !rnd ? LCPC_VERR_COLUMN_DEGREE : (!evl ? LCPC_VERR_COLUMN_EVAL : (!pth ? LCPC_VERR_COLUMN_PATH : 0));
+  }
   tv[4] = now_ms();
-  for (uint64_t i = 0; i < n_columns; i++)
-    if (status[i]) return status[i];
+  if (first_status) return first_status;
   if (dbg)
-    fprintf(stderr, "[lcpc_verify] parse %.2f ms, transcript %.2f (row encodes on the GPU meanwhile: %.2f), wait for encodes %.2f, column checks %.2f\n",
-            tv[1] - tv[0], tv[2] - tv[1], t_enc, tv[3] - tv[2], tv[4] - tv[3]);
-  // <inner_tensor, p_eval> (lib.rs:947-951): partial sums over blocks of 4096 terms, added in block order
-  const uint64_t n_blk = (n_per_row + 4095) / 4096;
-  std::vector<uint64_t> part(n_blk * MAXL, 0);
-  parallel_for(n_blk, 2, [&](uint64_t b, uint64_t e) {
-    for (uint64_t blk = b; blk < e; blk++) {
-      uint64_t a[MAXL] = {0, 0, 0, 0}, t[MAXL];
-      const uint64_t k1 = std::min<uint64_t>(n_per_row, (blk + 1) * 4096);
-      for (uint64_t k = blk * 4096; k < k1; k++) { h_mul(f, t, inner + k * L, p_eval.data() + k * L); h_add(f, a, a, t); }
-      memcpy(&part[blk * MAXL], a, F);
-    }
-  });
-  uint64_t acc[MAXL] = {0, 0, 0, 0};
-  for (uint64_t blk = 0; blk < n_blk; blk++) h_add(f, acc, acc, &part[blk * MAXL]);
-  memcpy(eval_out, acc, F);
+    fprintf(stderr, "[lcpc_verify] parse + limb checks %.2f ms, transcript %.2f (beside it: row encodes on the GPU %.2f, side thread %.2f), wait for "
+                    "the helpers %.2f, column compares + paths %.2f\n",
+            tv[1] - tv[0], tv[2] - tv[1], t_enc, t_side, tv[3] - tv[2], tv[4] - tv[3]);
+  memcpy(eval_out, eval_acc, F);
   return 0;
   LCPC_CATCH(c)
 }
