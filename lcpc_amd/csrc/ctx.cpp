@@ -6,46 +6,13 @@
 // lcpc-2d/src/lib.rs:74-104); commitments made with it live in their own objects (commit.cpp).
 // There is no CPU fallback: without a usable HIP device lcpc_ctx_create fails with LCPC_ERR_NO_DEVICE.
 #include "internal.h"
+#include <chrono>
 
 using namespace lcpc;
 
 namespace lcpc {
 
 const uint8_t LBL_DT[7] = "$l//DT", LBL_PR[7] = "$l//PR", LBL_PE[7] = "$l//PE", LBL_CO[7] = "$l//CO";  // macros.rs:31-34
-
-void to_r29(const FieldDesc& f, const uint64_t* in4, uint32_t* out12) {
-  uint64_t t[4];
-  memcpy(t, in4, 32);
-  for (int d = 0; d < 5; d++) h_add(f, t, t, t);
-  for (int k = 0; k < 9; k++) {
-    const int b = 29 * k, w = b / 64, sh = b % 64;
-    uint64_t x = t[w] >> sh;
-    if (sh > 35 && w + 1 < 4) x |= t[w + 1] << (64 - sh);
-    out12[k] = (uint32_t)(x & ((1u << 29) - 1));
-  }
-  out12[9] = out12[10] = out12[11] = 0;
-}
-
-// a container can show 256 hardware threads and be granted 16 CPUs of time; more threads than that only get throttled
-unsigned usable_cores() {
-  static const unsigned cached = [] {
-    unsigned n = std::thread::hardware_concurrency();
-    if (n == 0) n = 1;
-    long long q = -1, per = 100000;
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                         // cgroup v2: "<quota|max> <period>"
-      char qs[32] = {0};
-      if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0) q = atoll(qs);
-      fclose(f);
-    } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {      // cgroup v1
-      if (fscanf(f1, "%lld", &q) != 1) q = -1;
-      fclose(f1);
-      if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 100000; fclose(f2); }
-    }
-    if (q > 0 && per > 0) { const unsigned lim = (unsigned)std::max<long long>(1, q / per); if (lim < n) n = lim; }
-    return n;
-  }();
-  return cached;
-}
 
 void ctx_ref(lcpc_ctx* c) { c->refs.fetch_add(1); }
 
@@ -404,7 +371,11 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
     if (!sdig_n_per_row(*f, p->n_coeffs, (int)c->prm.sdig_code, &npr)) return LCPC_ERR_ARG;
   }
   std::vector<CsrMatrix> pre, post;
+  const bool dbg = getenv("LCPC_DEBUG_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_gen0 = now();
   if (!sdig_generate(*f, c->spec, npr, p->seed, pre, post, c->pre_dims, c->post_dims)) return LCPC_ERR_DIMS;
+  const double t_gen1 = now();
   c->n_per_row = npr;
   c->n_cols = sdig_codeword_length(c->pre_dims, c->post_dims);
   if (p->n_per_row && p->n_cols && p->n_cols != c->n_cols) return LCPC_ERR_DIMS;   // new_from_dims assert
@@ -417,12 +388,11 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
     HIPCHK(c, hipMemcpy(d.rowptr, m.rowptr.data(), m.rowptr.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(d.colidx, m.colidx.data(), m.colidx.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(d.vals, m.vals.data(), m.vals.size() * 8, hipMemcpyHostToDevice));
-    if (f->L == 4) {
+    if (f->L == 4) {      // the 29-bit-limb / 2^261 form of the values (lazy29_mac) is derived on the device from the uploaded copy
       const size_t nnz = m.colidx.size();
-      std::vector<uint32_t> v29(nnz * 12 + 12);
-      parallel_for(nnz, 16384, [&](uint64_t b, uint64_t e) { for (uint64_t k = b; k < e; k++) to_r29(*f, &m.vals[k * 4], &v29[k * 12]); });
-      if ((r = dev_alloc(err, &d.vals29, v29.size() * 4))) return r;
-      HIPCHK(c, hipMemcpy(d.vals29, v29.data(), v29.size() * 4, hipMemcpyHostToDevice));
+      if ((r = dev_alloc(err, &d.vals29, (nnz + 1) * 48))) return r;
+      HIPCHK(c, launch_to_r29(d.vals, nnz, d.vals29, nullptr));
+      HIPCHK(c, hipMemsetAsync(d.vals29 + nnz * 12, 0, 48, nullptr));      // one entry of slack for the one-ahead prefetch
     }
     return 0;
   };
@@ -432,6 +402,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
   if (!rc) rc = dev_alloc(err, &c->d_r2, 8 * f->L);
   if (rc) return rc;
   HIPCHK(c, hipMemcpy(c->d_r2, f->r2, 8 * f->L, hipMemcpyHostToDevice));
+  if (dbg) fprintf(stderr, "[SdigEncoding::new] matgen %.1f ms, convert + upload %.1f ms\n", t_gen1 - t_gen0, now() - t_gen1);
   return 0;
 }
 

@@ -1,12 +1,39 @@
 // lcpc_amd/csrc/encoding.cpp -- see encoding.h
 #include "encoding.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <mutex>
 #include <thread>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include "host_crypto.h"
+#include "host_par.h"
 
 namespace lcpc {
+
+// a container can show 256 hardware threads and be granted 16 CPUs of time; more threads than that only get throttled
+unsigned usable_cores() {
+  static const unsigned cached = [] {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    long long q = -1, per = 100000;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                         // cgroup v2: "<quota|max> <period>"
+      char qs[32] = {0};
+      if (fscanf(f, "%31s %lld", qs, &per) == 2 && strcmp(qs, "max") != 0) q = atoll(qs);
+      fclose(f);
+    } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {      // cgroup v1
+      if (fscanf(f1, "%lld", &q) != 1) q = -1;
+      fclose(f1);
+      if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &per) != 1) per = 100000; fclose(f2); }
+    }
+    if (q > 0 && per > 0) { const unsigned lim = (unsigned)std::max<long long>(1, q / per); if (lim < n) n = lim; }
+    return n;
+  }();
+  return cached;
+}
+
 
 // ---- field descriptors (lcpc-test-fields/src/lib.rs:13-59) -----------------------------------------
 static FieldDesc g_fields[4];
@@ -166,59 +193,221 @@ bool sdig_n_per_row(const FieldDesc& f, uint64_t len, int code, uint64_t* out, b
   return true;
 }
 
-// gen_code (matgen.rs:114-188) emits the matrix column by column (= per input); we scatter each
-// column's (sorted) entries into per-output buckets afterwards to get CSR-by-output.
-static void gen_code_csr(const FieldDesc& f, uint64_t n, uint64_t m, uint64_t d, ChaCha20Rng& rng, CsrMatrix& out) {
+// ---- matgen (matgen.rs:28-52, 114-188) ---------------------------------------------------------------------------------
+// gen_code draws, per input column, d distinct output indices (Uniform, re-drawn on collision), sorts them, then one
+// non-zero field element per entry (Field::random: masked 64 L-bit candidates, rejected while >= p -- 60 % of the
+// candidates of Ft255).  One ChaCha20 stream per level feeds precode then postcode, so WHERE a column's draws start
+// depends on every rejection before it.  The reference walks that chain serially; level 0 holds 82 % of the entries at
+// C3, so a thread per level (matgen.rs:38-49) hardly helps.  Here:
+//   1. the keystream of a level is materialised in bulk (seekable cipher: 16 blocks per vector pass, all cores);
+//   2. ONE cheap serial pass replays only the accept / reject decisions (one or two compares per candidate) and
+//      records the stream position at every chunk of columns;
+//   3. the chunks are then generated in parallel from their recorded positions (sort, copy the accepted values), and
+//   4. the CSC-by-input entries are transposed to CSR-by-output with a parallel stable counting sort.
+// Steps 2 and 3 are the same template (WRITE = false / true), so they cannot disagree about the stream.
+namespace {
+
+struct LevelStream {
+  uint32_t key[8];
+  uint64_t stream = 0;
+  uint64_t* w = nullptr;            // w[i] = the i-th next_u64() of the level's RNG
+  uint64_t n_valid = 0;
+  ~LevelStream() { free(w); }
+  void ensure(uint64_t n) {         // at least n values available
+    if (n <= n_valid) return;
+    uint64_t target = std::max<uint64_t>(n + (n >> 6) + 4096, n_valid);
+    target = (target + 127) & ~(uint64_t)127;                               // whole groups of 16 blocks (8 values per block)
+    uint64_t* nw = static_cast<uint64_t*>(realloc(w, target * 8));          // (not value-initialised: filled right below)
+    if (!nw) throw std::bad_alloc();
+    w = nw;
+    const uint64_t b0 = n_valid / 8, b1 = target / 8;
+    uint32_t* out = reinterpret_cast<uint32_t*>(w);                         // little-endian: value = word 2i | word 2i+1 << 32
+    parallel_for(b1 - b0, 4096, [&](uint64_t x, uint64_t y) { chacha20_keystream(key, stream, b0 + x, y - x, out + 16 * (b0 + x)); });
+    n_valid = target;
+  }
+};
+
+// rand 0.8 Uniform::<usize>::new(0, m).sample [3P] on the materialised stream
+struct UniformM {
+  uint64_t range, zone;
+  explicit UniformM(uint64_t m) : range(m) { zone = UINT64_MAX - (UINT64_MAX - m + 1) % m; }
+};
+
+// columns [c0, c1) of one matrix from stream position `pos`; returns the position after them.  WRITE = false: decisions
+// only.  `need`: called with the index bound before every read burst (extends the stream in the serial pass).
+template <bool WRITE, typename Need>
+uint64_t gen_columns(const FieldDesc& f, const uint64_t* const& ks, uint64_t pos, uint64_t c0, uint64_t c1, const UniformM& um, uint64_t d,
+                     uint32_t* ridx, uint64_t* vals, Need need) {
   const int L = f.L;
-  std::vector<uint32_t> ridx(n * d);
-  std::vector<uint64_t> vals(n * d * L);
-  std::vector<uint64_t> tmp(d);
-  for (uint64_t c = 0; c < n; c++) {
+  const uint64_t ptop = f.p[L - 1], mask = f.top_mask;
+  uint64_t tmp[64];
+  for (uint64_t c = c0; c < c1; c++) {
     uint64_t got = 0;
-    while (got < d) {
-      const uint64_t x = rng.uniform(m);
+    while (got < d) {                                          // d distinct indices (matgen.rs:119-131)
+      need(pos + 1);
+      const uint64_t v = ks[pos++];
+      const u128 mm = (u128)v * um.range;
+      if ((uint64_t)mm > um.zone) continue;
+      const uint64_t x = (uint64_t)(mm >> 64);
       bool dup = false;
       for (uint64_t i = 0; i < got; i++) dup |= tmp[i] == x;
       if (!dup) tmp[got++] = x;
     }
-    std::sort(tmp.begin(), tmp.end());
-    for (uint64_t i = 0; i < d; i++) {
-      uint64_t* v = &vals[(c * d + i) * L];
-      do rng.field_random(f, v); while (h_is_zero(f, v));
-      ridx[c * d + i] = (uint32_t)tmp[i];
+    if (WRITE) {
+      std::sort(tmp, tmp + d);
+      for (uint64_t i = 0; i < d; i++) ridx[c * d + i] = (uint32_t)tmp[i];
+    }
+    for (uint64_t i = 0; i < d; i++) {                         // one non-zero element per entry (matgen.rs:148-180)
+      for (;;) {
+        need(pos + L);
+        const uint64_t top = ks[pos + L - 1] & mask;
+        bool ok = top < ptop;
+        if (!ok && top == ptop) {                              // compare the lower limbs (rare)
+          uint64_t t[MAXL];
+          for (int j = 0; j < L; j++) t[j] = ks[pos + j];
+          t[L - 1] = top;
+          ok = !h_ge_p(f, t);
+        }
+        if (ok) {                                              // zero is re-drawn
+          bool nz = top != 0;
+          for (int j = 0; j + 1 < L && !nz; j++) nz = ks[pos + j] != 0;
+          ok = nz;
+        }
+        if (ok) {
+          if (WRITE) {
+            uint64_t* v = vals + (c * d + i) * L;
+            for (int j = 0; j + 1 < L; j++) v[j] = ks[pos + j];
+            v[L - 1] = top;
+          }
+          pos += L;
+          break;
+        }
+        pos += L;
+      }
     }
   }
+  return pos;
+}
+
+struct MatJob {
+  uint64_t n, m, d;
+  uint64_t chunk;                     // columns per chunk
+  std::vector<uint64_t> start;        // stream position of every chunk
+  CsrMatrix* out;
+};
+
+// entries (column-major, sorted inside a column) -> CSR by output, columns ascending inside a row: stable counting sort
+void transpose_to_csr(const FieldDesc& f, const MatJob& j, const RawBuf<uint32_t>& ridx, const RawBuf<uint64_t>& vals) {
+  const int L = f.L;
+  const uint64_t n = j.n, m = j.m, d = j.d, nchunks = j.start.size();
+  CsrMatrix& out = *j.out;
   out.n_in = n;
   out.n_out = m;
-  out.rowptr.assign(m + 1, 0);
-  for (uint64_t k = 0; k < n * d; k++) out.rowptr[ridx[k] + 1]++;
-  for (uint64_t o = 0; o < m; o++) out.rowptr[o + 1] += out.rowptr[o];
-  out.colidx.resize(n * d);
-  out.vals.resize(n * d * L);
-  std::vector<uint32_t> fill(out.rowptr.begin(), out.rowptr.end() - 1);
-  for (uint64_t c = 0; c < n; c++)
-    for (uint64_t i = 0; i < d; i++) {
-      const uint64_t k = c * d + i;
-      const uint32_t slot = fill[ridx[k]]++;
-      out.colidx[slot] = (uint32_t)c;
-      memcpy(&out.vals[(uint64_t)slot * L], &vals[k * L], 8 * L);
+  out.rowptr.alloc(m + 1);
+  out.rowptr[0] = 0;
+  out.colidx.alloc(n * d);
+  out.vals.alloc(n * d * L);
+  RawBuf<uint32_t> hist;                                       // hist[chunk][o] -> later: first slot of (chunk, o)
+  hist.alloc(nchunks * m);
+  parallel_for(nchunks, 1, [&](uint64_t a, uint64_t b) {
+    for (uint64_t ch = a; ch < b; ch++) {
+      uint32_t* h = &hist[ch * m];
+      memset(h, 0, m * 4);
+      const uint64_t k1 = std::min(n, (ch + 1) * j.chunk) * d;
+      for (uint64_t k = ch * j.chunk * d; k < k1; k++) h[ridx[k]]++;
     }
+  });
+  parallel_for(m, 2048, [&](uint64_t a, uint64_t b) {          // per output: its total, and each chunk's offset inside the row
+    for (uint64_t o = a; o < b; o++) {
+      uint32_t run = 0;
+      for (uint64_t ch = 0; ch < nchunks; ch++) { const uint32_t t = hist[ch * m + o]; hist[ch * m + o] = run; run += t; }
+      out.rowptr[o + 1] = run;
+    }
+  });
+  for (uint64_t o = 0; o < m; o++) out.rowptr[o + 1] += out.rowptr[o];
+  parallel_for(nchunks, 1, [&](uint64_t a, uint64_t b) {
+    for (uint64_t ch = a; ch < b; ch++) {
+      uint32_t* h = &hist[ch * m];
+      const uint64_t c1 = std::min(n, (ch + 1) * j.chunk);
+      for (uint64_t c = ch * j.chunk; c < c1; c++)
+        for (uint64_t i = 0; i < d; i++) {
+          const uint64_t k = c * d + i;
+          const uint32_t o = ridx[k];
+          const uint32_t slot = out.rowptr[o] + h[o]++;
+          out.colidx[slot] = (uint32_t)c;
+          memcpy(&out.vals[(uint64_t)slot * L], &vals[k * L], 8 * L);
+        }
+    }
+  });
 }
+
+// one level: precode then postcode from ONE stream (matgen.rs:43-48)
+void gen_level(const FieldDesc& f, uint64_t seed, uint64_t level, const LevelDims& pd, const LevelDims& qd, CsrMatrix& pre, CsrMatrix& post) {
+  LevelStream ks;
+  {
+    ChaCha20Rng rng = ChaCha20Rng::seed_from_u64(seed);
+    memcpy(ks.key, rng.key(), 32);
+    ks.stream = level;
+  }
+  MatJob jobs[2] = {{pd.n, pd.m, pd.d, 0, {}, &pre}, {qd.n, qd.m, qd.d, 0, {}, &post}};
+  // expected consumption: 1 value per index, L / P(accept) per element; the serial pass extends the stream if it runs short
+  double p_acc = 1.0;
+  {
+    const double ptop = (double)f.p[f.L - 1], range = (double)f.top_mask + 1.0;
+    p_acc = ptop / range;
+  }
+  const double per_entry = 1.02 + (double)f.L / p_acc;
+  const bool dbg = getenv("LCPC_DEBUG_TIMING") != nullptr && level == 0;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tt[5] = {now(), 0, 0, 0, 0};
+  ks.ensure((uint64_t)((double)(pd.n * pd.d + qd.n * qd.d) * per_entry * 1.01) + 65536);
+  auto need = [&](uint64_t bound) { if (bound > ks.n_valid) ks.ensure(bound + 65536); };
+  uint64_t pos = 0;
+  tt[1] = now();
+  for (MatJob& j : jobs) {                                     // step 2: positions of the chunks
+    const uint64_t target_chunks = 64;
+    j.chunk = std::max<uint64_t>(64, (j.n + target_chunks - 1) / target_chunks);
+    const UniformM um(j.m);
+    for (uint64_t c0 = 0; c0 < j.n; c0 += j.chunk) {
+      j.start.push_back(pos);
+      pos = gen_columns<false>(f, const_cast<const uint64_t* const&>(ks.w), pos, c0, std::min(j.n, c0 + j.chunk), um, j.d, nullptr, nullptr, need);
+    }
+  }
+  tt[2] = now();
+  RawBuf<uint32_t> ridx;                                       // one pair of entry buffers serves both matrices (no fresh pages)
+  RawBuf<uint64_t> vals;
+  ridx.alloc(std::max(jobs[0].n * jobs[0].d, jobs[1].n * jobs[1].d));
+  vals.alloc(std::max(jobs[0].n * jobs[0].d, jobs[1].n * jobs[1].d) * f.L);
+  for (MatJob& j : jobs) {                                     // steps 3 and 4
+    const UniformM um(j.m);
+    parallel_for(j.start.size(), 1, [&](uint64_t a, uint64_t b) {
+      for (uint64_t ch = a; ch < b; ch++)
+        gen_columns<true>(f, const_cast<const uint64_t* const&>(ks.w), j.start[ch], ch * j.chunk, std::min(j.n, (ch + 1) * j.chunk), um, j.d, ridx.data(), vals.data(), [](uint64_t) {});
+    });
+    const double t0 = now();
+    transpose_to_csr(f, j, ridx, vals);
+    tt[3] += now() - t0;
+  }
+  if (dbg)
+    fprintf(stderr, "[matgen level 0] keystream %.1f ms (%.0f M values), position pass %.1f, generate %.1f, transpose %.1f\n", tt[1] - tt[0],
+            (double)ks.n_valid / 1e6, tt[2] - tt[1], now() - tt[2] - tt[3], tt[3]);
+}
+
+}  // namespace
+
 bool sdig_generate(const FieldDesc& f, const SdigSpec& s, uint64_t n_per_row, uint64_t seed, std::vector<CsrMatrix>& pre,
                    std::vector<CsrMatrix>& post, std::vector<LevelDims>& pre_dims, std::vector<LevelDims>& post_dims) {
   if (!sdig_level_dims(s, n_per_row, (double)f.flog2(), pre_dims, post_dims)) return false;
   const size_t t = pre_dims.size();
-  pre.assign(t, CsrMatrix());
-  post.assign(t, CsrMatrix());
-  std::vector<std::thread> th;                         // levels are independent streams (matgen.rs:38-49)
   for (size_t i = 0; i < t; i++)
-    th.emplace_back([&, i] {
-      ChaCha20Rng rng = ChaCha20Rng::seed_from_u64(seed);
-      rng.set_stream((uint64_t)i);
-      gen_code_csr(f, pre_dims[i].n, pre_dims[i].m, pre_dims[i].d, rng, pre[i]);
-      gen_code_csr(f, post_dims[i].n, post_dims[i].m, post_dims[i].d, rng, post[i]);
-    });
-  for (auto& x : th) x.join();
+    if (pre_dims[i].d > 64 || post_dims[i].d > 64) return false;           // (the specs keep d <= 31)
+  pre.clear(); post.clear();
+  pre.resize(t); post.resize(t);
+  // level 0 carries most of the entries: it gets this thread (and, inside its parallel steps, all cores); the remaining
+  // levels run beside its serial pass on a second thread (levels are independent streams, matgen.rs:38-49)
+  std::thread rest([&] { for (size_t i = 1; i < t; i++) gen_level(f, seed, i, pre_dims[i], post_dims[i], pre[i], post[i]); });
+  gen_level(f, seed, 0, pre_dims[0], post_dims[0], pre[0], post[0]);
+  rest.join();
   return true;
 }
 

@@ -4,6 +4,9 @@
 // lcpc-brakedown-pc/src/{lib.rs:54-137, matgen.rs, codespec.rs}.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
 #include <vector>
 #include "host_field.h"
 
@@ -33,12 +36,36 @@ uint64_t sdig_codeword_length(const std::vector<LevelDims>& pre, const std::vect
 // SdigEncoding::new's choice of n_per_row (brakedown lib.rs:103-110 -> 69-87)
 bool sdig_n_per_row(const FieldDesc& f, uint64_t len, int code, uint64_t* n_per_row, bool ml = false);
 
+// plain array without value-initialisation: the matrices are tens of megabytes that are overwritten anyway, and a
+// std::vector would first zero them on ONE thread (page faults included) before the parallel fill starts
+template <typename T> struct RawBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  RawBuf() = default;
+  RawBuf(const RawBuf&) = delete;
+  RawBuf& operator=(const RawBuf&) = delete;
+  RawBuf(RawBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  RawBuf& operator=(RawBuf&& o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+  ~RawBuf() { free(p); }
+  void alloc(size_t count) {
+    free(p);
+    p = static_cast<T*>(malloc((count ? count : 1) * sizeof(T)));
+    if (!p) throw std::bad_alloc();
+    n = count;
+  }
+  void zero() { memset(p, 0, n * sizeof(T)); }
+  size_t size() const { return n; }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
 // one expander matrix, CSR by *output* (the transpose view of the reference's CSC-by-input)
 struct CsrMatrix {
   uint64_t n_in = 0, n_out = 0;
-  std::vector<uint32_t> rowptr;    // n_out + 1
-  std::vector<uint32_t> colidx;    // nnz, input index
-  std::vector<uint64_t> vals;      // nnz * L, Montgomery limbs
+  RawBuf<uint32_t> rowptr;    // n_out + 1
+  RawBuf<uint32_t> colidx;    // nnz, input index
+  RawBuf<uint64_t> vals;      // nnz * L, Montgomery limbs
 };
 // matgen.rs:28-52 + 114-188: precode[i], postcode[i] from (n_per_row, seed); RNG-order identical to the
 // reference (per level: ChaCha20Rng::seed_from_u64(seed), set_stream(i); precode then postcode).

@@ -266,27 +266,63 @@ ChaCha20Rng ChaCha20Rng::seed_from_u64(uint64_t state) {
   }
   return ChaCha20Rng(seed);
 }
-void ChaCha20Rng::refill() {
-  for (int blk = 0; blk < 4; blk++) {
-    uint32_t s[16] = {0x61707865u, 0x3320646Eu, 0x79622D32u, 0x6B206574u};
-    for (int i = 0; i < 8; i++) s[4 + i] = key_[i];
-    s[12] = (uint32_t)counter_; s[13] = (uint32_t)(counter_ >> 32);
-    s[14] = (uint32_t)stream_;  s[15] = (uint32_t)(stream_ >> 32);
-    uint32_t x[16];
-    memcpy(x, s, 64);
-    auto qr = [&](int a, int b, int c, int d) {
-      x[a] += x[b]; x[d] = ror32(x[d] ^ x[a], 16);
-      x[c] += x[d]; x[b] = ror32(x[b] ^ x[c], 20);
-      x[a] += x[b]; x[d] = ror32(x[d] ^ x[a], 24);
-      x[c] += x[d]; x[b] = ror32(x[b] ^ x[c], 25);
-    };
-    for (int r = 0; r < 10; r++) {
-      qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
-      qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
-    }
-    for (int i = 0; i < 16; i++) buf_[16 * blk + i] = x[i] + s[i];
-    counter_++;
+// W blocks side by side (structure of arrays): the quarter-round loops run over the lane index, which the compiler turns
+// into vector instructions (AVX-512 / AVX2 / SSE2 clones picked at load time)
+#if defined(__x86_64__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+static void chacha20_blocks16(const uint32_t key[8], uint64_t stream, uint64_t block0, uint32_t* out) {
+  constexpr int W = 16;
+  uint32_t x[16][W], s[16][W];
+  for (int l = 0; l < W; l++) {
+    const uint64_t ctr = block0 + (uint64_t)l;
+    s[0][l] = 0x61707865u; s[1][l] = 0x3320646Eu; s[2][l] = 0x79622D32u; s[3][l] = 0x6B206574u;
+    for (int i = 0; i < 8; i++) s[4 + i][l] = key[i];
+    s[12][l] = (uint32_t)ctr; s[13][l] = (uint32_t)(ctr >> 32);
+    s[14][l] = (uint32_t)stream; s[15][l] = (uint32_t)(stream >> 32);
   }
+  for (int i = 0; i < 16; i++)
+    for (int l = 0; l < W; l++) x[i][l] = s[i][l];
+#define LCPC_QR(a, b, c, d)                                                                     \
+  for (int l = 0; l < W; l++) { x[a][l] += x[b][l]; uint32_t t = x[d][l] ^ x[a][l]; x[d][l] = (t << 16) | (t >> 16); } \
+  for (int l = 0; l < W; l++) { x[c][l] += x[d][l]; uint32_t t = x[b][l] ^ x[c][l]; x[b][l] = (t << 12) | (t >> 20); } \
+  for (int l = 0; l < W; l++) { x[a][l] += x[b][l]; uint32_t t = x[d][l] ^ x[a][l]; x[d][l] = (t << 8) | (t >> 24); }  \
+  for (int l = 0; l < W; l++) { x[c][l] += x[d][l]; uint32_t t = x[b][l] ^ x[c][l]; x[b][l] = (t << 7) | (t >> 25); }
+  for (int r = 0; r < 10; r++) {
+    LCPC_QR(0, 4, 8, 12) LCPC_QR(1, 5, 9, 13) LCPC_QR(2, 6, 10, 14) LCPC_QR(3, 7, 11, 15)
+    LCPC_QR(0, 5, 10, 15) LCPC_QR(1, 6, 11, 12) LCPC_QR(2, 7, 8, 13) LCPC_QR(3, 4, 9, 14)
+  }
+#undef LCPC_QR
+  for (int l = 0; l < W; l++)
+    for (int i = 0; i < 16; i++) out[16 * l + i] = x[i][l] + s[i][l];
+}
+static void chacha20_block1(const uint32_t key[8], uint64_t stream, uint64_t ctr, uint32_t* out) {
+  uint32_t s[16] = {0x61707865u, 0x3320646Eu, 0x79622D32u, 0x6B206574u};
+  for (int i = 0; i < 8; i++) s[4 + i] = key[i];
+  s[12] = (uint32_t)ctr; s[13] = (uint32_t)(ctr >> 32);
+  s[14] = (uint32_t)stream; s[15] = (uint32_t)(stream >> 32);
+  uint32_t x[16];
+  memcpy(x, s, 64);
+  auto qr = [&](int a, int b, int c, int d) {
+    x[a] += x[b]; x[d] = ror32(x[d] ^ x[a], 16);
+    x[c] += x[d]; x[b] = ror32(x[b] ^ x[c], 20);
+    x[a] += x[b]; x[d] = ror32(x[d] ^ x[a], 24);
+    x[c] += x[d]; x[b] = ror32(x[b] ^ x[c], 25);
+  };
+  for (int r = 0; r < 10; r++) {
+    qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+    qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+  }
+  for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+void chacha20_keystream(const uint32_t key[8], uint64_t stream, uint64_t block0, uint64_t nblocks, uint32_t* out) {
+  uint64_t b = 0;
+  for (; b + 16 <= nblocks; b += 16) chacha20_blocks16(key, stream, block0 + b, out + 16 * b);
+  for (; b < nblocks; b++) chacha20_block1(key, stream, block0 + b, out + 16 * b);
+}
+void ChaCha20Rng::refill() {
+  chacha20_keystream(key_, stream_, counter_, 4, buf_);
+  counter_ += 4;
   idx_ = 0;
 }
 uint32_t ChaCha20Rng::next_u32() {

@@ -36,12 +36,19 @@ class Transcript {
   void prf(uint8_t* d, size_t n, bool more);
 };
 
+// ChaCha20 keystream (the rand_chacha layout: 64-bit block counter in words 12-13, 64-bit stream id in words 14-15):
+// the 16 * nblocks words of blocks [block0, block0 + nblocks).  The stream is seekable, so long runs are generated in
+// bulk, 16 blocks per vector pass and on as many threads as the caller likes (matgen).
+void chacha20_keystream(const uint32_t key[8], uint64_t stream, uint64_t block0, uint64_t nblocks, uint32_t* out);
+
 // rand_chacha 0.3 ChaCha20Rng [3P]: 64-bit block counter, 64-bit stream id, 4-block buffer
 class ChaCha20Rng {
  public:
   explicit ChaCha20Rng(const uint8_t seed[32]);
   static ChaCha20Rng seed_from_u64(uint64_t state);     // rand_core 0.6 PCG32 expansion [3P]
   void set_stream(uint64_t s) { stream_ = s; }
+  const uint32_t* key() const { return key_; }
+  uint64_t stream() const { return stream_; }
   uint32_t next_u32();
   uint64_t next_u64();
   uint64_t uniform(uint64_t high);                      // rand 0.8 Uniform::<usize>::new(0, high).sample [3P]

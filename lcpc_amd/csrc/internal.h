@@ -23,6 +23,7 @@
 #include "encoding.h"
 #include "host_crypto.h"
 #include "host_field.h"
+#include "host_par.h"
 #include "kernels.h"
 
 namespace lcpc {
@@ -177,40 +178,9 @@ inline size_t elem_bytes(const lcpc_ctx* c) { return (size_t)8 * c->L; }
 // leaf message = 32 + F * n_rows bytes -> BLAKE3 chunks of 1 KiB
 inline uint64_t leaf_chunks(const lcpc_ctx* c, uint64_t n_rows) { return (32 + elem_bytes(c) * n_rows + 1023) / 1024; }
 
-// host cores this process may really use (hardware threads capped by the cgroup CPU quota)
-unsigned usable_cores();
-
-// small fork-join helper for the host-side glue (the reference uses rayon at the same places: lib.rs:923-944)
-template <typename Fn> void parallel_for(uint64_t n, uint64_t grain, Fn fn, unsigned max_threads = 16) {
-  unsigned nt = usable_cores();
-  if (nt > max_threads) nt = max_threads;
-  if (nt <= 1 || n < 2 * grain) { fn((uint64_t)0, n); return; }
-  const uint64_t nchunks = (n + grain - 1) / grain;
-  if (nt > nchunks) nt = (unsigned)nchunks;
-  std::atomic<uint64_t> next{0};
-  auto body = [&] {
-    for (;;) {
-      const uint64_t c = next.fetch_add(1);
-      if (c >= nchunks) return;
-      const uint64_t b = c * grain, e = b + grain < n ? b + grain : n;
-      fn(b, e);
-    }
-  };
-  std::vector<std::thread> th;
-  th.reserve(nt);
-  try {
-    for (unsigned t = 0; t + 1 < nt; t++) th.emplace_back(body);
-  } catch (...) {       // thread creation failed: the calling thread (and whatever started) finishes the work
-  }
-  body();
-  for (auto& x : th) x.join();
-}
-
 // labels of the transcript (macros.rs:31-34)
 extern const uint8_t LBL_DT[7], LBL_PR[7], LBL_PE[7], LBL_CO[7];
 
-// Ft255 element in ff_derive's Montgomery form (a * 2^256) -> a * 2^261 mod p as 9 limbs of 29 bits, 12-word stride
-void to_r29(const FieldDesc& f, const uint64_t* in4, uint32_t* out12);
 
 // ---- ctx.cpp ----------------------------------------------------------------------------------------
 void ctx_ref(lcpc_ctx* c);
