@@ -555,8 +555,9 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
   *reinterpret_cast<uint4*>(o) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
   *reinterpret_cast<uint4*>(o + 4) = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
-hipError_t launch_leaf_chunks(int nl, const LeafArgs& a, hipStream_t st) {
-  if (a.n_chunks_local == 0 || a.n_cols == 0) return hipSuccess;
+// grid.y is limited to 65535: a commitment with millions of short rows (new_from_dims with a small n_per_row) has more
+// leaf-message chunks than that, so the chunk range is launched in slices
+static hipError_t launch_leaf_chunks_slice(int nl, const LeafArgs& a, hipStream_t st) {
   dim3 grid((unsigned)((a.n_cols + 255) / 256), a.n_chunks_local);
   if (a.canon_in) {
     if (nl != 8) return hipErrorInvalidValue;
@@ -571,6 +572,19 @@ hipError_t launch_leaf_chunks(int nl, const LeafArgs& a, hipStream_t st) {
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+hipError_t launch_leaf_chunks(int nl, const LeafArgs& a, hipStream_t st) {
+  if (a.n_chunks_local == 0 || a.n_cols == 0) return hipSuccess;
+  constexpr u32 SLICE = 32768;
+  for (u32 s0 = 0; s0 < a.n_chunks_local; s0 += SLICE) {
+    LeafArgs b = a;
+    b.chunk_begin = a.chunk_begin + s0;
+    b.n_chunks_local = a.n_chunks_local - s0 < SLICE ? a.n_chunks_local - s0 : SLICE;
+    b.out = a.out + (u64)s0 * a.n_cols * 8;
+    hipError_t e = launch_leaf_chunks_slice(nl, b, st);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 __device__ __forceinline__ void ld8(u32 d[8], const u32* p) {
@@ -884,15 +898,23 @@ hipError_t launch_gather_columns(int nl, const u32* comm, u64 n_rows, u64 row_st
   if (n == 0) return hipSuccess;
   unsigned gx = (unsigned)((n_rows + 255) / 256);
   if (gx > 64) gx = 64;
-  dim3 grid(gx, n);
-  switch (nl) {
-    case 2: hipLaunchKernelGGL(gather_columns_kernel<2>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, cols, vals, r2); break;
-    case 4: hipLaunchKernelGGL(gather_columns_kernel<4>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, cols, vals, r2); break;
-    case 6: hipLaunchKernelGGL(gather_columns_kernel<6>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, cols, vals, r2); break;
-    case 8: hipLaunchKernelGGL(gather_columns_kernel<8>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, cols, vals, r2); break;
-    default: return hipErrorInvalidValue;
+  constexpr u32 SLICE = 32768;                 // grid.y limit: columns in slices
+  for (u32 s0 = 0; s0 < n; s0 += SLICE) {
+    const u32 cnt = n - s0 < SLICE ? n - s0 : SLICE;
+    dim3 grid(gx, cnt);
+    const u64* c = cols + s0;
+    u32* v = vals + (u64)s0 * n_rows * nl;
+    switch (nl) {
+      case 2: hipLaunchKernelGGL(gather_columns_kernel<2>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, c, v, r2); break;
+      case 4: hipLaunchKernelGGL(gather_columns_kernel<4>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, c, v, r2); break;
+      case 6: hipLaunchKernelGGL(gather_columns_kernel<6>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, c, v, r2); break;
+      case 8: hipLaunchKernelGGL(gather_columns_kernel<8>, grid, dim3(256), 0, st, comm, n_rows, row_stride, col_stride, c, v, r2); break;
+      default: return hipErrorInvalidValue;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
   }
-  return hipGetLastError();
+  return hipSuccess;
 }
 __global__ void __launch_bounds__(256) gather_paths_kernel(const u32* hashes, u64 np2, u32 path_len, const u64* cols, u32 n,
                                                           u32* paths) {
@@ -944,6 +966,7 @@ __global__ void __launch_bounds__(256) spmv_kernel(SpmvArgs a) {
 }
 hipError_t launch_spmv(int nl, const SpmvArgs& a, hipStream_t st) {
   if (a.m == 0 || a.n_rows == 0) return hipSuccess;
+  if (a.n_rows > 65535) return hipErrorInvalidValue;        // (the host takes the position-major path from 16 rows on)
   dim3 grid((unsigned)((a.m + 255) / 256), (unsigned)a.n_rows);
   switch (nl) {
     case 2: hipLaunchKernelGGL(spmv_kernel<2>, grid, dim3(256), 0, st, a); break;
@@ -972,6 +995,7 @@ __global__ void __launch_bounds__(64) sdig_rs_kernel(const u32* in, u64 in_strid
 hipError_t launch_sdig_rs(int nl, const u32* in, u64 in_stride, u32 n_in, u32* mat, u64 stride, u64 out_off, u32 n_out,
                           u64 n_rows, const u32* r2, hipStream_t st) {
   if (n_out == 0 || n_rows == 0) return hipSuccess;
+  if (n_rows > 65535) return hipErrorInvalidValue;
   dim3 grid((n_out + 63) / 64, (unsigned)n_rows);
   switch (nl) {
     case 2: hipLaunchKernelGGL(sdig_rs_kernel<2>, grid, dim3(64), 0, st, in, in_stride, n_in, mat, stride, out_off, n_out, r2); break;
@@ -1201,6 +1225,7 @@ __global__ void __launch_bounds__(256) pad_rows_kernel(const u32* src, u64 src_s
 hipError_t launch_pad_rows(int nl, const u32* src, u64 src_stride, u32* dst, u64 dst_stride, u64 n_valid, u64 n_rows,
                            hipStream_t st) {
   if (n_rows == 0 || n_valid == 0) return hipSuccess;
+  if (n_rows > 65535) return hipErrorInvalidValue;
   unsigned gx = (unsigned)((n_valid + 255) / 256);
   if (gx > 1024) gx = 1024;
   dim3 grid(gx, (unsigned)n_rows);

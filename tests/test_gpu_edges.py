@@ -303,3 +303,22 @@ def test_ab_switch_paths_stay_correct(oracle, switch):
     pf = c.prove(t, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
     opf, _ = oc.prove(t, oenc, mk_transcript(O.Transcript, root, enc.get_n_col_opens()))
     assert pf.to_bytes() == opf
+
+
+def test_many_short_rows_exceed_grid_y(oracle):
+    """A commitment made with new_from_dims and a small n_per_row has more BLAKE3 chunks per leaf message than a grid
+    dimension may hold (65535): 2.2 M rows of 8 Ft255 coefficients -> 68 751 chunks.  The column hash launches the chunk
+    range in slices; root and opened columns must still equal the oracle's."""
+    O, fid = oracle, 3
+    n_per_row, n_cols, n_rows = 8, 16, 2_200_001
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+    coeffs = O.random_elems(fid, n_rows * n_per_row - 3, 91)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=8)
+    assert c.n_rows == n_rows
+    assert c.get_root() == oc.get_root()
+    assert (c.hashes() == oc.hashes()).all()
+    vals, _ = c.open_columns([0, 15, 7])
+    ocomm = oc.comm().reshape(n_rows, n_cols, 4)
+    assert (vals == ocomm[:, [0, 15, 7]].transpose(1, 0, 2)).all()
