@@ -33,7 +33,7 @@ def test_fuzz_ligero(oracle, seed):
     for i in range(20):
         fid = rnd.choice([0, 1, 2, 3, 3, 3])
         rho = rnd.choice([(1, 2), (1, 2), (1, 4), (3, 4), (38, 39)])
-        log_n = rnd.randrange(1, 18 if fid == 3 else 15)
+        log_n = rnd.randrange(1, 19 if fid == 3 else 15)
         n_cols = 1 << log_n
         n_per_row = max(1, min(n_cols - 1, n_cols * rho[0] // rho[1] - rnd.choice([0, 0, 1, 3])))
         max_rows = max(1, min(600, (1 << 19) // n_cols))

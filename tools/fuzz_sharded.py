@@ -31,7 +31,7 @@ for case in range(n_cases):
     oc = O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4)
     assert all(r == oc.get_root() for r in roots), (case, fid, n_rows, n_per_row, n_cols, G)
     for eng in engines:
-        assert (LcCommit(eng.enc).hashes() == oc.hashes()).all(), (case, "hashes")
+        assert (eng.cm.hashes() == oc.hashes()).all(), (case, "hashes")
     if case % 25 == 0:
         print("case", case, "ok", flush=True)
 print("all", n_cases, "sharded cases ok")
