@@ -222,14 +222,31 @@ def main():
         t_init = torch.zeros(1, device=dev)
         dist.all_reduce(t_init)
         torch.cuda.synchronize()
+        exchange_note = None
         if args.exchange == "native":
-            engine.comm_init()
-
+            # the library's own RCCL exchange; cross-checked once against the torch.distributed exchange of the same
+            # shard phases (outside the timed region) -- any disagreement or failure falls back to the latter, and says so
+            ok = 1
+            try:
+                engine.comm_init()
+                r_native = engine.commit_native(coeffs, n_rows_total, want_root=True, borrow=borrow)
+                r_torch = sharded_commit(engine, coeffs, n_rows_total, want_root=True, borrow=borrow)
+                if r_native != r_torch:
+                    ok, exchange_note = 0, "native root != torch.distributed root"
+            except Exception as ex:
+                ok, exchange_note = 0, "native exchange failed: %r" % (ex,)
+            t_ok = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            if int(t_ok.item()) == 0:
+                args.exchange = "torch"
+                exchange_note = exchange_note or "another rank reported a native-exchange problem"
+                print("[rank %d] falling back to the torch.distributed exchange: %s" % (rank, exchange_note), file=sys.stderr)
+        if args.exchange == "native":
             def step(sync=False, borrow_=borrow):
                 return engine.commit_native(coeffs, n_rows_total, want_root=sync, borrow=borrow_)
         else:
             def step(sync=False, borrow_=borrow):
-                return sharded_commit(engine, coeffs, n_rows_total, want_root=sync)
+                return sharded_commit(engine, coeffs, n_rows_total, want_root=sync, borrow=borrow_)
 
     def fence():
         if distributed:
@@ -408,6 +425,8 @@ def main():
         out["e2e_host"] = e2e
     if shard_ms is not None:
         out["shard_ms"] = shard_ms
+    if distributed and exchange_note:
+        out["exchange_fallback"] = exchange_note
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -219,7 +219,9 @@ int  lcpc_commit_shard_device(lcpc_commit_t *cm, const uint64_t *coeffs_local_de
                               void *stream, uint32_t flags, uint8_t *nodes_dev);
 /* phase 2 (after the all-gather): gathered_dev is the raw all-gather output, rank g's nodes at
  * [(g * slots_per_rank + k) * n_cols + col][32 B] (slots_per_rank >= max nodes per rank; unused slots ignored)
- * -> leaf digests, Merkle tree, root.  The buffer is clobbered. */
+ * -> leaf digests, Merkle tree, root.  The buffer is clobbered.
+ * slots_per_rank == 0 selects the COMPACT layout the native exchange uses: slot g = node 0 of rank g (g < shard_count),
+ * then the nodes k >= 1 of all ranks in rank order from slot shard_count on. */
 int  lcpc_commit_finish_device(lcpc_commit_t *cm, uint8_t *gathered_dev, uint64_t n_rows_total, uint32_t slots_per_rank,
                                void *stream, uint8_t *root);
 /* collapse on the local rows only (tensor entries for the local rows); partial results are summed

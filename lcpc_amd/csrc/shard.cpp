@@ -351,7 +351,7 @@ int lcpc_commit_shard_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uin
 }
 
 int lcpc_commit_finish_device(lcpc_commit_t* m, uint8_t* gathered, uint64_t n_rows_total, uint32_t slots_per_rank, void* stream, uint8_t* root) {
-  if (!m || !gathered || n_rows_total != m->n_rows || slots_per_rank == 0) return LCPC_ERR_ARG;
+  if (!m || !gathered || n_rows_total != m->n_rows) return LCPC_ERR_ARG;
   LCPC_TRY
   std::lock_guard<std::mutex> g(m->mu);
   HIPCHK(m, hipSetDevice(m->enc->prm.device));

@@ -216,10 +216,10 @@ def sharded_prove(engine, outer_tensor, tr, group=None, allgather=None):
     return data, cols
 
 
-def sharded_commit(engine, local_coeffs, n_rows_total, group=None, want_root=True):
+def sharded_commit(engine, local_coeffs, n_rows_total, group=None, want_root=True, borrow=False):
     """one row-sharded commit step: local encode + node CVs, all-gather, finish.  Returns the root."""
     _, _, _, _, n_chunks = engine.layout(n_rows_total)
-    nodes = engine.commit_shard(local_coeffs, n_rows_total)
+    nodes = engine.commit_shard(local_coeffs, n_rows_total, borrow) if borrow else engine.commit_shard(local_coeffs, n_rows_total)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         gathered, slots = exchange_nodes(nodes, n_chunks, group)
     else:

@@ -61,6 +61,34 @@ def test_sharded_equals_unsharded(oracle, fid, n_rows, n_per_row, n_cols, G):
             assert (c.comm(rb, re - rb) == oc.comm().reshape(n_rows, -1)[rb:re].reshape(-1, L)).all()
 
 
+@pytest.mark.parametrize("fid,n_rows,n_per_row,n_cols,G", [(3, 512, 256, 512, 8), (3, 512, 256, 512, 2), (3, 1024, 128, 256, 8), (3, 70, 64, 128, 4),
+                                                     (0, 3000, 64, 128, 3), (3, 20, 64, 128, 2)])
+def test_compact_exchange_layout(oracle, fid, n_rows, n_per_row, n_cols, G):
+    """the layout the native RCCL exchange produces (lcpc_commit_sharded_device: one all-gather of node 0 of every rank,
+    then one broadcast per extra node) assembled by hand: slot g = node 0 of rank g, extras in rank order from slot G on;
+    lcpc_commit_finish_device with slots_per_rank = 0 must fold it to the oracle's tree on every rank."""
+    O = oracle
+    L = O.limbs(fid)
+    coeffs = O.random_elems(fid, n_rows * n_per_row, 29)
+    dev = torch.from_numpy(coeffs.view(np.int64)).cuda().reshape(n_rows, n_per_row, L)
+    engines = [HipShardEngine(LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=(g, G))) for g in range(G)]
+    nodes = []
+    for g, eng in enumerate(engines):
+        rb, re, cb, ce, nch = eng.layout(n_rows)
+        nodes.append(eng.commit_shard(dev[rb:re].contiguous(), n_rows).clone())
+    extras = [nd[k] for nd in nodes for k in range(1, nd.shape[0])]
+    gathered = torch.zeros((G + len(extras), n_cols, 32), dtype=torch.uint8, device="cuda")
+    for g, nd in enumerate(nodes):
+        if nd.shape[0]:
+            gathered[g] = nd[0]
+    for i, e in enumerate(extras):
+        gathered[G + i] = e
+    oc = O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4)
+    for eng in engines:
+        assert eng.commit_finish(gathered.clone(), n_rows, 0) == oc.get_root()
+        assert (eng.cm.hashes() == oc.hashes()).all()
+
+
 def test_sharding_rejects_straddling_field():
     # ft191 rows (24 B) straddle 1 KiB chunk boundaries: row sharding is refused rather than silently wrong
     with pytest.raises(lcpc_amd.LcpcError) as e:
