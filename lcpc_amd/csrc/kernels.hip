@@ -1084,6 +1084,59 @@ hipError_t launch_transpose_from_t(int nl, const u32* t, u64 n_pos, u64 n_rows, 
 
 // OPW = outputs per workgroup: 4 for the wide levels, 1 for the narrow tail levels (a few hundred outputs: the
 // launch is latency-bound, so spread the outputs over as many workgroups as possible)
+typedef u32 __attribute__((address_space(4))) ConstU32;
+// one output's partial dot product over terms [k0, k1) of its CSR row (wave-uniform bounds), gathered from column rr
+template <int NL>
+__device__ __forceinline__ Fe<NL> spmm_t_terms(const SpmmTArgs& a, const u32* xin, size_t pstride, u32 k0, u32 k1) {
+  Fe<NL> res = fe_zero<NL>();
+  if constexpr (NL == 8) {
+    // The matrix is read through the constant address space: its wave-uniform addresses become scalar loads (s_load
+    // into SGPRs, which the multiplier takes directly) instead of vector loads + readfirstlane (-10 VALU per term).
+    const ConstU32* cidx = (const ConstU32*)a.colidx;
+    const ConstU32* cv29 = (const ConstU32*)a.vals29;
+    for (u32 kb = k0; kb < k1; kb += 60) {         // <= 60 terms per Montgomery reduction (lazy29_reduce bound)
+      const u32 ke = kb + 60 < k1 ? kb + 60 : k1;
+      Lazy29 acc;
+      lazy29_zero(acc);
+      u32 since = 0;
+      // the column index is fetched two terms ahead, the gathered operand and the matrix value one term ahead (indices
+      // clamped to the chunk: the redundant scalar loads at its end stay in bounds)
+      Fe<NL> x = fe_load<NL>(xin + (size_t)cidx[kb] * pstride);
+      u32 cn = cidx[kb + 1 < ke ? kb + 1 : kb];
+      Fe29 v;
+#pragma unroll
+      for (int i = 0; i < 9; i++) v.v[i] = cv29[(size_t)kb * 12 + i];
+      for (u32 k = kb; k < ke; k++) {
+        Fe<NL> xn = x;
+        if (k + 1 < ke) xn = fe_load<NL>(xin + (size_t)cn * pstride);
+        const u32 kn = k + 1 < ke ? k + 1 : k, kn2 = k + 2 < ke ? k + 2 : k;
+        cn = cidx[kn2];
+        Fe29 vn;
+#pragma unroll
+        for (int i = 0; i < 9; i++) vn.v[i] = cv29[(size_t)kn * 12 + i];
+        lazy29_mac(acc, fe_to29(x), v);
+        v = vn;
+        if (++since == 6) { lazy29_normalize(acc); since = 0; }
+        x = xn;
+      }
+      res = fe_add<NL>(res, lazy29_reduce(acc));
+    }
+  } else {
+    for (u32 kb = k0; kb < k1; kb += 8) {
+      Wide<NL> w = wide_zero<NL>();
+      const u32 ke = kb + 8 < k1 ? kb + 8 : k1;
+      for (u32 k = kb; k < ke; k++) {
+        const u32 col = __builtin_amdgcn_readfirstlane(a.colidx[k]);
+        const Fe<NL> v = fe_load<NL>(a.vals + (size_t)k * NL);
+        wide_mac<NL>(w, v, fe_load<NL>(xin + (size_t)col * pstride));
+      }
+      res = fe_add<NL>(res, wide_reduce<NL>(w));
+    }
+  }
+  return res;
+}
+
+// OPW = outputs per workgroup: 4 for the wide levels, 1 for the narrower ones
 template <int NL, int SPMM_OPW>
 __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a) {
   const u64 row = (u64)blockIdx.y * 128 + threadIdx.x;
@@ -1096,43 +1149,45 @@ __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a) {
     if (o >= a.m) break;
     const u32 k0 = __builtin_amdgcn_readfirstlane(a.rowptr[o]);
     const u32 k1 = __builtin_amdgcn_readfirstlane(a.rowptr[o + 1]);
-    Fe<NL> res;
-    if constexpr (NL == 8) {
-      res = fe_zero<NL>();
-      for (u32 kb = k0; kb < k1; kb += 60) {         // <= 60 terms per Montgomery reduction (lazy29_reduce bound)
-        const u32 ke = kb + 60 < k1 ? kb + 60 : k1;
-        Lazy29 acc;
-        lazy29_zero(acc);
-        u32 since = 0;
-        u32 col = __builtin_amdgcn_readfirstlane(a.colidx[kb]);
-        Fe<NL> x = fe_load<NL>(xin + (size_t)col * pstride);
-        for (u32 k = kb; k < ke; k++) {
-          Fe<NL> xn = x;
-          if (k + 1 < ke) {                          // prefetch the next gathered operand
-            const u32 cn = __builtin_amdgcn_readfirstlane(a.colidx[k + 1]);
-            xn = fe_load<NL>(xin + (size_t)cn * pstride);
-          }
-          Fe29 v;
+    const Fe<NL> res = spmm_t_terms<NL>(a, xin, pstride, k0, k1);
+    if (live) {
+      u32* dst = a.out_alt ? a.out_alt + (o * a.n_rows + row) * NL : a.t + ((a.out_off + o) * a.n_rows + row) * NL;
+      fe_store<NL>(dst, res);
+    }
+  }
+}
+
+// The tail levels of the recursion have a few hundred outputs or fewer, each a dependent chain of up to ~100 gathered
+// terms: the launch is bound by that chain's latency, not by throughput.  SL wave-groups per output each take 1/SL of the
+// terms; the partial sums (field elements: addition is exact, so the split does not change the result) meet in LDS.
+template <int NL, int SL>
+__global__ void __launch_bounds__(128 * SL) spmm_t_sliced_kernel(SpmmTArgs a) {
+  __shared__ u32 part[(SL - 1) * 128 * NL];
+  const u32 lane = threadIdx.x & 127;
+  const u32 sl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+  const u64 row = (u64)blockIdx.y * 128 + lane;
+  const bool live = row < a.n_rows;
+  const u64 rr = live ? row : 0;
+  const u32* xin = a.t + (a.in_off * a.n_rows + rr) * NL;
+  const size_t pstride = (size_t)a.n_rows * NL;
+  const u64 o = blockIdx.x;
+  const u32 k0 = __builtin_amdgcn_readfirstlane(a.rowptr[o]);
+  const u32 k1 = __builtin_amdgcn_readfirstlane(a.rowptr[o + 1]);
+  const u32 len = k1 - k0;
+  const u32 ks = k0 + (u32)(((u64)len * sl) / SL), ke = k0 + (u32)(((u64)len * (sl + 1)) / SL);
+  Fe<NL> res = spmm_t_terms<NL>(a, xin, pstride, ks, ke);
+  if (sl) {
 #pragma unroll
-          for (int i = 0; i < 9; i++) v.v[i] = __builtin_amdgcn_readfirstlane(a.vals29[(size_t)k * 12 + i]);
-          lazy29_mac(acc, fe_to29(x), v);
-          if (++since == 6) { lazy29_normalize(acc); since = 0; }
-          x = xn;
-        }
-        res = fe_add<NL>(res, lazy29_reduce(acc));
-      }
-    } else {
-      res = fe_zero<NL>();
-      for (u32 kb = k0; kb < k1; kb += 8) {
-        Wide<NL> w = wide_zero<NL>();
-        const u32 ke = kb + 8 < k1 ? kb + 8 : k1;
-        for (u32 k = kb; k < ke; k++) {
-          const u32 col = __builtin_amdgcn_readfirstlane(a.colidx[k]);
-          const Fe<NL> v = fe_load<NL>(a.vals + (size_t)k * NL);
-          wide_mac<NL>(w, v, fe_load<NL>(xin + (size_t)col * pstride));
-        }
-        res = fe_add<NL>(res, wide_reduce<NL>(w));
-      }
+    for (int i = 0; i < NL; i++) part[((sl - 1) * NL + i) * 128 + lane] = res.v[i];
+  }
+  __syncthreads();
+  if (sl == 0) {
+#pragma unroll
+    for (int s = 0; s < SL - 1; s++) {
+      Fe<NL> p;
+#pragma unroll
+      for (int i = 0; i < NL; i++) p.v[i] = part[(s * NL + i) * 128 + lane];
+      res = fe_add<NL>(res, p);
     }
     if (live) {
       u32* dst = a.out_alt ? a.out_alt + (o * a.n_rows + row) * NL : a.t + ((a.out_off + o) * a.n_rows + row) * NL;
@@ -1145,9 +1200,15 @@ hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st) {
   if (a.m >= 8192) {
     dim3 grid((unsigned)((a.m + 3) / 4), (unsigned)((a.n_rows + 127) / 128));
     LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_kernel<NLV, 4>), grid, dim3(128), 0, st, a));
-  } else {
+  } else if (a.m > 2048) {
     dim3 grid((unsigned)a.m, (unsigned)((a.n_rows + 127) / 128));
     LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_kernel<NLV, 1>), grid, dim3(128), 0, st, a));
+  } else if (a.m > 256) {
+    dim3 grid((unsigned)a.m, (unsigned)((a.n_rows + 127) / 128));
+    LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_sliced_kernel<NLV, 4>), grid, dim3(512), 0, st, a));
+  } else {
+    dim3 grid((unsigned)a.m, (unsigned)((a.n_rows + 127) / 128));
+    LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_sliced_kernel<NLV, 8>), grid, dim3(1024), 0, st, a));
   }
   return hipGetLastError();
 }
