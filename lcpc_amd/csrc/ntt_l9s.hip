@@ -293,9 +293,9 @@ hipError_t launch_t(const NttPassArgs& a, const u32* pack, const NttPackInfo& pi
 
 }  // namespace
 
-bool ntt_l9s_supported(uint32_t log_n, uint32_t n_passes, int log_tile) { return n_passes == 2 && log_tile == 10 && log_n >= 11 && log_n <= 18; }
+bool ntt_l9s_supported(uint32_t log_n, uint32_t n_passes, int log_tile) { return n_passes == 2 && log_tile == 10 && log_n >= 11 && log_n <= 20; }
 
-#define L9S_FIRST_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#define L9S_FIRST_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 
 NttPackInfo ntt_l9s_pack_info(uint32_t s, bool first) {
   if (!first) return pack_info_t<10, 0>();

@@ -1,5 +1,5 @@
-"""Every shape of the specialised Ft255 row NTT (ntt_l9s.hip): two-pass plans, n_cols = 2^11 .. 2^18, i.e. first passes of
-1 .. 8 stages (odd counts peel a radix-2 round at stage 0) on 2 .. 512-element runs, last pass of 10 stages.  For each:
+"""Every shape of the specialised Ft255 row NTT (ntt_l9s.hip): two-pass plans, n_cols = 2^11 .. 2^20, i.e. first passes of
+1 .. 10 stages (odd counts peel a radix-2 round at stage 0) on 1 .. 512-element runs, last pass of 10 stages.  For each:
 commit (canonical-output path, coeffs copy fused into pass 1, ragged last row) and encode_rows (Montgomery path) against
 the oracle, at the rates the reference uses (1/2 default, 1/4 timing test, 38/39 and 3/4: no zero half / partly zero).
 The general kernel (LCPC_NTT_GENERAL=1) must give the same bytes."""
@@ -13,7 +13,7 @@ from lcpc_amd import LcCommit, LigeroEncoding
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("log_n", list(range(11, 19)))
+@pytest.mark.parametrize("log_n", list(range(11, 21)))
 @pytest.mark.parametrize("rate", ["1/2", "1/4", "38/39", "3/4", "1/2-"])
 def test_commit_all_two_pass_shapes(oracle, log_n, rate):
     O, fid = oracle, 3
@@ -37,7 +37,7 @@ def test_commit_all_two_pass_shapes(oracle, log_n, rate):
     assert (enc.encode(rows) == oc.comm()[n_cols:]).all()
 
 
-@pytest.mark.parametrize("log_n", [11, 14, 17, 18])
+@pytest.mark.parametrize("log_n", [11, 14, 17, 18, 19, 20])
 def test_general_kernel_agrees(oracle, log_n):
     O, fid = oracle, 3
     n_cols, n_per_row = 1 << log_n, 1 << (log_n - 1)
