@@ -112,8 +112,10 @@ __device__ __forceinline__ Fe<NL> tw_mul(const Fe<NL>& d, const Tw<NL>& t) {
   else return fe_mul<NL>(d, t.w);
 }
 
-template <int NL, int LT>
-__global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
+// BS threads per workgroup: 256, or 1024 when the launch has too few tiles to fill the chip (tiny commits: a round is
+// then one quad per thread instead of four in sequence)
+template <int NL, int LT, int BS>
+__global__ void __launch_bounds__(BS) ntt_pass_kernel(NttPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   const u32 k = a.log_n, t0 = a.t0, s = a.s, ltj = a.log_tj;
   const u32 lb = k - t0 - s;                    // bits below the pass's i-field
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
   };
 
   const u32* src = a.src + row * a.src_stride * NL;
-  for (u32 e = tid; e < T; e += 256) {
+  for (u32 e = tid; e < T; e += BS) {
     const u32 g = gindex(e);
     Fe<NL> v = (g < a.n_valid && row * a.src_stride + g < a.n_src_total) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
     lds_put<NL, LT>(lds, e, v);
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
     const u32 hb = s - u - 1;                    // pair bit of stage u; stage u+1 uses hb-1
     const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
     const bool last_two = (t + 2 == k);          // stages k-2, k-1: twiddles are 1, w^(n/4), 1
-    for (u32 q = tid; q < T / 4; q += 256) {
+    for (u32 q = tid; q < T / 4; q += BS) {
       const u32 lp = q & lp_mask;
       const u32 j = (q >> lbt) & (i_mask >> 2);
       const u32 hp = q >> (lbt + s - 2);
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
     const u32 t = t0 + u;
     const u32 hb = s - u - 1;
     const u32 gm = (1u << (k - t - 1)) - 1;
-    for (u32 q = tid; q < T / 2; q += 256) {
+    for (u32 q = tid; q < T / 2; q += BS) {
       const u32 lp = q & lp_mask;
       const u32 j = (q >> lbt) & (i_mask >> 1);
       const u32 hp = q >> (lbt + s - 1);
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(NttPassArgs a) {
   }
 
   u32* dst = a.dst + row * a.dst_stride * NL;
-  for (u32 e = tid; e < T; e += 256) fe_store<NL>(dst + (size_t)gindex(e) * NL, lds_get<NL, LT>(lds, e));
+  for (u32 e = tid; e < T; e += BS) fe_store<NL>(dst + (size_t)gindex(e) * NL, lds_get<NL, LT>(lds, e));
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -414,36 +416,32 @@ template <int LT>
 static hipError_t launch_ntt_pass_l9_t(const NttPassArgs& a, hipStream_t st) {
   const u64 tiles = ((u64)1 << (a.log_n - a.s - a.log_tj)) * a.n_rows;
   const size_t lds_bytes = (size_t)Lds9<LT>::WORDS * 4;
-  static bool attr_set_dev[64] = {};            // the attribute is per device (one process may drive several GPUs)
-  int dev_id = 0;
-  (void)hipGetDevice(&dev_id);
-  bool& attr_set = attr_set_dev[dev_id & 63];
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_l9_kernel<LT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  // (idempotent and cheap; set on every launch rather than cached in an unsynchronised static)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_l9_kernel<LT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((ntt_pass_l9_kernel<LT>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
   return hipGetLastError();
 }
 
+template <int NL, int LT, int BS>
+static hipError_t launch_ntt_pass_bs(const NttPassArgs& a, u64 tiles, hipStream_t st) {
+  const size_t lds_bytes = ((size_t)NL * 4) << LT;
+  // hipFuncSetAttribute is idempotent and cheap; calling it on every launch keeps this free of unsynchronised caches
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<NL, LT, BS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((ntt_pass_kernel<NL, LT, BS>), dim3((unsigned)tiles), dim3(BS), lds_bytes, st, a);
+  return hipGetLastError();
+}
 template <int NL, int LT>
 static hipError_t launch_ntt_pass_t(const NttPassArgs& a, hipStream_t st) {
   const u64 tiles = ((u64)1 << (a.log_n - a.s - a.log_tj)) * a.n_rows;
-  const size_t lds_bytes = ((size_t)NL * 4) << LT;
-  static bool attr_set_dev[64] = {};            // the attribute is per device (one process may drive several GPUs)
-  int dev_id = 0;
-  (void)hipGetDevice(&dev_id);
-  bool& attr_set = attr_set_dev[dev_id & 63];
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<NL, LT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  // fewer tiles than CUs and at least 1024 quads per round: spend the idle SIMDs inside the workgroup
+  if constexpr (LT >= 12) {
+    if (tiles <= 256 && a.s + a.log_tj >= 12) return launch_ntt_pass_bs<NL, LT, 1024>(a, tiles, st);
   }
-  hipLaunchKernelGGL((ntt_pass_kernel<NL, LT>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a);
-  return hipGetLastError();
+  return launch_ntt_pass_bs<NL, LT, 256>(a, tiles, st);
 }
 hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream_t st) {
   if (a.s + a.log_tj > (uint32_t)log_tile) return hipErrorInvalidValue;
