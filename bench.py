@@ -312,7 +312,7 @@ def main():
     ntt_launches = max(1, tm.encode_launches)
     ntt_ms = tm.encode_ms / ntt_launches
     achieved = (enc_bytes / ntt_launches) / (ntt_ms * 1e-3) / 1e9 if ntt_ms > 0 else 0.0
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_issue = None, None, None
     stamp = kernel_stamp()
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path) and world == 1 and args.log_len == 26:
@@ -321,6 +321,14 @@ def main():
         pmc = json.load(open(pmc_path))
         if pmc.get("kernel_stamp") == stamp and pmc.get("borrow_coeffs", False) == borrow:
             per = [(2.0 * v["FETCH_KB"] + v["WRITE_KB"]) * 1024 / 1e9 for kname, v in pmc["kernels"].items() if kname.startswith("ntt_pass")]
+            insts = [v["SQ_INSTS_VALU"] for kname, v in pmc["kernels"].items() if kname.startswith("ntt_pass") and "SQ_INSTS_VALU" in v]
+            if insts and ntt_ms > 0:
+                # what actually binds the kernel: vector-ALU instruction issue, one wave instruction per SIMD every 4 cycles
+                # (256 CUs x 4 SIMDs at the 2.4 GHz peak clock; the board sustains ~2.1 GHz at its power limit)
+                per_s = sum(insts) / len(insts) / (ntt_ms * 1e-3)
+                valu_issue = {"wave_insts_per_launch": round(sum(insts) / len(insts)), "achieved_Ginst_per_s": round(per_s / 1e9, 1),
+                              "peak_Ginst_per_s": 614.4, "frac": round(per_s / 614.4e9, 3),
+                              "source": "SQ_INSTS_VALU, profiles/pmc_latest.json (same stamp)"}
             if per:         # the NTT passes are separate kernel instantiations, one launch each per commit: mean per launch
                 traffic = round(sum(per) / len(per), 3)
                 traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc, kernel stamp %s; GB per launch = 2*FETCH_SIZE + WRITE_SIZE, mean over the %d NTT passes)" % (stamp, len(per))
@@ -330,7 +338,7 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_unit": "GB/launch", "traffic_source": traffic_src,
                 "algorithmic_GB_per_launch": round(enc_bytes / ntt_launches / 1e9, 3),
-                "avg_launch_ms": round(ntt_ms, 4),
+                "avg_launch_ms": round(ntt_ms, 4), "valu_issue": valu_issue,
                 "note": "255-bit modular multiply: integer-VALU bound (DESIGN.md section 6), not HBM-bound",
                 "commit_GBps": round(commit_bytes / (tm.total_ms * 1e-3) / 1e9, 1) if tm.total_ms > 0 else None,
                 "power": None,

@@ -4,7 +4,7 @@
 #   bench_kernel_stats.txt    rocprofv3 --kernel-trace --stats of the same command (no CPU baseline)
 #   bench_pmc_{fetch,write,sq}.txt + pmc.json     separate --pmc passes (never combined with traces)
 #   clock_power.txt           rocm-smi sclk / socket power sampled while the bench loops
-#   configs.jsonl, c3_kernel_stats.txt, c5_kernel_stats.txt   the other BASELINE.json configs
+#   configs.jsonl, c3_kernel_stats.txt, c3_dispatches.txt, c5_kernel_stats.txt, c4_rank.jsonl   the other BASELINE.json configs
 # Run on the MI355X box:  gpurun -- 'bash tools/profile_round.sh r01f'
 TAG=${1:-latest}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -20,10 +20,10 @@ rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench -- python $R/bench.py --steps 2 
 python $R/tools/rocpd_summary.py $(db $O/fetch) --pmc > $O/bench_pmc_fetch.txt
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench -- python $R/bench.py --steps 2 --warmup 1 --lean > $O/write.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/write) --pmc > $O/bench_pmc_write.txt
-python $R/tools/pmc_to_json.py $(db $O/fetch) $(db $O/write) $O/pmc.json > /dev/null      # -> copy to profiles/pmc_latest.json
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
   -d $O/sq -o bench -- python $R/bench.py --steps 2 --warmup 1 --lean > $O/sq.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/sq) --pmc > $O/bench_pmc_sq.txt
+python $R/tools/pmc_to_json.py $(db $O/fetch) $(db $O/write) $O/pmc.json $(db $O/sq) > /dev/null      # -> copy to profiles/pmc_latest.json
 # clocks / power while the bench loops
 python $R/bench.py --steps 1200 --warmup 2 --no-cpu-baseline > $O/clk_bench.log 2>&1 &
 BP=$!
@@ -38,6 +38,8 @@ tail -1 $O/clk_bench.log | cut -c1-220 >> $O/clock_power.txt
 python $R/tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.log
 rocprofv3 --kernel-trace --stats -d $O/c3 -o c3 -- python $R/tools/bench_configs.py c3 > $O/c3.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/c3) > $O/c3_kernel_stats.txt
+python $R/tools/rocpd_dispatches.py $(db $O/c3) | tail -24 > $O/c3_dispatches.txt      # the last commit, launch by launch
+python $R/tools/bench_c4_rank.py > $O/c4_rank.jsonl 2> $O/c4_rank.log
 rocprofv3 --kernel-trace --stats -d $O/c5 -o c5 -- python $R/tools/bench_configs.py c5 > $O/c5.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/c5) > $O/c5_kernel_stats.txt
 rm -rf $O/kt $O/fetch $O/write $O/sq $O/c3 $O/c5     # raw .db files stay out of the merge-back
