@@ -170,7 +170,8 @@ void lcpc_transcript_free(lcpc_transcript *);
 /* ---- prove / verify ---- */
 /* LcCommit::prove (lib.rs:304-311 -> 1004-1093); the encoder is the one the commitment was made with.  The proof is returned in the reference's bincode 1.3
  * wire layout (lib.rs:550-609): the only way to hand an LcEvalProof to the reference (its fields are
- * private).  `*proof` is malloc'ed; free with lcpc_free.  cols_opened (n_col_opens entries) may be NULL. */
+ * private).  `*proof` is allocated by the library; release it with lcpc_free
+ * (which may keep one released buffer for the next proof instead of returning it to the OS).  cols_opened (n_col_opens entries) may be NULL. */
 int  lcpc_prove(lcpc_commit_t *cm, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
                 uint8_t **proof, uint64_t *proof_len, uint64_t *cols_opened);
 /* LcEvalProof::verify (lib.rs:518-527 -> 832-952) on a bincode proof; `ctx` plays the role of `enc`

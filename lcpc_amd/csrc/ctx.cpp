@@ -526,6 +526,6 @@ void lcpc_root_bincode(const uint8_t root[32], uint8_t out[40]) {
   memcpy(out, &l, 8);
   memcpy(out + 8, root, 32);
 }
-void lcpc_free(void* p) { free(p); }
+void lcpc_free(void* p) { lcpc::proof_buf_free(p); }
 
 }  // extern "C"

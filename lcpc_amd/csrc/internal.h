@@ -44,6 +44,10 @@ struct EncodeWs {
   uint64_t t_cap = 0;
 };
 
+// proof buffers (prove.cpp): lcpc_free hands them back; one is kept for the next proof
+void* proof_buf_alloc(size_t n);
+void proof_buf_free(void* p);
+
 }  // namespace lcpc
 
 struct lcpc_transcript {

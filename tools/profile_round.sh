@@ -40,6 +40,7 @@ rocprofv3 --kernel-trace --stats -d $O/c3 -o c3 -- python $R/tools/bench_configs
 python $R/tools/rocpd_summary.py $(db $O/c3) > $O/c3_kernel_stats.txt
 python $R/tools/rocpd_dispatches.py $(db $O/c3) | tail -24 > $O/c3_dispatches.txt      # the last commit, launch by launch
 python $R/tools/bench_c4_rank.py > $O/c4_rank.jsonl 2> $O/c4_rank.log
+python $R/tools/bench_pvs.py > $O/pvs.jsonl 2> $O/pvs.log                              # the reference's rough_bench / prove_verify_size_bench loops
 rocprofv3 --kernel-trace --stats -d $O/c5 -o c5 -- python $R/tools/bench_configs.py c5 > $O/c5.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/c5) > $O/c5_kernel_stats.txt
 rm -rf $O/kt $O/fetch $O/write $O/sq $O/c3 $O/c5     # raw .db files stay out of the merge-back
