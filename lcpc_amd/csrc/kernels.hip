@@ -1080,8 +1080,6 @@ hipError_t launch_transpose_from_t(int nl, const u32* t, u64 n_pos, u64 n_rows, 
   return hipGetLastError();
 }
 
-// OPW = outputs per workgroup: 4 for the wide levels, 1 for the narrow tail levels (a few hundred outputs: the
-// launch is latency-bound, so spread the outputs over as many workgroups as possible)
 typedef u32 __attribute__((address_space(4))) ConstU32;
 // one output's partial dot product over terms [k0, k1) of its CSR row (wave-uniform bounds), gathered from column rr
 template <int NL>
@@ -1134,7 +1132,7 @@ __device__ __forceinline__ Fe<NL> spmm_t_terms(const SpmmTArgs& a, const u32* xi
   return res;
 }
 
-// OPW = outputs per workgroup: 4 for the wide levels, 1 for the narrower ones
+// OPW = outputs per workgroup (4: the wide levels; narrower ones go to spmm_t_sliced_kernel)
 template <int NL, int SPMM_OPW>
 __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a) {
   const u64 row = (u64)blockIdx.y * 128 + threadIdx.x;
@@ -1200,7 +1198,7 @@ hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st) {
     LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_kernel<NLV, 4>), grid, dim3(128), 0, st, a));
   } else if (a.m > 2048) {
     dim3 grid((unsigned)a.m, (unsigned)((a.n_rows + 127) / 128));
-    LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_kernel<NLV, 1>), grid, dim3(128), 0, st, a));
+    LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_sliced_kernel<NLV, 2>), grid, dim3(256), 0, st, a));
   } else if (a.m > 256) {
     dim3 grid((unsigned)a.m, (unsigned)((a.n_rows + 127) / 128));
     LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_sliced_kernel<NLV, 4>), grid, dim3(512), 0, st, a));
