@@ -3,8 +3,10 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -32,6 +34,70 @@ unsigned usable_cores() {
     return n;
   }();
   return cached;
+}
+
+// ---- the worker pool behind parallel_for (host_par.h) -------------------------------------------------
+namespace {
+struct ParPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<ParJob*> jobs;                    // regions with unclaimed chunks (and exhausted ones until their caller removes them)
+  ParJob* pick() {                              // under mu
+    for (ParJob* j : jobs)
+      if (j->next.load(std::memory_order_relaxed) < j->n_chunks && j->attached.load(std::memory_order_relaxed) < j->max_workers) return j;
+    return nullptr;
+  }
+  static void drain(ParJob* j) {
+    for (;;) {
+      const uint64_t c = j->next.fetch_add(1);
+      if (c >= j->n_chunks) return;
+      try { j->run(j->ctx, c); } catch (...) { j->failed.store(true); }
+    }
+  }
+  void worker() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      ParJob* j;
+      while (!(j = pick())) cv.wait(lk);
+      j->attached.fetch_add(1);                 // under mu: the caller removes the job under mu before it waits for attached == 0
+      lk.unlock();
+      drain(j);
+      j->attached.fetch_sub(1);                 // the last touch of *j by this thread
+      lk.lock();
+    }
+  }
+};
+ParPool* par_pool() {
+  // created on first use and never destroyed (detached workers: nothing to join at process exit or library unload)
+  static ParPool* pool = [] {
+    ParPool* p = new ParPool;
+    const unsigned n = usable_cores() > 1 ? usable_cores() - 1 : 0;
+    for (unsigned i = 0; i < n; i++) {
+      try { std::thread([p] { p->worker(); }).detach(); } catch (...) { break; }     // fewer workers: the callers do more themselves
+    }
+    return p;
+  }();
+  return pool;
+}
+}  // namespace
+
+void par_run(ParJob& job) {
+  ParPool* p = par_pool();
+  {
+    std::lock_guard<std::mutex> g(p->mu);
+    p->jobs.push_back(&job);
+  }
+  if (job.max_workers == 1) p->cv.notify_one(); else p->cv.notify_all();
+  ParPool::drain(&job);                         // the caller works too, so a busy (or absent) pool only costs parallelism
+  {
+    std::lock_guard<std::mutex> g(p->mu);
+    for (size_t i = 0; i < p->jobs.size(); i++)
+      if (p->jobs[i] == &job) { p->jobs.erase(p->jobs.begin() + i); break; }
+  }
+  // no new worker can attach now; wait for those still running a chunk (about as long as the caller's own last chunk)
+  for (unsigned spin = 0; job.attached.load() != 0; spin++) {
+    if (spin > 256) std::this_thread::yield();
+  }
 }
 
 
