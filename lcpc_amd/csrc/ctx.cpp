@@ -22,6 +22,7 @@ static void ctx_free(lcpc_ctx* c) {
   dev_free(c->d_pack[0]); dev_free(c->d_pack[1]);
   dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
   dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->d_scratch);
+  if (c->h_varena) (void)hipHostFree(c->h_varena);
   for (auto* v : {&c->d_pre, &c->d_post})
     for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); dev_free(d.vals29); }
   delete c;

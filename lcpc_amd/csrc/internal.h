@@ -87,6 +87,11 @@ struct lcpc_ctx {
   std::atomic<int> refs{1};        // the handle itself + one per live lcpc_commit
   std::string err;
   std::mutex mu;
+  // lcpc_verify's host working set (encoded rows as they come back, to_repr of the polynomials): pinned, kept between
+  // calls (a fresh 150 MB of pageable memory costs ~20 ms in first-touch faults and munmap at Brakedown 2^27)
+  std::mutex verify_mu;            // held for a whole lcpc_verify call
+  uint8_t* h_varena = nullptr;
+  size_t h_varena_cap = 0;
 };
 
 struct lcpc_commit_s {

@@ -347,13 +347,26 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
   //   side thread  to_repr of the polynomials the transcript absorbs (published one by one), the limb check of the
   //                columns, and the part of step 3 (lib.rs:923-944) that does not depend on WHICH columns were drawn:
   //                the tensor . column dot products and the leaf hash of every opened column, and <inner, p_eval>.
-  std::unique_ptr<uint64_t[]> enc(new uint64_t[(size_t)(n_deg + 1) * n_cols * L]);
+  const size_t enc_words = (size_t)(n_deg + 1) * n_cols * L, canon_words = (size_t)(n_deg + 1) * n_per_row * L;
+  std::lock_guard<std::mutex> arena_lock(c->verify_mu);
+  {
+    const size_t need = (enc_words + canon_words) * 8 + 256;
+    if (c->h_varena_cap < need) {
+      if (hipSetDevice(c->prm.device) != hipSuccess) return LCPC_ERR_HIP;
+      if (c->h_varena) (void)hipHostFree(c->h_varena);
+      c->h_varena = nullptr; c->h_varena_cap = 0;
+      void* hp = nullptr;
+      if (hipHostMalloc(&hp, need + need / 4, hipHostMallocDefault) != hipSuccess) return LCPC_ERR_NOMEM;
+      c->h_varena = static_cast<uint8_t*>(hp); c->h_varena_cap = need + need / 4;
+    }
+  }
+  uint64_t* const enc = reinterpret_cast<uint64_t*>(c->h_varena);
+  uint64_t* const vcanon = enc + ((enc_words + 31) & ~(size_t)31);
   std::vector<const uint64_t*> enc_msgs(n_deg + 1);
   for (uint64_t i = 0; i < n_deg; i++) enc_msgs[i] = p_random[i].data();
   enc_msgs[n_deg] = p_eval.data();
   std::vector<std::vector<uint64_t>> rand_tensors(n_deg, std::vector<uint64_t>(n_rows * L));
   std::vector<uint64_t> cols_to_open(n_columns);
-  std::vector<uint64_t> vcanon((n_deg + 1) * n_per_row * L);
   std::vector<uint64_t> dots((n_deg + 1) * n_columns * MAXL);                 // dots[d][i] = <tensor_d, column i>
   std::vector<uint8_t> leaf(n_columns * 32);
   uint64_t eval_acc[MAXL] = {0, 0, 0, 0};
@@ -365,7 +378,7 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
   std::thread enc_thread, side_thread;
   JoinGuard join_enc{enc_thread}, join_side{side_thread};
   struct Release { std::atomic<bool>& flag; ~Release() { flag.store(true); } } release{tensors_ready};   // (runs before the joins on every exit path)
-  enc_thread = std::thread([&] { const double t0 = now_ms(); enc_rc = encode_msgs_host(c, enc_msgs.data(), n_deg + 1, enc.get()); t_enc = now_ms() - t0; });
+  enc_thread = std::thread([&] { const double t0 = now_ms(); enc_rc = encode_msgs_host(c, enc_msgs.data(), n_deg + 1, enc); t_enc = now_ms() - t0; });
   side_thread = std::thread([&] {
     try {
       const double t0 = now_ms();

@@ -5,7 +5,7 @@ import bench_configs as B
 import oracle_lib as O
 from common import mk_transcript, powers
 from lcpc_amd import LcCommit, SdigEncoding, Transcript
-for lgl in (13, 21, 25):
+for lgl in ([int(a) for a in sys.argv[1:]] or [13, 21, 25]):
     n = 1 << lgl
     enc = SdigEncoding.new(3, n, 0)
     coeffs = B.rand_coeffs(n, 4, 1)
