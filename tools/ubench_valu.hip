@@ -89,6 +89,13 @@ KERNEL(k_ashrrev_i64, u64 a0=x;u64 a1=y;u64 a2=x+1;u64 a3=y+1;u64 a4=x+2;u64 a5=
      : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7)),
   (u32)(a0^a1^a2^a3^a4^a5^a6^a7))
 
+// cross-lane moves (what a limb-sliced multiply -- one element spread over 9 lanes -- would pay per limb product)
+KERNEL(k_dpp_ror, DECL8, asm volatile("v_mov_b32_dpp %0, %8 row_ror:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n"
+                                      "v_mov_b32_dpp %4, %9 row_ror:2 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %4 row_ror:2 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %5 row_ror:2 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %6 row_ror:2 row_mask:0xf bank_mask:0xf\n"
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(x),"v"(y)), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_bpermute, DECL8; u32 idx = ((threadIdx.x + 9) & 63) * 4, asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)\n"
+     : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(idx)), a0^a1^a2^a3^a4^a5^a6^a7)
+
 template <typename K> static double run(K kern, const char* name, int ops_per_body, int waves_per_simd, u32* d){
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   int blocks = 256 * waves_per_simd;   // 256 CUs x (waves_per_simd) blocks of 256 threads = 4 waves => waves/SIMD
@@ -113,6 +120,7 @@ int main(){
     run(k_cndmask,"v_cndmask_b32 (vcc)",8,w,d); run(k_cndmask_cmp,"v_cmp + 8 cndmask(vcc)",9,w,d); run(k_cndmask_e64,"v_cndmask_b32_e64 sgpr",8,w,d); run(k_sel_arith,"xor/and/xor select",8,w,d); run(k_addc_chain,"v_addc_co_u32 chain",8,w,d); run(k_lshrrev_b64,"v_lshrrev_b64",8,w,d); run(k_mad_snop,"mad_u64 + s_nop 0",4,w,d);
     run(k_lshl_add_u64,"v_lshl_add_u64",8,w,d); run(k_fma_f32,"v_fma_f32",8,w,d); run(k_fma_f64,"v_fma_f64",8,w,d);
     run(k_xor_sdwa,"v_xor_b32_sdwa (word)",8,w,d); run(k_perm_b32,"v_perm_b32",8,w,d); run(k_mad_i64_i32,"v_mad_i64_i32",8,w,d); run(k_ashrrev_i64,"v_ashrrev_i64",8,w,d);
+    run(k_dpp_ror,"v_mov_b32_dpp row_ror",8,w,d); run(k_bpermute,"ds_bpermute_b32",8,w,d);
   }
   return 0;
 }
