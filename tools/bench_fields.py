@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""tools/bench_fields.py [log_len] -- Ligero and Brakedown commits of 2^log_len coefficients (default 24) in each of the four
+test fields (the reference benches Ft127 and Ft255: lcpc-ligero-pc/src/bench.rs, lcpc-brakedown-pc/src/bench.rs)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
+import torch
+
+import bench_configs as B
+from lcpc_amd import LcCommit, LigeroEncoding, SdigEncoding
+
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+n = 1 << lg
+for kind in ("ligero", "sdig"):
+    for fid, name, L in ((0, "ft63", 1), (1, "ft127", 2), (2, "ft191", 3), (3, "ft255", 4)):
+        enc = LigeroEncoding.new(fid, n) if kind == "ligero" else SdigEncoding.new(fid, n, 0)
+        coeffs = B.rand_coeffs(n, L, 7 + fid)
+        st = torch.cuda.current_stream().cuda_stream
+        c = LcCommit(enc)
+        for _ in range(3):
+            LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False, into=c)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False, into=c)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        print(json.dumps({"enc": kind, "field": name, "log_len": lg, "dims": [c.n_rows, c.n_per_row, c.n_cols],
+                          "ms_per_commit": round(dt * 1e3, 3), "elems_per_s": n / dt, "GB_per_s_coeffs": round(n * 8 * L / dt / 1e9, 1)}), flush=True)
+        del c, enc, coeffs
