@@ -132,12 +132,22 @@ class HipShardEngine:
         idb = (C.c_uint8 * 128)()
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
-        if rank == 0:
-            self.enc._check(lib.lcpc_comm_unique_id(idb))
+        # every rank draws an id first: that proves its process can load and call RCCL.  ncclCommInitRank is a collective --
+        # a rank that failed before reaching it would leave the others waiting -- so the outcome is agreed on before anyone
+        # enters it (and rank 0's id is the one that is used)
+        rc = lib.lcpc_comm_unique_id(idb)
         if world > 1:
+            ok = torch.tensor([0 if rc else 1], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                from . import LcpcError
+                raise LcpcError(rc if rc else -20, "another rank could not load RCCL")
             box = [bytes(idb)]
             dist.broadcast_object_list(box, src=0, group=group)
             idb = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        elif rc:
+            from . import LcpcError
+            raise LcpcError(rc)
         self.enc._check(lib.lcpc_comm_init(self.enc._h, idb, rank, world))
 
     def commit_native(self, local_coeffs, n_rows_total, want_root=True, borrow=False):
