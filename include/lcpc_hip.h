@@ -175,7 +175,8 @@ void lcpc_transcript_free(lcpc_transcript *);
 int  lcpc_prove(lcpc_commit_t *cm, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
                 uint8_t **proof, uint64_t *proof_len, uint64_t *cols_opened);
 /* LcEvalProof::verify (lib.rs:518-527 -> 832-952) on a bincode proof; `ctx` plays the role of `enc`
- * (it need not hold a commitment).  eval_out: L limbs. */
+ * (it need not hold a commitment).  eval_out: L limbs.  Bytes after the last column are ignored, as by
+ * bincode::deserialize (bincode 1.3's top-level functions allow trailing bytes). */
 int  lcpc_verify(lcpc_ctx *ctx, const uint8_t root[32], const uint64_t *outer_tensor, uint64_t n_outer,
                  const uint64_t *inner_tensor, uint64_t n_inner, const uint8_t *proof, uint64_t proof_len,
                  lcpc_transcript *tr, uint64_t *eval_out);

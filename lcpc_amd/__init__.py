@@ -359,7 +359,10 @@ class LcEvalProof:
         self._own = data if isinstance(data, _OwnedBuffer) else None
         self._bytes = None if self._own else bytes(data)
         self.L, self.cols_opened = L, cols_opened
-        hdr = np.frombuffer(self._own.view if self._own else self._bytes, np.uint64, 2)
+        buf = self._own.view if self._own else self._bytes
+        if len(buf) < 16:         # bincode::deserialize fails on a buffer that ends inside the header (io::UnexpectedEof)
+            raise LcpcError(VERR_MALFORMED, "proof shorter than its header")
+        hdr = np.frombuffer(buf, np.uint64, 2)
         self.n_cols, self._n_per_row = int(hdr[0]), int(hdr[1])
 
     @property

@@ -325,7 +325,7 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
       if (r.bad || dl != 32 || !d) return LCPC_VERR_MALFORMED;     // Output<D> is 32 bytes
     }
   }
-  if (r.pos != proof_len) return LCPC_VERR_MALFORMED;
+  // (bytes after the last column are ignored, as by bincode::deserialize, whose legacy options allow trailing bytes)
   const uint64_t n_col_opens = lcpc_get_n_col_opens(c);                        // lib.rs:845-860
   if (n_col_opens != n_columns || n_col_opens == 0) return LCPC_VERR_NUM_COL_OPENS;
   const uint64_t n_rows = cols[0].size() / L;
