@@ -323,8 +323,10 @@ def main():
             per = [(2.0 * v["FETCH_KB"] + v["WRITE_KB"]) * 1024 / 1e9 for kname, v in pmc["kernels"].items() if kname.startswith("ntt_pass")]
             insts = [v["SQ_INSTS_VALU"] for kname, v in pmc["kernels"].items() if kname.startswith("ntt_pass") and "SQ_INSTS_VALU" in v]
             if insts and ntt_ms > 0:
-                # what actually binds the kernel: vector-ALU instruction issue, one wave instruction per SIMD every 4 cycles
-                # (256 CUs x 4 SIMDs at the 2.4 GHz peak clock; the board sustains ~2.1 GHz at its power limit)
+                # what actually binds the kernel: vector-ALU instruction issue.  Peak = one mad-class (VOP3 / 64-bit)
+                # wave instruction per SIMD every 4 cycles, 256 CUs x 4 SIMDs at the 2.4 GHz peak clock; measured
+                # (profiles/r02_ubench_valu.txt): v_mad_i64_i32 4.7 cycles, plain VOP2 integer ops 2.4; the board
+                # sustains ~2.1 GHz at its power limit while this kernel runs
                 per_s = sum(insts) / len(insts) / (ntt_ms * 1e-3)
                 valu_issue = {"wave_insts_per_launch": round(sum(insts) / len(insts)), "achieved_Ginst_per_s": round(per_s / 1e9, 1),
                               "peak_Ginst_per_s": 614.4, "frac": round(per_s / 614.4e9, 3),
