@@ -165,3 +165,30 @@ def test_brakedown_ft255_2e24(oracle):
         part = host[r0 * npr:min(n, (r0 + 3) * npr)]
         blk[:part.shape[0]] = part
         assert (c.comm(r0, 3) == O.Commit.commit(blk, oenc, n_threads=4).comm()).all()
+
+
+def test_c4_fullsize_row_sharded_emulated(oracle):
+    """BASELINE configs[3] as specified except for the wire: 2^28 Ft255 coefficients (1024 x 262144 -> 524288), rows split
+    over 8 shard contexts (128 rows each, as on 8 GPUs) that here share ONE device; the all-gather of the subtree nodes is
+    emulated by placing each rank's nodes in the gather buffer.  Every rank's root and full `hashes` must equal the
+    unsharded 2^28 commit (which test_ligero_ft255_fullsize[28] pins to the oracle by rows, columns and proof)."""
+    from test_gpu_sharded import run_sharded
+    fid, n = 3, 1 << 28
+    enc = LigeroEncoding.new(fid, n)
+    nr, npr, nc = enc.get_dims(n)
+    assert (nr, npr, nc) == (1024, 262144, 524288)
+    coeffs = device_random_coeffs(fid, n, 9)
+    ref = LcCommit.commit_device(coeffs.data_ptr(), n, enc, torch.cuda.current_stream().cuda_stream, borrow=True)
+    root, hashes = ref.get_root(), ref.hashes().copy()
+    del ref, enc
+    torch.cuda.empty_cache()
+    roots, engines = run_sharded(lambda sh: LigeroEncoding.new_from_dims(fid, npr, nc, shard=sh), 8, coeffs.reshape(nr, npr, 4), nr)
+    assert all(r == root for r in roots)
+    n_rows_seen = 0
+    for g, eng in enumerate(engines):
+        rb, re, cb, ce, nch = eng.layout(nr)
+        # 33 chunks of 32 rows (the leaf message starts with a 32-byte prefix: chunk 0 holds 31 rows) over 8 ranks: 4 or 5 chunks each
+        assert nch == 33 and rb == n_rows_seen and 127 <= re - rb <= 160
+        n_rows_seen = re
+        assert (eng.cm.hashes() == hashes).all(), "rank %d" % g
+    assert n_rows_seen == nr
