@@ -48,32 +48,30 @@ static void keccak_f1600_scalar(uint64_t a[25]) {
 #if defined(__x86_64__)
 // Keccak-f[1600] on AVX-512VL: one 64-bit lane per XMM register (32 registers: the 25 lanes, 5 column parities and two
 // temporaries fit without spilling, which the 16 general-purpose registers of the scalar form cannot offer), 3-input
-// logic (vpternlogq: theta's XOR3, chi's a ^ (~b & c) in one instruction) and native rotates (vprolq).  90 instructions
-// per round, no shuffles: pi is bookkeeping done by the generator (tools/gen_keccak_x25.py -> keccak_x25_gen.h).
-// Measured on the GPU boxes' EPYC 9575F: 173 ns per permutation against 197-217 ns scalar (and 233 ns for a plane-per-ZMM
-// variant whose 21 shuffles per round are slower there); the serial STROBE absorb of prove / verify
-// (lcpc-2d/src/lib.rs:1045-1047) runs at the speed of this permutation.
+// logic (vpternlogq: theta's XOR3, chi's a ^ (~b & c) in one instruction) and native rotates (vprolq).  105-110 instructions
+// per round, no shuffles: pi is bookkeeping done by the generator (tools/gen_keccak_x25.py -> keccak_x25_gen.h), which also
+// allocates the registers and emits the whole permutation as one asm statement (left to the compiler, the intrinsic
+// form is spilled 4-9 times per round).  The serial STROBE absorb of prove / verify (lcpc-2d/src/lib.rs:1045-1047) runs
+// at the speed of this permutation; timings in DESIGN.md section 6a.
 #define LCPC_AVX512VL __attribute__((target("avx512f,avx512vl")))
 #include "keccak_x25_gen.h"
-namespace {
-struct K25 {
-  __m128i s[25];
-};
-LCPC_AVX512VL inline void k25_load(K25& k, const uint64_t a[25]) {
-  for (int i = 0; i < 25; i++) k.s[i] = _mm_cvtsi64_si128((long long)a[i]);
+// which mix: measured per vendor (see the generator); AMD parts take the xor-heavy one
+// (LCPC_KECCAK = portable | tern | xor overrides the choice: tests/test_abi.py runs all three)
+static const char* keccak_override() {
+  static const char* v = getenv("LCPC_KECCAK");
+  return v;
 }
-LCPC_AVX512VL inline void k25_store(uint64_t a[25], const K25& k) {
-  for (int i = 0; i < 25; i++) a[i] = (uint64_t)_mm_cvtsi128_si64(k.s[i]);
+static bool cpu_prefers_xor_mix() {
+  static const bool xor_mix = keccak_override() ? strcmp(keccak_override(), "xor") == 0 : (bool)__builtin_cpu_is("amd");
+  return xor_mix;
 }
-}  // namespace
-LCPC_AVX512VL static void keccak_f1600_avx512(uint64_t a[25]) {
-  K25 k;
-  k25_load(k, a);
-  keccak_x25_rounds(k.s);
-  k25_store(a, k);
+LCPC_AVX512VL static inline void keccak_x25_permute(uint64_t* st) {
+  if (cpu_prefers_xor_mix()) keccak_x25_permute_xor(st); else keccak_x25_permute_tern(st);
 }
+LCPC_AVX512VL static void keccak_f1600_avx512(uint64_t a[25]) { keccak_x25_permute(a); }
 static bool cpu_has_avx512() {
-  static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
+  static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") &&
+                         !(keccak_override() && strcmp(keccak_override(), "portable") == 0);
   return ok;
 }
 void keccak_f1600(uint64_t a[25]) {
@@ -165,25 +163,24 @@ void Transcript::append_message(const uint8_t* label, size_t llen, const uint8_t
 }
 #if defined(__x86_64__)
 // The coefficient absorbs of prove / verify (lib.rs:1045-1047, 1066-1068): n_per_row operations of ~46 bytes each, one
-// permutation every 3.6 of them, strictly serial.  Here the sponge state stays in vector registers for the whole
-// run; the bytes of the current rate block are laid down in a staging buffer (plain stores -- a position is written once
+// permutation every 3.6 of them, strictly serial.  The bytes of the current rate block are laid down in a staging buffer (plain stores -- a position is written once
 // between two permutations, so "store" equals STROBE's XOR) and folded into the state when the block is full.
 namespace {
 struct Sponge25 {             // state lanes + the staging copy of the current rate block
-  K25 k;
+  alignas(64) uint64_t st[25];
   alignas(64) uint8_t blk[256];
   unsigned pos, pb;
 };
 constexpr unsigned STROBE_R = 166;
-LCPC_AVX512VL inline void sp_fold(Sponge25& s) {            // lanes 0..20 cover the rate and the two padding bytes
-  for (int i = 0; i < 21; i++) s.k.s[i] = _mm_xor_si128(s.k.s[i], _mm_loadl_epi64(reinterpret_cast<const __m128i*>(s.blk + 8 * i)));
+inline void sp_fold(Sponge25& s) {                          // lanes 0..20 cover the rate and the two padding bytes
+  for (int i = 0; i < 21; i++) { uint64_t w; memcpy(&w, s.blk + 8 * i, 8); s.st[i] ^= w; }
 }
 LCPC_AVX512VL inline void sp_flush(Sponge25& s) {           // Transcript::run_f
   s.blk[s.pos] ^= (uint8_t)s.pb;
   s.blk[s.pos + 1] ^= 0x04;
   s.blk[STROBE_R + 1] ^= 0x80;
   sp_fold(s);
-  keccak_x25_rounds(s.k.s);
+  keccak_x25_permute(s.st);
   memset(s.blk, 0, 192);
   s.pos = 0;
   s.pb = 0;
@@ -191,6 +188,16 @@ LCPC_AVX512VL inline void sp_flush(Sponge25& s) {           // Transcript::run_f
 LCPC_AVX512VL inline void sp_emit(Sponge25& s, uint8_t b) {
   s.blk[s.pos++] = b;
   if (s.pos == STROBE_R) sp_flush(s);
+}
+LCPC_AVX512VL inline void sp_emit_bulk(Sponge25& s, const uint8_t* p, size_t len) {     // == sp_emit byte by byte
+  while (len) {
+    const size_t room = STROBE_R - s.pos, take = len < room ? len : room;
+    memcpy(s.blk + s.pos, p, take);
+    s.pos += (unsigned)take;
+    p += take;
+    len -= take;
+    if (s.pos == STROBE_R) sp_flush(s);
+  }
 }
 LCPC_AVX512VL inline void sp_begin_op(Sponge25& s, uint8_t flags) {
   const uint8_t h0 = (uint8_t)s.pb;
@@ -202,34 +209,48 @@ LCPC_AVX512VL inline void sp_begin_op(Sponge25& s, uint8_t flags) {
 LCPC_AVX512VL static void append_messages_avx512(uint64_t st[25], uint8_t& pos_io, uint8_t& pb_io, const uint8_t* label, size_t llen,
                                                const uint8_t* msgs, size_t mlen, size_t n) {
   Sponge25 s;
-  k25_load(s.k, st);
+  memcpy(s.st, st, 200);
   memset(s.blk, 0, sizeof s.blk);
   s.pos = pos_io;
   s.pb = pb_io;
   const uint32_t l32 = (uint32_t)mlen;
   const uint8_t le[4] = {(uint8_t)l32, (uint8_t)(l32 >> 8), (uint8_t)(l32 >> 16), (uint8_t)(l32 >> 24)};
-  const size_t total = 2 + llen + 4 + 2 + mlen;
+  const size_t hdr_len = 2 + llen + 4 + 2, total = hdr_len + mlen;
+  uint8_t tmpl[32] = {0};                    // [pos_begin, M|A, label, len_le32, pos_begin', A] with the two positions patched per message
+  if (hdr_len <= 32) {
+    tmpl[1] = 0x10 | 0x02;
+    memcpy(tmpl + 2, label, llen);
+    memcpy(tmpl + 2 + llen, le, 4);
+    tmpl[2 + llen + 5] = 0x02;
+  }
   for (size_t i = 0; i < n; i++) {
     const uint8_t* msg = msgs + i * mlen;
     if (s.pos + total < STROBE_R) {          // the whole operation stays inside the block: no permutation, no pos_begin reset
       uint8_t* w = s.blk + s.pos;
-      w[0] = (uint8_t)s.pb; w[1] = 0x10 | 0x02;                    // begin_op(meta-AD): flags M | A
-      memcpy(w + 2, label, llen);
-      memcpy(w + 2 + llen, le, 4);                                 // meta_ad(len, more = true): no header
-      w[2 + llen + 4] = (uint8_t)(s.pos + 1); w[2 + llen + 5] = 0x02;   // begin_op(AD)
-      memcpy(w + 2 + llen + 6, msg, mlen);
+      if (hdr_len <= 32) {
+        memcpy(w, tmpl, 32);                                       // fixed-size copy of the framing; its zero tail is overwritten below
+      } else {
+        w[1] = 0x10 | 0x02;
+        memcpy(w + 2, label, llen);
+        memcpy(w + 2 + llen, le, 4);
+        w[2 + llen + 5] = 0x02;
+      }
+      w[0] = (uint8_t)s.pb;                                        // begin_op(meta-AD, flags M | A): previous pos_begin
+      w[2 + llen + 4] = (uint8_t)(s.pos + 1);                      // begin_op(AD): pos_begin of the meta-AD operation
+      if (mlen == 32) memcpy(w + hdr_len, msg, 32);                // (the coefficient absorbs of Ft255: inlined moves)
+      else memcpy(w + hdr_len, msg, mlen);
       s.pb = s.pos + 2 + (unsigned)llen + 4 + 1;
       s.pos += (unsigned)total;
       continue;
     }
-    sp_begin_op(s, 0x10 | 0x02);
-    for (size_t j = 0; j < llen; j++) sp_emit(s, label[j]);
-    for (int j = 0; j < 4; j++) sp_emit(s, le[j]);
+    sp_begin_op(s, 0x10 | 0x02);             // the operation crosses the end of the block: one permutation on the way
+    sp_emit_bulk(s, label, llen);
+    sp_emit_bulk(s, le, 4);
     sp_begin_op(s, 0x02);
-    for (size_t j = 0; j < mlen; j++) sp_emit(s, msg[j]);
+    sp_emit_bulk(s, msg, mlen);
   }
   sp_fold(s);                                // what the open block holds goes into the state, as STROBE keeps it
-  k25_store(st, s.k);
+  memcpy(st, s.st, 200);
   pos_io = (uint8_t)s.pos;
   pb_io = (uint8_t)s.pb;
 }

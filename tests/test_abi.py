@@ -170,6 +170,40 @@ def test_batched_absorb_matches_oracle(oracle):
         assert t1.challenge_bytes(b"d", 16) == t2.challenge_bytes(b"d", 16)
 
 
+@pytest.mark.parametrize("mix", ["portable", "tern", "xor"])
+def test_keccak_mixes_match_oracle(mix):
+    """every Keccak-f[1600] implementation in host_crypto.cpp (scalar, and the two generated AVX-512VL instruction mixes of
+    which one is picked per CPU vendor) gives the oracle's transcript: run in a fresh process with LCPC_KECCAK forcing it."""
+    import subprocess
+    import sys
+    code = r"""
+import os, random, sys
+sys.path[:0] = [%r, %r, %r]
+import oracle_lib as O
+import lcpc_amd
+rnd = random.Random(5)
+for trial in range(12):
+    mlen = [8, 32, 24, 77][trial %% 4]
+    n = rnd.randrange(1, 1500)
+    data = bytes(rnd.randrange(256) for _ in range(n * mlen))
+    t1, t2 = lcpc_amd.Transcript(b"mix"), O.Transcript(b"mix")
+    t1.append_message(b"pre", data[:37]); t2.append_message(b"pre", data[:37])
+    t1.append_messages(b"lbl", data, mlen)
+    for i in range(n):
+        t2.append_message(b"lbl", data[i * mlen:(i + 1) * mlen])
+    assert t1.challenge_bytes(b"c", 64) == t2.challenge_bytes(b"c", 64), trial
+    for i in range(40):                      # the one-message path (keccak_f1600 through run_f)
+        t1.append_message(b"x", data[i:i + 50]); t2.append_message(b"x", data[i:i + 50])
+    assert t1.challenge_bytes(b"d", 32) == t2.challenge_bytes(b"d", 32)
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"))
+    env = dict(os.environ, LCPC_KECCAK=mix)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    if mix != "portable" and "Illegal instruction" in (r.stderr or "") + str(r.returncode):
+        pytest.skip("no AVX-512VL on this CPU")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
 def test_shard_node_layout_matches_python():
     """lcpc_shard_nodes (C) == lcpc_amd.distributed.aligned_nodes (Python): both sides of the exchange must agree."""
     import ctypes as C
