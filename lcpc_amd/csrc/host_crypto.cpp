@@ -68,6 +68,9 @@ static bool cpu_prefers_xor_mix() {
 LCPC_AVX512VL static inline void keccak_x25_permute(uint64_t* st) {
   if (cpu_prefers_xor_mix()) keccak_x25_permute_xor(st); else keccak_x25_permute_tern(st);
 }
+LCPC_AVX512VL static inline void keccak_x25_absorb(uint64_t* st, uint8_t* blk) {      // st ^= blk; permute; blk = 0
+  if (cpu_prefers_xor_mix()) keccak_x25_absorb_xor(st, blk); else keccak_x25_absorb_tern(st, blk);
+}
 LCPC_AVX512VL static void keccak_f1600_avx512(uint64_t a[25]) { keccak_x25_permute(a); }
 static bool cpu_has_avx512() {
   static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") &&
@@ -179,9 +182,7 @@ LCPC_AVX512VL inline void sp_flush(Sponge25& s) {           // Transcript::run_f
   s.blk[s.pos] ^= (uint8_t)s.pb;
   s.blk[s.pos + 1] ^= 0x04;
   s.blk[STROBE_R + 1] ^= 0x80;
-  sp_fold(s);
-  keccak_x25_permute(s.st);
-  memset(s.blk, 0, 192);
+  keccak_x25_absorb(s.st, s.blk);            // folds lanes 0..20 of the block into the state on the way in, zeroes the block
   s.pos = 0;
   s.pb = 0;
 }
