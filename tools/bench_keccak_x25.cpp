@@ -38,7 +38,8 @@ int main() {
     struct V { const char* name; Fn fn; } vs[] = {{"theta via D (xor)", keccak_v_theta_d}, {"theta via D + parity all xor", keccak_v_theta_d_parx},
                                                   {"theta via D + chi andn/xor in 2 rows", keccak_v_theta_d_chi2}, {"no vpternlogq at all", keccak_v_all_xor},
                                                   {"theta via D in 3 columns", keccak_v_d3}, {"theta via D in 4 columns", keccak_v_d4}, {"chi without copies", keccak_v_fresh},
-                                                  {"theta via D + chi without copies", keccak_v_d_fresh}, {"theta via D in 3 columns + chi without copies", keccak_v_d3_fresh}};
+                                                  {"theta via D + chi without copies", keccak_v_d_fresh}, {"theta via D in 3 columns + chi without copies", keccak_v_d3_fresh},
+                                                  {"xor mix, every 2nd rho rotate as vpshldq", keccak_v_shld2}, {"xor mix, every 3rd rho rotate as vpshldq", keccak_v_shld3}, {"xor mix, all rho rotates as vpshldq", keccak_v_shld1}};
     for (auto& v : vs) {
       uint64_t c[25], d[25];
       for (int i = 0; i < 25; i++) c[i] = d[i] = i * 0x9e3779b97f4a7c15ull + (i << 7);
