@@ -280,6 +280,56 @@ def test_concurrent_contexts_and_streams(oracle):
     assert not errs, errs
 
 
+def test_concurrent_prove_and_verify_one_encoder(oracle):
+    """one encoder shared by several host threads (the reference shares &E across Rayon workers, lib.rs:74-104): three
+    commitments under it prove at the same time (each LcCommit has its own lock and buffers; the proof-buffer pool and the
+    host worker pool are shared), then every proof is verified from three threads at once on that same context (verifies on
+    one context are serialised internally).  Proof bytes must equal the oracle's, verdicts must all be accepts."""
+    import threading
+    from common import mk_transcript, powers
+    from lcpc_amd import Transcript
+    O, fid, n = oracle, 3, 1 << 14
+    enc, oenc = LigeroEncoding.new(fid, n), O.Encoding.ligero(fid, n)
+    nco = enc.get_n_col_opens()
+    import pyref as P
+    jobs = []
+    for i in range(3):
+        coeffs = O.random_elems(fid, n, 300 + i)
+        c = LcCommit.commit(coeffs, enc)
+        x = (0xabcdef + i) % P.FIELDS[fid].p
+        inner, outer = powers(O, fid, x, c.n_per_row), powers(O, fid, x, c.n_rows, c.n_per_row)
+        oc = O.Commit.commit(coeffs, oenc, n_threads=2)
+        want, _ = oc.prove(outer, oenc, mk_transcript(O.Transcript, oc.get_root(), nco))
+        jobs.append({"c": c, "root": c.get_root(), "inner": inner, "outer": outer, "want": want, "pf": []})
+    errs = []
+
+    def prove(j):
+        try:
+            for _ in range(6):
+                pf = j["c"].prove(j["outer"], enc, mk_transcript(Transcript, j["root"], nco))
+                if pf.to_bytes() != j["want"]:
+                    errs.append("proof bytes differ")
+                j["pf"].append(pf)
+                del j["pf"][:-2]                     # older proofs are freed while other threads allocate theirs
+        except Exception as e:
+            errs.append(repr(e))
+
+    def verify(j):
+        try:
+            for _ in range(6):
+                j["pf"][-1].verify(j["root"], j["outer"], j["inner"], enc, mk_transcript(Transcript, j["root"], nco))
+        except Exception as e:
+            errs.append(repr(e))
+
+    for fn in (prove, verify):
+        th = [threading.Thread(target=fn, args=(j,)) for j in jobs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(300)
+        assert not errs, errs
+
+
 @pytest.mark.parametrize("switch", ["LCPC_NTT_PACKED", "LCPC_COMM_MONT"])
 def test_ab_switch_paths_stay_correct(oracle, switch):
     """the A/B switches select alternative kernels (packed-limb NTT; Montgomery-form comm with the
