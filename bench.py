@@ -185,6 +185,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the lcpc HIP path has no CPU fallback")
     if args.force_device is not None:
         local_rank = args.force_device
+    elif args.dist_backend != "nccl":              # debug runs: more ranks than GPUs share the devices
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
