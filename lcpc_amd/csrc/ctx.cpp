@@ -175,14 +175,14 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
   for (size_t i = 0; i + 1 < t; i++) {
     const uint64_t in_end = in_start + c->d_pre[i].n_in;
     a.out_alt = nullptr; a.in_off = in_start; a.out_off = in_end;
-    a.rowptr = c->d_pre[i].rowptr; a.colidx = c->d_pre[i].colidx; a.vals = c->d_pre[i].vals; a.m = c->d_pre[i].n_out;
+    a.rowptr = c->d_pre[i].rowptr; a.colidx = c->d_pre[i].colidx; a.vals = c->d_pre[i].vals; a.vals29 = c->d_pre[i].vals29; a.m = c->d_pre[i].n_out;
     ECHK(launch_spmv(c->NL, a, st));
     nl++;
     in_start = in_end;
   }
   const uint64_t in_end = in_start + pl.n_in;
   a.out_alt = ws->d_tmp; a.out_alt_stride = pl.n_out; a.in_off = in_start; a.out_off = 0;
-  a.rowptr = pl.rowptr; a.colidx = pl.colidx; a.vals = pl.vals; a.m = pl.n_out;
+  a.rowptr = pl.rowptr; a.colidx = pl.colidx; a.vals = pl.vals; a.vals29 = pl.vals29; a.m = pl.n_out;
   ECHK(launch_spmv(c->NL, a, st));
   const uint64_t out_end = in_end + c->d_post[t - 1].n_in;
   ECHK(launch_sdig_rs(c->NL, ws->d_tmp, pl.n_out, (uint32_t)pl.n_out, j.dst, c->n_cols, in_end,
@@ -193,7 +193,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
   for (size_t ii = t; ii-- > 0;) {
     in_start -= c->d_pre[ii].n_out;
     a.out_alt = nullptr; a.in_off = in_start; a.out_off = out_start;
-    a.rowptr = c->d_post[ii].rowptr; a.colidx = c->d_post[ii].colidx; a.vals = c->d_post[ii].vals; a.m = c->d_post[ii].n_out;
+    a.rowptr = c->d_post[ii].rowptr; a.colidx = c->d_post[ii].colidx; a.vals = c->d_post[ii].vals; a.vals29 = c->d_post[ii].vals29; a.m = c->d_post[ii].n_out;
     ECHK(launch_spmv(c->NL, a, st));
     nl++;
     out_start += c->d_post[ii].n_out;

@@ -97,6 +97,7 @@ struct SpmvArgs {
   const uint32_t* rowptr;       // [m+1]
   const uint32_t* colidx;       // [nnz]
   const uint32_t* vals;         // [nnz][NL]
+  const uint32_t* vals29;       // Ft255: [nnz][12], the 29-bit-limb / 2^261 form (may be null)
   uint64_t m, n_rows;
 };
 hipError_t launch_spmv(int nl, const SpmvArgs& a, hipStream_t st);

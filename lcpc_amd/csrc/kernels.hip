@@ -940,39 +940,70 @@ hipError_t launch_gather_paths(const u32* hashes, u64 np2, u32 path_len, const u
 // rows of the commitment in one launch: lane = output index o (consecutive lanes write consecutive
 // codeword positions), blockIdx.y = matrix row of the commitment.  Products accumulate unreduced.
 // =================================================================================================
-template <int NL>
+// SL lanes per output: lane s of the group takes terms k0 + s, k0 + s + SL, ..; the partial sums (exact field elements) are
+// added across the group with lane shuffles.  A launch of this path has a few rows only (the verifier's 1 + n_degree_tests
+// single-row encodes, commitments of < 16 rows) and is bound by the latency of an output's ~45 dependent index -> gather ->
+// multiply steps, not by throughput: eight lanes per output cut that chain to ~6 steps.
+template <int NL, int SL>
 __global__ void __launch_bounds__(256) spmv_kernel(SpmvArgs a) {
-  const u64 o = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (o >= a.m) return;
+  const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 o = gid / SL;
+  const u32 sl = (u32)(gid % SL);
+  const bool live = o < a.m;                         // whole groups are live or dead together (256 % SL == 0)
+  const u64 oo = live ? o : 0;
   const u64 row = blockIdx.y;
   const u32* x = a.mat + (row * a.stride + a.in_off) * NL;
-  const u32 k0 = a.rowptr[o], k1 = a.rowptr[o + 1];
-  constexpr u32 BATCH = 8;
+  const u32 k0 = a.rowptr[oo], k1 = a.rowptr[oo + 1];
   Fe<NL> acc = fe_zero<NL>();
-  for (u32 kb = k0; kb < k1; kb += BATCH) {
-    Wide<NL> w = wide_zero<NL>();
-    const u32 ke = kb + BATCH < k1 ? kb + BATCH : k1;
-    for (u32 k = kb; k < ke; k++) {
-      const Fe<NL> v = fe_load<NL>(a.vals + (u64)k * NL);
-      const Fe<NL> xv = fe_load<NL>(x + (u64)a.colidx[k] * NL);
-      wide_mac<NL>(w, v, xv);
+  bool lazy = false;
+  if constexpr (NL == 8) {
+    lazy = a.vals29 != nullptr && k1 - k0 <= 60 * SL;  // lazy29_reduce takes <= 60 terms: a lane sees ceil((k1 - k0) / SL)
+    if (lazy) {
+      // the carry-free 29-bit-limb dot product of the position-major kernels
+      Lazy29 l;
+      lazy29_zero(l);
+      u32 since = 0;
+      for (u32 k = k0 + sl; k < k1; k += SL) {
+        Fe29 v;
+#pragma unroll
+        for (int i = 0; i < 9; i++) v.v[i] = a.vals29[(size_t)k * 12 + i];
+        lazy29_mac(l, fe_to29(fe_load<NL>(x + (u64)a.colidx[k] * NL)), v);
+        if (++since == 6) { lazy29_normalize(l); since = 0; }
+      }
+      acc = lazy29_reduce(l);
     }
-    acc = fe_add<NL>(acc, wide_reduce<NL>(w));
   }
-  u32* dst = a.out_alt ? a.out_alt + (row * a.out_alt_stride + o) * NL : a.mat + (row * a.stride + a.out_off + o) * NL;
-  fe_store<NL>(dst, acc);
+  if (!lazy) {
+    constexpr u32 BATCH = 8;
+    for (u32 kb = k0 + sl; kb < k1; kb += BATCH * SL) {
+      Wide<NL> w = wide_zero<NL>();
+#pragma unroll 2
+      for (u32 i = 0; i < BATCH; i++) {
+        const u32 k = kb + i * SL;
+        if (k >= k1) break;
+        wide_mac<NL>(w, fe_load<NL>(a.vals + (u64)k * NL), fe_load<NL>(x + (u64)a.colidx[k] * NL));
+      }
+      acc = fe_add<NL>(acc, wide_reduce<NL>(w));
+    }
+  }
+#pragma unroll
+  for (int off = SL / 2; off > 0; off >>= 1) {
+    Fe<NL> other;
+#pragma unroll
+    for (int i = 0; i < NL; i++) other.v[i] = (u32)__shfl_xor((int)acc.v[i], off, 64);
+    acc = fe_add<NL>(acc, other);
+  }
+  if (live && sl == 0) {
+    u32* dst = a.out_alt ? a.out_alt + (row * a.out_alt_stride + o) * NL : a.mat + (row * a.stride + a.out_off + o) * NL;
+    fe_store<NL>(dst, acc);
+  }
 }
 hipError_t launch_spmv(int nl, const SpmvArgs& a, hipStream_t st) {
   if (a.m == 0 || a.n_rows == 0) return hipSuccess;
   if (a.n_rows > 65535) return hipErrorInvalidValue;        // (the host takes the position-major path from 16 rows on)
-  dim3 grid((unsigned)((a.m + 255) / 256), (unsigned)a.n_rows);
-  switch (nl) {
-    case 2: hipLaunchKernelGGL(spmv_kernel<2>, grid, dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(spmv_kernel<4>, grid, dim3(256), 0, st, a); break;
-    case 6: hipLaunchKernelGGL(spmv_kernel<6>, grid, dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(spmv_kernel<8>, grid, dim3(256), 0, st, a); break;
-    default: return hipErrorInvalidValue;
-  }
+  constexpr int SL = 8;
+  dim3 grid((unsigned)((a.m * SL + 255) / 256), (unsigned)a.n_rows);
+  LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmv_kernel<NLV, SL>), grid, dim3(256), 0, st, a));
   return hipGetLastError();
 }
 

@@ -1,0 +1,14 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
+import torch
+import bench_configs as B
+from lcpc_amd import LcCommit, SdigEncoding
+lgl = int(sys.argv[1]) if len(sys.argv) > 1 else 13
+n = 1 << lgl
+enc = SdigEncoding.new(3, n, 0)
+coeffs = B.rand_coeffs(n, 4, 1)
+st = torch.cuda.current_stream().cuda_stream
+c = LcCommit(enc)
+for _ in range(5):
+    LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=True, into=c)
