@@ -1167,6 +1167,7 @@ __device__ __forceinline__ Fe<NL> spmm_t_terms(const SpmmTArgs& a, const u32* xi
 template <int NL, int SPMM_OPW>
 __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a) {
   const u64 row = (u64)blockIdx.y * 128 + threadIdx.x;
+  if ((row & ~(u64)63) >= a.n_rows) return;          // a wave with no row at all (<= 64 rows: the workgroup's second wave)
   const bool live = row < a.n_rows;
   const u64 rr = live ? row : 0;                     // dead lanes recompute row 0 and do not store
   const u32* xin = a.t + (a.in_off * a.n_rows + rr) * NL;
@@ -1202,7 +1203,8 @@ __global__ void __launch_bounds__(128 * SL) spmm_t_sliced_kernel(SpmmTArgs a) {
   const u32 k1 = __builtin_amdgcn_readfirstlane(a.rowptr[o + 1]);
   const u32 len = k1 - k0;
   const u32 ks = k0 + (u32)(((u64)len * sl) / SL), ke = k0 + (u32)(((u64)len * (sl + 1)) / SL);
-  Fe<NL> res = spmm_t_terms<NL>(a, xin, pstride, ks, ke);
+  const bool wave_live = (row & ~(u64)63) < a.n_rows;  // (a wave with no row at all still has to reach the barrier)
+  Fe<NL> res = wave_live ? spmm_t_terms<NL>(a, xin, pstride, ks, ke) : fe_zero<NL>();
   if (sl) {
 #pragma unroll
     for (int i = 0; i < NL; i++) part[((sl - 1) * NL + i) * 128 + lane] = res.v[i];
