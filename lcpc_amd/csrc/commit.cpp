@@ -29,7 +29,7 @@ int ensure_commit_buffers(lcpc_commit_t* m, uint64_t n_rows_local, bool own_coef
     if ((rc = dev_alloc(&m->err, &m->d_coeffs, (size_t)rows * c->n_per_row * eb))) return rc;
     m->cap_coeff_rows = rows;
   }
-  const bool need_comm = !(c->prm.encoding == LCPC_ENC_SDIG && n_rows_local >= 16);   // else made on demand (lcpc_get_comm)
+  const bool need_comm = !(c->prm.encoding == LCPC_ENC_SDIG && n_rows_local >= sdig_t_min_rows());   // else made on demand (lcpc_get_comm)
   if (need_comm && (rows > m->cap_comm_rows || !m->d_comm)) {
     dev_free(m->d_comm); m->d_comm = nullptr; m->cap_comm_rows = 0;
     if ((rc = dev_alloc(&m->err, &m->d_comm, (size_t)rows * c->n_cols * eb))) return rc;
@@ -124,8 +124,8 @@ static int encode_commit(lcpc_commit_t* m, const uint32_t* src, uint64_t n_src_t
 }
 
 // can the first encode pass write the coeffs copy on the fly?  (Ligero: fused into the first NTT pass; Brakedown with
-// >= 16 rows: fused into the input transpose)
-static bool fused_copy(const lcpc_ctx* c, uint64_t n_rows_local) { return c->prm.encoding == LCPC_ENC_LIGERO || n_rows_local >= 16; }
+// >= sdig_t_min_rows() rows: fused into the input transpose)
+static bool fused_copy(const lcpc_ctx* c, uint64_t n_rows_local) { return c->prm.encoding == LCPC_ENC_LIGERO || n_rows_local >= sdig_t_min_rows(); }
 
 static int commit_tail(lcpc_commit_t* m, hipStream_t st, uint8_t* root) {
   if (m->timing) HIPCHK(m, hipEventRecord(m->ev[1], st));
@@ -329,7 +329,7 @@ int lcpc_commit_device(lcpc_commit_t* m, const uint64_t* coeffs_dev, uint64_t n_
     m->coeffs_view = src;
   } else if (fused_copy(c, n_rows)) {
     // the padded local copy of coeffs (lib.rs:636-645; LcCommit keeps it for prove) is written by the first
-    // NTT pass (Ligero) / the input transpose (Brakedown, >= 16 rows) while it streams the caller's buffer
+    // NTT pass (Ligero) / the input transpose (Brakedown, position-major path) while it streams the caller's buffer
     if ((rc = encode_commit(m, src, n_coeffs, true, st))) return rc;
     m->coeffs_view = m->d_coeffs;
   } else {
@@ -415,7 +415,7 @@ int lcpc_commit_from_parts(lcpc_commit_t* m, const uint64_t* comm, const uint64_
   const size_t eb = elem_bytes(c);
   int rc = ensure_commit_buffers(m, n_rows, true);
   if (rc) return rc;
-  if (!m->d_comm || m->cap_comm_rows < n_rows) {           // (Brakedown >= 16 rows: ensure_commit_buffers leaves comm for later)
+  if (!m->d_comm || m->cap_comm_rows < n_rows) {           // (Brakedown, position-major path: ensure_commit_buffers leaves comm for later)
     dev_free(m->d_comm); m->d_comm = nullptr; m->cap_comm_rows = 0;
     if ((rc = dev_alloc(&m->err, &m->d_comm, (size_t)n_rows * c->n_cols * eb))) return rc;
     m->cap_comm_rows = n_rows;

@@ -12,6 +12,12 @@ using namespace lcpc;
 
 namespace lcpc {
 
+uint64_t sdig_t_min_rows() {
+  static const uint64_t v = getenv("LCPC_SDIG_T_MIN_ROWS") ? strtoull(getenv("LCPC_SDIG_T_MIN_ROWS"), nullptr, 10) : 24;
+  return v;
+}
+
+
 const uint8_t LBL_DT[7] = "$l//DT", LBL_PR[7] = "$l//PR", LBL_PE[7] = "$l//PE", LBL_CO[7] = "$l//CO";  // macros.rs:31-34
 
 void ctx_ref(lcpc_ctx* c) { c->refs.fetch_add(1); }
@@ -117,7 +123,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
     if (rc) { ws->tmp_cap = 0; return rc; }
     ws->tmp_cap = cap_b / eb;
   }
-  if (n_rows >= 16) {
+  if (n_rows >= sdig_t_min_rows()) {
     // fast path: position-major working copy T[pos][row] (lane = row: contiguous gathers, wave-uniform matrix)
     {
       uint64_t cap_b = ws->t_cap * eb;

@@ -44,6 +44,10 @@ struct EncodeWs {
   uint64_t t_cap = 0;
 };
 
+// Brakedown: from this many rows on the rows are encoded on a position-major copy (lane = row); below, row-major with
+// lanes over outputs and terms.  LCPC_SDIG_T_MIN_ROWS overrides (A/B only).
+uint64_t sdig_t_min_rows();
+
 // proof buffers (prove.cpp): lcpc_free hands them back; one is kept for the next proof
 void* proof_buf_alloc(size_t n);
 void proof_buf_free(void* p);
@@ -105,7 +109,7 @@ struct lcpc_commit_s {
                                            // when the commit was made with LCPC_COMMIT_BORROW_COEFFS
   uint64_t cap_coeff_rows = 0, cap_comm_rows = 0, cap_cvs = 0;
   lcpc::EncodeWs ws;
-  bool comm_t = false;             // Brakedown commit with >= 16 local rows: the commitment matrix lives in ws.d_t (position-major,
+  bool comm_t = false;             // Brakedown commit with >= sdig_t_min_rows() local rows: the commitment matrix lives in ws.d_t (position-major,
                                    // element (row, col) at (col * n_rows_local + row)); hash / open read it there, d_comm is only
                                    // filled on demand (lcpc_get_comm) -- no back-transpose on the commit path
   bool comm_rows_valid = false;    // d_comm holds the row-major copy of the commitment in ws.d_t

@@ -2,7 +2,7 @@
 //
 //   K1  ntt_pass_kernel / ntt_pass_l9_kernel (Ft255), roots_kernel
 //                               LcEncoding::encode for Ligero = fffft fft_io_pc, precomp_fft (ligero lib.rs:140, 162-164)
-//   K2  transpose_to/from_t, spmm_t, sdig_rs_t (>= 16 rows); spmv, sdig_rs (few rows)
+//   K2  transpose_to/from_t, spmm_t, sdig_rs_t (>= 24 rows); spmv, sdig_rs (fewer rows)
 //                               LcEncoding::encode for Brakedown                   (brakedown encode.rs:36-110)
 //   K3  leaf_chunk / leaf_finish hash_columns (+ subtree pre-merge for sharding)    (lcpc-2d lib.rs:706-745)
 //   K4  merkle_subtree           merkle_tree / merkle_layer                         (lib.rs:747-785)
@@ -942,7 +942,7 @@ hipError_t launch_gather_paths(const u32* hashes, u64 np2, u32 path_len, const u
 // =================================================================================================
 // SL lanes per output: lane s of the group takes terms k0 + s, k0 + s + SL, ..; the partial sums (exact field elements) are
 // added across the group with lane shuffles.  A launch of this path has a few rows only (the verifier's 1 + n_degree_tests
-// single-row encodes, commitments of < 16 rows) and is bound by the latency of an output's ~45 dependent index -> gather ->
+// single-row encodes, commitments of < 24 rows) and is bound by the latency of an output's ~45 dependent index -> gather ->
 // multiply steps, not by throughput: eight lanes per output cut that chain to ~6 steps.
 template <int NL, int SL>
 __global__ void __launch_bounds__(256) spmv_kernel(SpmvArgs a) {
@@ -1000,7 +1000,7 @@ __global__ void __launch_bounds__(256) spmv_kernel(SpmvArgs a) {
 }
 hipError_t launch_spmv(int nl, const SpmvArgs& a, hipStream_t st) {
   if (a.m == 0 || a.n_rows == 0) return hipSuccess;
-  if (a.n_rows > 65535) return hipErrorInvalidValue;        // (the host takes the position-major path from 16 rows on)
+  if (a.n_rows > 65535) return hipErrorInvalidValue;        // (the host takes the position-major path from 24 rows on)
   constexpr int SL = 8;
   dim3 grid((unsigned)((a.m * SL + 255) / 256), (unsigned)a.n_rows);
   LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmv_kernel<NLV, SL>), grid, dim3(256), 0, st, a));

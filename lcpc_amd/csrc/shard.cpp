@@ -195,7 +195,7 @@ static int commit_shard_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, ui
   m->n_rows = n_rows_total; m->row_begin = rb; m->n_rows_local = re - rb;
   m->chunk_begin = cb; m->chunk_end = ce; m->n_chunks = nch;
   m->launches[0] = m->launches[1] = m->launches[2] = 0;
-  const bool fused = c->prm.encoding == LCPC_ENC_LIGERO || m->n_rows_local >= 16;
+  const bool fused = c->prm.encoding == LCPC_ENC_LIGERO || m->n_rows_local >= sdig_t_min_rows();
   const bool borrow = (flags & LCPC_COMMIT_BORROW_COEFFS) != 0 && m->n_rows_local > 0;   // local rows are always whole rows
   int rc = ensure_commit_buffers(m, m->n_rows_local, !borrow);
   if (rc) return rc;

@@ -368,11 +368,14 @@ def test_commit_device_ragged(oracle, kind, fid, n, rho):
 
 
 @pytest.mark.parametrize("fid,n_per_row,n_rows,seed,code", [(3, 300, 40, 1, 3), (3, 257, 130, 2, 3), (0, 500, 17, 3, 5),
-                                                            (1, 400, 33, 4, 1), (2, 350, 129, 5, 6), (3, 2000, 70, 6, 2)])
+                                                            (1, 400, 33, 4, 1), (2, 350, 129, 5, 6), (3, 2000, 70, 6, 2),
+                                                            (3, 900, 23, 7, 3), (3, 900, 24, 8, 3), (0, 500, 25, 9, 5), (3, 1200, 64, 10, 3),
+                                                            (3, 1200, 65, 11, 3)])
 def test_brakedown_many_rows_vs_oracle(oracle, fid, n_per_row, n_rows, seed, code):
-    """>= 16 rows selects the position-major SpMM path (lane = row, wave-uniform matrix entries, R29 lazy dot
-    products for Ft255 / wide accumulators otherwise): every field, row counts that are not multiples of the
-    128-lane row block or of the 32x32 transpose tile, a ragged last row."""
+    """>= 24 rows selects the position-major SpMM path (lane = row, wave-uniform matrix entries, R29 lazy dot
+    products for Ft255 / wide accumulators otherwise), fewer the row-major path with lanes over outputs and terms: every
+    field, both sides of that threshold, row counts that are not multiples of the 128-lane row block, of its 64-lane waves
+    (row-less waves leave early) or of the 32x32 transpose tile, a ragged last row."""
     O = oracle
     oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, seed, code)
     _, _, n_cols = oenc.get_dims(n_per_row)
