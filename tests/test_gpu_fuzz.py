@@ -55,7 +55,7 @@ def test_fuzz_brakedown(oracle, seed):
         fid = rnd.choice([0, 1, 3, 3])
         code = rnd.randrange(1, 7)
         n_per_row = rnd.randrange(60, 3000)
-        n_rows = rnd.choice([1, 2, 7, 15, 16, 17, 40, 90])
+        n_rows = rnd.choice([1, 2, 7, 15, 16, 17, 23, 24, 25, 40, 64, 65, 90, 130])
         n = n_rows * n_per_row - rnd.randrange(0, n_per_row)
         mseed = rnd.randrange(1 << 40)
         oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, mseed, code)
