@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""tools/trace_small_sdig.py [log_len] -- five Brakedown commits of 2^log_len Ft255 coefficients (default 13: 3 rows), to be run
+under `rocprofv3 --kernel-trace` and read with tools/rocpd_dispatches.py: which launches a small commitment consists of."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
