@@ -16,5 +16,5 @@ for r in rows:
     gap = (d["start"] - prev_end) / 1e3 if prev_end is not None else 0.0
     prev_end = d["end"]
     if sub in d["name"]:
-        nm = d["name"].split("(")[0].replace("void ", "").replace("lcpc::", "").replace("(anonymous namespace)::", "")[:48]
+        nm = d["name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("lcpc::", "")[:48]
         print("%-48s %9.1f us  (gap %7.1f)  grid %s x %s" % (nm, (d["end"] - d["start"]) / 1e3, gap, d.get("grid_x", d.get("grid_size_x")), d.get("grid_y", d.get("grid_size_y"))))
