@@ -127,29 +127,39 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
   std::thread filler;
   JoinGuard join{filler};
   bool have_eval = false;
+  int eval_rc = 0;                                                            // of the p_eval collapse when it runs on the helper thread
   for (uint64_t i = 0; i < n_deg; i++) {                                      // lib.rs:1024-1050
     uint8_t key[32];
     tr.challenge_bytes(LBL_DT, 6, key, 32);
     ChaCha20Rng rng(key);
     for (uint64_t r = 0; r < nr; r++) rng.field_random(f, &tensors[r * L]);
+    // The eval tensor is independent of the transcript.  Sharded: it is fused into the first pass over coeffs (one
+    // exchange for both polynomials).  Unsharded: the transcript only waits for p_random; the helper thread collapses
+    // p_eval while this one absorbs p_random (a second pass over coeffs on an otherwise idle GPU: -0.3 ms on the wait).
     uint32_t nt = 1;
-    if (i == 0) {   // the eval tensor is independent of the transcript: fuse it into the first pass over coeffs
+    static const bool fused_only = getenv("LCPC_PROVE_EVAL_FUSED") != nullptr;   // A/B: p_eval fused into the first pass as when sharded
+    const bool eval_here = i == 0, eval_beside = eval_here && xchg == nullptr && !fused_only;
+    if (eval_here) {
       memcpy(&tensors[nr * L], outer, nr * L * 8);
-      nt = 2;
+      if (!eval_beside) nt = 2;
     }
     double t0 = now_ms();
     if (filler.joinable()) filler.join();                                     // the arena is about to be overwritten
+    if (eval_rc) return eval_rc;
     int rc = collapse(tensors, nt, polys, canon);
     if (rc) return rc;
     t_collapse += now_ms() - t0;
-    if (nt == 2) {
-      have_eval = true;
-      if (n_deg > 1) { p_eval_canon.assign(canon + np * L, canon + 2 * np * L); }
-    }
+    if (eval_here) have_eval = true;
+    if (nt == 2 && n_deg > 1) p_eval_canon.assign(canon + np * L, canon + 2 * np * L);
     // the helper copies this round's polynomial(s) into the proof (and thereby faults the fresh pages in) meanwhile
-    filler = std::thread([=, &out] {
+    filler = std::thread([=, &out, &eval_rc, &p_eval_canon, &collapse] {
+      if (eval_beside) {
+        eval_rc = collapse(tensors + nr * L, 1, polys + np * L, canon + np * L);
+        if (eval_rc) return;
+        if (n_deg > 1) p_eval_canon.assign(canon + np * L, canon + 2 * np * L);
+      }
       memcpy(out.p + off_rand0 + i * (8 + pbytes), polys, pbytes);
-      if (nt == 2) memcpy(out.p + off_eval, polys + np * L, pbytes);
+      if (eval_here) memcpy(out.p + off_eval, polys + np * L, pbytes);
       if (i + 1 == n_deg) memset(out.p + head, 0, total - head);              // touch the column area before the copies land in it
     });
     t0 = now_ms();
@@ -164,6 +174,8 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
     memcpy(out.p + off_eval, polys, pbytes);
     absorb_canon(tr, LBL_PE, f, canon, np);
   } else {
+    if (n_deg == 1 && filler.joinable()) filler.join();                      // p_eval may still be on its way (eval_beside)
+    if (eval_rc) return eval_rc;
     absorb_canon(tr, LBL_PE, f, n_deg > 1 ? p_eval_canon.data() : canon + np * L, np);   // lib.rs:1066-1068
   }
   tp[2] = now_ms();

@@ -14,7 +14,7 @@ c = LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=True, borrow=True
 x = 0x123456789abcdef % P.FT255.p
 inner = powers(O, 3, x, c.n_per_row); outer = powers(O, 3, x, c.n_rows, c.n_per_row)
 root = c.get_root(); nco = enc.get_n_col_opens()
-for rep in range(4):
+for rep in range(int(os.environ.get("PV_REPS", "4"))):
     LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=True, borrow=True, into=c)
     t0 = time.perf_counter(); pf = c.prove(outer, enc, mk_transcript(Transcript, root, nco)); tp = time.perf_counter() - t0
     t0 = time.perf_counter(); pf.verify(root, outer, inner, enc, mk_transcript(Transcript, root, nco)); tv = time.perf_counter() - t0
