@@ -2,8 +2,8 @@
 """bench.py -- headline benchmark: field-elements committed per second, Ligero commit of 2^26 Ft255
 coefficients (rho = 1/2, BLAKE3), BASELINE.json's metric, on N MI355X of one node.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py [--gpus N] [--steps K] [--warmup W]      (N > 1 without WORLD_SIZE: bench.py starts its own N ranks)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1, what the driver does)
 
 A "step" is one full commit (pad -> row NTTs -> column BLAKE3 -> Merkle tree, lcpc-2d/src/lib.rs:622-671) of
 one synthetic coefficient vector that is already resident in HBM when the timed region starts.  For N > 1 the
@@ -141,6 +141,34 @@ def cpu_commit(O, np, log_len, n_per_row, n_cols, threads, seed=1):
     return n / dt, dt, root, coeffs
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started without a launcher: become the launcher.  One rank per GPU under
+    torch.distributed.run on 127.0.0.1, the same command line; rank 0's JSON line goes to this process's stdout.  Fewer
+    than N visible devices is an error (never a silent 1-GPU run), unless the debug switches that let ranks share a
+    device (--dist-backend gloo / --force-device) are given."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    shared_ok = args.dist_backend != "nccl" or args.force_device is not None
+    if have < args.gpus and not (shared_ok and have >= 1):
+        raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible -- refusing to run a smaller job under that label" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench.py] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit("bench.py: the %d-rank job failed (exit code %d)" % (args.gpus, rc))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,8 +176,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-len", type=int, default=26)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--copy-coeffs", action="store_true", help="LcCommit.coeffs as a private copy (the reference's semantics) instead of "
-                    "borrowing the caller's HBM buffer (LCPC_COMMIT_BORROW_COEFFS)")
+    ap.add_argument("--borrow-coeffs", action="store_true", help="LcCommit.coeffs aliases the caller's HBM buffer (LCPC_COMMIT_BORROW_COEFFS) "
+                    "instead of the private copy LcCommit::commit makes (lcpc-2d/src/lib.rs:636-645), which is the default and what `value` times")
+    ap.add_argument("--copy-coeffs", action="store_true", help="(the default since round 3; kept so that older command lines still parse)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power-sample", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -161,8 +190,13 @@ def main():
                          "between the two library phases")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) | gloo (debug: ranks may share a GPU; implies --exchange torch)")
     ap.add_argument("--force-device", type=int, default=None, help="debug: every rank uses this HIP device")
-    ap.add_argument("--check", action="store_true", help="debug: compare the sharded root with an unsharded commit of the same data")
+    ap.add_argument("--check", action="store_true", help="(always on for N > 1 since round 3; kept so that older command lines still parse)")
+    ap.add_argument("--no-check", action="store_true", help="N > 1: skip the untimed comparison of the sharded root with an unsharded commit of the same data")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args)
 
     if args.lean:
         args.no_cpu_baseline = args.no_power_sample = args.no_e2e = True
@@ -179,7 +213,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:                         # never report a job of another size than the one asked for
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the lcpc HIP path has no CPU fallback")
@@ -187,6 +221,9 @@ def main():
         local_rank = args.force_device
     elif args.dist_backend != "nccl":              # debug runs: more ranks than GPUs share the devices
         local_rank %= torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py --gpus %d: rank %d has no device of its own (%d visible); one GPU per rank, or the debug switches "
+                         "--dist-backend gloo / --force-device" % (args.gpus, rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
@@ -204,7 +241,7 @@ def main():
     n_rows1, n_per_row, n_cols = lcpc_amd.static_get_dims(fid, lcpc_amd.ENC_LIGERO, n_total)
     n_rows_total = n_rows1 * world if args.scaling == "weak" else n_rows1
     n_coeffs_job = n_rows_total * n_per_row
-    borrow = not args.copy_coeffs
+    borrow = args.borrow_coeffs
     stream = torch.cuda.current_stream().cuda_stream
 
     if not distributed:
@@ -221,9 +258,12 @@ def main():
         rb, re, cb, ce, n_chunks = engine.layout(n_rows_total)
         coeffs = device_random_coeffs(torch, max(re - rb, 1) * n_per_row, L, 1234 + rank, dev)
         # bring the communicators up outside the measured region (RCCL connects lazily on the first collective)
-        t_init = torch.zeros(1, device=dev)
+        t_init = torch.ones(1, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t_init)
         torch.cuda.synchronize()
+        ranks_seen = int(t_init.item())
+        if ranks_seen != args.gpus:
+            raise SystemExit("bench.py --gpus %d: the all-reduce saw %d ranks" % (args.gpus, ranks_seen))
         exchange_note = None
         if args.exchange == "native":
             # the library's own RCCL exchange; cross-checked once against the torch.distributed exchange of the same
@@ -255,9 +295,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.check and distributed:
-        # every rank regenerates the whole coefficient matrix (rank r's rows come from seed 1234 + r) and compares
-        # the sharded root with a plain single-context commit
+    check = None
+    if distributed and not args.no_check:
+        # first step of every N > 1 run (untimed): every rank regenerates the whole coefficient matrix (rank r's rows come
+        # from seed 1234 + r) and compares the sharded root with a plain single-context commit of it
         root_sharded = step(sync=True)
         parts = []
         for r in range(world):
@@ -269,9 +310,14 @@ def main():
         ref = LcCommit.commit_device(full.data_ptr(), n_coeffs_job, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=local_rank), stream)
         ok = ref.get_root() == root_sharded
         print("[rank %d] sharded root %s unsharded root: %s" % (rank, "==" if ok else "!=", root_sharded.hex()), file=sys.stderr)
-        if not ok:
+        t_ok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if int(t_ok.item()) == 0:
             raise SystemExit("sharded commit root mismatch")
+        check = {"sharded_root_equals_unsharded_root": True, "on": "all %d ranks, the job's own coefficients, before the timed region" % world,
+                 "root": root_sharded.hex()}
         del full, parts, ref
+        torch.cuda.empty_cache()
 
     # setup, not warm-up steps: a device that sat idle while the inputs were generated needs tens of milliseconds to
     # come back to working clocks (measured: a 0.6 ms kernel takes 8-20 ms right after an idle period)
@@ -338,7 +384,9 @@ def main():
                 traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc, kernel stamp %s; GB per launch = 2*FETCH_SIZE + WRITE_SIZE, mean over the %d NTT passes)" % (stamp, len(per))
         else:
             traffic_src = "profiles/pmc_latest.json is stale for these kernels (stamp %s != %s): not quoted" % (pmc.get("kernel_stamp"), stamp)
-    roofline = {"bound": "hbm", "kernel": "ntt_pass_l9s_kernel (row NTT, Ft255 signed lazy-limb arithmetic, shape-specialised; %d pass launches per commit)" % ntt_launches,
+    roofline = {"bound": "valu_issue", "bound_note": "what limits the kernel is vector-ALU instruction issue (`valu_issue` below, DESIGN.md section 6); "
+                "achieved / peak / frac are the HBM figures the contract asks for (algorithmic bytes per launch / launch time against 8 TB/s)",
+                "kernel": "ntt_pass_l9s_kernel (row NTT, Ft255 signed lazy-limb arithmetic, shape-specialised; %d pass launches per commit)" % ntt_launches,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_unit": "GB/launch", "traffic_source": traffic_src,
                 "algorithmic_GB_per_launch": round(enc_bytes / ntt_launches / 1e9, 3),
@@ -364,7 +412,8 @@ def main():
         for _ in range(5):
             step(borrow_=not borrow)
         torch.cuda.synchronize()
-        other_mode = {"coeffs": "borrowed" if not borrow else "copied (the reference's LcCommit owns its coeffs)",
+        other_mode = {"coeffs": "borrowed (LCPC_COMMIT_BORROW_COEFFS: LcCommit.coeffs aliases the caller's HBM buffer)" if not borrow
+                                else "copied (the reference's LcCommit owns its coeffs)",
                       "ms_per_step": round((time.perf_counter() - t1) / 5 * 1e3, 3)}
         step()
         torch.cuda.synchronize()
@@ -428,7 +477,7 @@ def main():
                                    (world, "RCCL inside the library" if args.exchange == "native" else "torch.distributed all-gather")) if distributed else "none",
                       "input": "device-resident (HBM)",
                       "coeffs": "borrowed: LcCommit.coeffs aliases the caller's HBM buffer (LCPC_COMMIT_BORROW_COEFFS)" if borrow
-                                else "copied into the LcCommit"},
+                                else "copied into the LcCommit (as LcCommit::commit does, lcpc-2d/src/lib.rs:636-645)"},
            "roofline": roofline}
     roofline["power"] = power
     if other_mode is not None:
@@ -437,6 +486,11 @@ def main():
         out["e2e_host"] = e2e
     if shard_ms is not None:
         out["shard_ms"] = shard_ms
+    if distributed:
+        out["ranks_seen"] = ranks_seen
+        out["check"] = check
+        out["devices"] = "one HIP device per rank" if (args.dist_backend == "nccl" and args.force_device is None) else \
+                         "DEBUG: ranks share devices (--dist-backend %s%s)" % (args.dist_backend, "" if args.force_device is None else ", --force-device %d" % args.force_device)
     if distributed and exchange_note:
         out["exchange_fallback"] = exchange_note
 

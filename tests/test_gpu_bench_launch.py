@@ -1,0 +1,54 @@
+"""bench.py as the driver starts it: `python bench.py --gpus N` with no launcher around it must start N ranks itself
+(it used to run ONE rank and print n_gpus 1).  On the single-GPU test box the two ranks share device 0 over
+gloo (the debug switches); with >= 2 GPUs the same command without them runs one rank per GPU on RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, timeout=900):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_self_launches_two_ranks():
+    shared = torch.cuda.device_count() < 2
+    extra = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--log-len", "22"]
+    if shared:
+        extra += ["--dist-backend", "gloo", "--force-device", "0"]
+    r = _run(extra)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
+    assert out["check"]["sharded_root_equals_unsharded_root"] is True
+    assert out["shard_ms"] is not None and out["value"] > 0
+    assert ("DEBUG" in out["devices"]) == shared
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_ranks_than_devices():
+    n = torch.cuda.device_count() + 1
+    r = _run(["--gpus", str(n), "--steps", "1", "--warmup", "0", "--log-len", "20"], timeout=300)
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_bench_without_device_fails_loudly():
+    """no GPU in this container: N = 1 and N > 1 both exit non-zero with a message, never a fabricated line"""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    for n in ("1", "2"):
+        r = _run(["--gpus", n, "--steps", "1", "--warmup", "0"], timeout=300)
+        assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
+        assert "GPU" in r.stderr or "device" in r.stderr
