@@ -295,7 +295,7 @@ void lcpc_commit_destroy(lcpc_commit_t* m) {
   if (!m) return;
   (void)hipSetDevice(m->enc->prm.device);
   dev_free(m->d_coeffs); dev_free(m->d_comm); dev_free(m->d_hashes); dev_free(m->d_cvs); dev_free(m->d_scratch); dev_free(m->d_node_tab);
-  dev_free(m->d_t29); dev_free(m->ws.d_tmp); dev_free(m->ws.d_t); dev_free(m->d_gather); dev_free(m->d_xsend); dev_free(m->d_xrecv);
+  dev_free(m->d_t29); dev_free(m->ws.d_tmp); dev_free(m->ws.d_t); dev_free(m->ws.d_mid); dev_free(m->d_gather); dev_free(m->d_xsend); dev_free(m->d_xrecv);
   for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : m->ev_batch) if (e) (void)hipEventDestroy(e);
   if (m->h_pin) (void)hipHostFree(m->h_pin);

@@ -27,7 +27,7 @@ static void ctx_free(lcpc_ctx* c) {
   comm_release(c);
   dev_free(c->d_pack[0]); dev_free(c->d_pack[1]);
   dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
-  dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->d_scratch);
+  dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->ws.d_mid); dev_free(c->d_scratch);
   if (c->h_varena) (void)hipHostFree(c->h_varena);
   for (auto* v : {&c->d_pre, &c->d_post})
     for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); dev_free(d.vals29); }
@@ -35,6 +35,26 @@ static void ctx_free(lcpc_ctx* c) {
 }
 void ctx_unref(lcpc_ctx* c) {
   if (c->refs.fetch_sub(1) == 1) ctx_free(c);
+}
+
+// Rows per batch of the 29-bit-limb intermediate between the two K1s passes (0 = keep the packed intermediate in comm).
+// Measured (tools/ab_mid_shapes.py, profiles/r03_mid_shapes.jsonl): the limb format saves ~3 % of the VALU instructions
+// (no clamp / pack at the first pass's store, no unpack at the last pass's load) and 1.5 % of the time while the first
+// pass stores runs of >= 32 elements (n_cols <= 2^15); with shorter runs its three planes become partial-line writes
+// (64 + 64 + 16 bytes per run at 2^18 columns) and it LOSES 1-2 %.  Hence: on by default only for n_cols <= 2^15;
+// LCPC_NTT_MID_MAX_MB=<MiB> forces it for every shape within that budget (A/B, tests), =0 turns it off.
+uint64_t ntt_mid_rows(const lcpc_ctx* c, uint64_t n_rows) {
+  const char* ev = getenv("LCPC_NTT_MID_MAX_MB");               // read per call: the tests switch it between commits
+  if (!c->l9s || n_rows == 0) return 0;
+  if (!ev && c->log_n > 15) return 0;
+  const uint64_t max_mb = ev ? strtoull(ev, nullptr, 10) : 6144;
+  if (max_mb == 0) return 0;
+  const uint64_t per_row = c->n_cols * 36;
+  uint64_t fit = (max_mb << 20) / per_row;
+  if (fit == 0) return 0;
+  if (fit >= n_rows) return n_rows;
+  const uint64_t batches = (n_rows + fit - 1) / fit;       // equal batches
+  return (n_rows + batches - 1) / batches;
 }
 
 // ---- NTT pass plan (DESIGN.md "K1") ----------------------------------------------------------------
@@ -86,6 +106,41 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
   if (j.kept_t) *j.kept_t = false;
   const uint64_t n_rows = j.n_rows;
   if (n_rows == 0) return 0;
+  if (c->prm.encoding == LCPC_ENC_LIGERO && c->l9s) {
+    // the shape-specialised two-pass kernel; between the passes the rows live as 29-bit limbs in ws->d_mid (row batches
+    // sized by ntt_mid_rows), or -- if that buffer cannot be had -- packed in dst itself
+    uint64_t rb = ws->mid_failed ? 0 : ntt_mid_rows(c, n_rows);
+    if (rb) {
+      std::string scratch_err;
+      if (ensure_dev(&scratch_err, &ws->d_mid, &ws->mid_cap, rb * c->n_cols * 36)) { ws->mid_failed = true; ws->mid_cap = 0; rb = 0; }
+    }
+    const uint64_t step = rb ? rb : n_rows;
+    for (uint64_t r0 = 0; r0 < n_rows; r0 += step) {
+      const uint64_t nr = std::min(step, n_rows - r0);
+      for (int i = 0; i < 2; i++) {
+        const Pass& p = c->passes[i];
+        const bool first = i == 0;
+        NttPassArgs a{};
+        a.roots29c = j.canon_out ? c->d_roots29c : nullptr;
+        a.mont_prefix = (j.canon_out && !first) ? 4u : 0u;              // the last pass ends with a radix-4 round (10 stages)
+        a.dst = j.dst + r0 * c->n_cols * c->NL;
+        a.src = first ? j.src + r0 * j.src_stride * c->NL : a.dst;
+        a.roots = c->d_roots; a.roots29 = c->d_roots29; a.qp29 = c->d_qp29;
+        a.src_stride = first ? j.src_stride : c->n_cols;
+        a.dst_stride = c->n_cols;
+        a.n_valid = first ? j.n_valid : c->n_cols;
+        const uint64_t consumed = r0 * j.src_stride;
+        a.n_src_total = !first || j.n_src_total == ~(uint64_t)0 ? ~(uint64_t)0 : (j.n_src_total > consumed ? j.n_src_total - consumed : 0);
+        a.copy_dst = first && j.copy_dst ? j.copy_dst + r0 * j.src_stride * c->NL : nullptr;
+        a.n_rows = nr;
+        a.log_n = c->log_n; a.t0 = p.t0; a.s = p.s; a.log_tj = p.log_tj;
+        a.mid = rb ? ws->d_mid : nullptr;
+        ECHK(launch_ntt_pass_l9s(a, first, c->d_pack[i], c->pack_info[i], st));
+        nl++;
+      }
+    }
+    return 0;
+  }
   if (c->prm.encoding == LCPC_ENC_LIGERO) {
     bool first = true;
     for (const Pass& p : c->passes) {
@@ -106,8 +161,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.copy_dst = first ? j.copy_dst : nullptr;
       a.n_rows = n_rows;
       a.log_n = c->log_n; a.t0 = p.t0; a.s = p.s; a.log_tj = p.log_tj;
-      if (c->l9s) ECHK(launch_ntt_pass_l9s(a, first, c->d_pack[first ? 0 : 1], c->pack_info[first ? 0 : 1], st));
-      else ECHK(launch_ntt_pass(c->NL, p.log_tile, a, st));
+      ECHK(launch_ntt_pass(c->NL, p.log_tile, a, st));
       nl++;
       first = false;
     }

@@ -42,7 +42,12 @@ struct EncodeWs {
   uint64_t tmp_cap = 0;
   uint32_t* d_t = nullptr;         // position-major working copy T[pos][row] of the rows being encoded
   uint64_t t_cap = 0;
+  uint32_t* d_mid = nullptr;       // Ligero, Ft255 two-pass plans: the 29-bit-limb intermediate between the passes (ntt_l9s.hip),
+  uint64_t mid_cap = 0;            // rows_per_batch x n_cols x 36 bytes (bytes)
+  bool mid_failed = false;         // the allocation failed once: stay on the packed intermediate (comm itself)
 };
+// rows whose limb intermediate fits LCPC_NTT_MID_MAX_MB (default 6144 MiB: the whole headline commitment in one batch; 0 = off)
+uint64_t ntt_mid_rows(const lcpc_ctx* c, uint64_t n_rows);
 
 // Brakedown: from this many rows on the rows are encoded on a position-major copy (lane = row); below, row-major with
 // lanes over outputs and terms.  LCPC_SDIG_T_MIN_ROWS overrides (A/B only).

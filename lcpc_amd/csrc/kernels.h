@@ -22,6 +22,9 @@ struct NttPassArgs {
   uint32_t* copy_dst;      // if non-null (first pass): padded copy of src, same strides (LcCommit.coeffs)
   uint64_t n_rows;
   uint32_t log_n, t0, s, log_tj;   // stages [t0, t0+s) on tiles of 2^s x 2^log_tj elements
+  uint32_t* mid = nullptr; // shape-specialised two-pass kernel only, may be null: the 29-bit-limb intermediate between the passes
+                           // (n_rows x n_cols x 36 bytes, layout in ntt_l9s.hip); the first pass writes it instead of dst, the
+                           // last pass reads it instead of src
 };
 hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream_t st);
 

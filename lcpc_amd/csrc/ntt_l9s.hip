@@ -45,7 +45,13 @@ template <int S, int LBT> struct Shape {
   static constexpr u32 period4(int r) { return 1u << (S - U0 - 2 * r - 2 + LBT); }
 };
 
-template <int S, int LTJ, bool FIRST>
+// MID: the intermediate between the two passes is not the packed comm buffer but a.mid, which holds every element as the
+// LDS tile holds it -- 9 signed 29-bit limbs, normalised, |value| < 4p (invariant I of field_dev.h) -- laid out per row as
+// the successor's tiles: [tile of 1024 elements][limbs 0-3 x 1024 | limbs 4-7 x 1024 | limb 8 x 1024] (36 KiB per tile).
+// The first pass then stores its tile as it stands (no clamp, no reduction, no 29 -> 32-bit packing: ~60 VALU per element)
+// and the last pass's tile load is a plain 36 KiB copy into LDS (no unpacking: ~17 per element), at 36 instead of 32 bytes
+// per element of intermediate traffic on a kernel that HBM does not bind.
+template <int S, int LTJ, bool FIRST, bool MID>
 __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, const u32* __restrict__ pack, NttPackInfo pi) {
   constexpr int NL = 8, LT = S + LTJ, LBT = LTJ;
   constexpr bool LAST = !FIRST;
@@ -78,6 +84,13 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
   const bool canon = a.roots29c != nullptr;
   for (u32 i = tid; i < 64 * 12; i += 256) nqp[i] = 0u - a.qp29[i];
   const u32* src = a.src + row * a.src_stride * NL;
+  if constexpr (LAST && MID) {
+    // the tile as the first pass left it: [limbs 0-3][limbs 4-7][limb 8] planes, the LDS layout itself
+    const uint4* t4 = reinterpret_cast<const uint4*>(a.mid + (row << k) * 9 + (size_t)tile * (9 * T));
+    uint4* l4 = reinterpret_cast<uint4*>(lds);
+#pragma unroll
+    for (u32 i = tid; i < 9 * T / 4; i += 256) l4[i] = t4[i];
+  } else {
 #pragma unroll
   for (u32 e = tid; e < T; e += 256) {
     const u32 g = gindex(e);
@@ -89,6 +102,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       v = fe_load<NL>(src + (size_t)g * NL);                 // < 2^256 (the first pass's store), not necessarily < p
     }
     lds9_put<LT>(lds, e, l9::from_packed(v));
+  }
   }
   __syncthreads();
   const u32* cls_pack = pack + (size_t)(FIRST ? tile : 0u) * pi.class_words;
@@ -203,6 +217,22 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     __syncthreads();
   }
 
+  if constexpr (FIRST && MID) {
+    // every slot holds a normalised value with |value| < 4p (c0 clamped, c1 / c3 products, c2 a normalised sum of two
+    // products; after a lone radix-2 round: loads, normalised sums, products): stored as it is.  lb == 10 (the successor
+    // runs 10 stages), so slot (i, lp) is element (tile << LTJ | lp) of the successor's tile i
+    u32* mrow = a.mid + (row << k) * 9;
+#pragma unroll
+    for (u32 e = tid; e < T; e += 256) {
+      const u32 e2 = (tile << LTJ) | (e & ((1u << LBT) - 1));
+      u32* t = mrow + (size_t)(e >> LBT) * (9 * T);
+      const L9 x = lds9_get<LT>(lds, e);
+      *reinterpret_cast<uint4*>(t + (size_t)e2 * 4) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+      *reinterpret_cast<uint4*>(t + (size_t)(T + e2) * 4) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+      t[(size_t)8 * T + e2] = x.v[8];
+    }
+    return;
+  }
   u32* dst = a.dst + row * a.dst_stride * NL;
 #pragma unroll
   for (u32 e = tid; e < T; e += 256) {
@@ -278,17 +308,21 @@ template <int S, int LBT> NttPackInfo pack_info_t() {
   return pi;
 }
 
-template <int S, int LTJ, bool FIRST>
-hipError_t launch_t(const NttPassArgs& a, const u32* pack, const NttPackInfo& pi, hipStream_t st) {
+template <int S, int LTJ, bool FIRST, bool MID>
+hipError_t launch_tm(const NttPassArgs& a, const u32* pack, const NttPackInfo& pi, hipStream_t st) {
   constexpr int LT = S + LTJ;
   const u64 tiles = ((u64)1 << (a.log_n - LT)) * a.n_rows;
   const size_t lds_bytes = (size_t)Lds9<LT>::WORDS * 4;
   // hipFuncSetAttribute is idempotent and cheap; calling it on every launch keeps this free of unsynchronised caches
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_l9s_kernel<S, LTJ, FIRST>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_l9s_kernel<S, LTJ, FIRST, MID>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((ntt_pass_l9s_kernel<S, LTJ, FIRST>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a, pack, pi);
+  hipLaunchKernelGGL((ntt_pass_l9s_kernel<S, LTJ, FIRST, MID>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a, pack, pi);
   return hipGetLastError();
+}
+template <int S, int LTJ, bool FIRST>
+hipError_t launch_t(const NttPassArgs& a, const u32* pack, const NttPackInfo& pi, hipStream_t st) {
+  return a.mid ? launch_tm<S, LTJ, FIRST, true>(a, pack, pi, st) : launch_tm<S, LTJ, FIRST, false>(a, pack, pi, st);
 }
 
 }  // namespace

@@ -51,3 +51,31 @@ def test_general_kernel_agrees(oracle, log_n):
     g = LcCommit.commit(coeffs, enc_g)
     assert (g.comm() == c.comm()).all() and (g.hashes() == c.hashes()).all()
     assert g.get_root() == O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4).get_root()
+
+
+@pytest.mark.parametrize("log_n", [11, 12, 15, 18, 19])
+@pytest.mark.parametrize("mid_mb", ["0", "1", "64"])
+def test_limb_intermediate_modes_agree(oracle, log_n, mid_mb):
+    """the 36-byte 29-bit-limb intermediate between the two passes (default: whole commitment in one batch) against the
+    packed intermediate in comm itself (LCPC_NTT_MID_MAX_MB=0; the default above 2^15 columns), forced on (64 MiB) and in row batches (1 MiB of intermediate: 7 rows at
+    2^12 columns, one row at a time or none at all above 2^14 -- then the packed path must take over)"""
+    O, fid = oracle, 3
+    n_cols, n_per_row = 1 << log_n, 1 << (log_n - 1)
+    n_rows = 9 if log_n <= 15 else 3
+    coeffs = O.random_elems(fid, n_rows * n_per_row - 5, 11 + log_n)
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    c = LcCommit.commit(coeffs, enc)
+    os.environ["LCPC_NTT_MID_MAX_MB"] = mid_mb
+    try:
+        g = LcCommit.commit(coeffs, enc)
+        rows = np.zeros((n_rows * n_cols, 4), np.uint64)
+        for r in range(n_rows):
+            seg = coeffs[r * n_per_row:(r + 1) * n_per_row]
+            rows[r * n_cols:r * n_cols + len(seg)] = seg
+        e = enc.encode(rows)
+    finally:
+        del os.environ["LCPC_NTT_MID_MAX_MB"]
+    oc = O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4)
+    assert (g.comm() == c.comm()).all() and (g.hashes() == c.hashes()).all() and (g.coeffs() == c.coeffs()).all()
+    assert g.get_root() == oc.get_root() and (c.comm() == oc.comm()).all()
+    assert (e == oc.comm()).all()
