@@ -26,7 +26,7 @@ static void ctx_free(lcpc_ctx* c) {
   (void)hipSetDevice(c->prm.device);
   comm_release(c);
   dev_free(c->d_pack[0]); dev_free(c->d_pack[1]);
-  dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
+  dev_free(c->d_rootsl); dev_free(c->d_qpl); dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
   dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->ws.d_mid); dev_free(c->d_scratch);
   if (c->h_varena) (void)hipHostFree(c->h_varena);
   for (auto* v : {&c->d_pre, &c->d_post})
@@ -138,6 +138,26 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
         ECHK(launch_ntt_pass_l9s(a, first, c->d_pack[i], c->pack_info[i], st));
         nl++;
       }
+    }
+    return 0;
+  }
+  if (c->prm.encoding == LCPC_ENC_LIGERO && c->lns) {
+    for (int i = 0; i < 2; i++) {
+      const Pass& p = c->passes[i];
+      const bool first = i == 0;
+      NttPassArgs a{};
+      a.src = first ? j.src : j.dst;
+      a.dst = j.dst;
+      a.roots = c->d_roots; a.roots29 = c->d_rootsl; a.qp29 = c->d_qpl;
+      a.src_stride = first ? j.src_stride : c->n_cols;
+      a.dst_stride = c->n_cols;
+      a.n_valid = first ? j.n_valid : c->n_cols;
+      a.n_src_total = first ? j.n_src_total : ~(uint64_t)0;
+      a.copy_dst = first ? j.copy_dst : nullptr;
+      a.n_rows = n_rows;
+      a.log_n = c->log_n; a.t0 = p.t0; a.s = p.s; a.log_tj = p.log_tj;
+      ECHK(launch_ntt_pass_lns(c->NL, a, first, c->d_pack[i], c->pack_info[i], st));
+      nl++;
     }
     return 0;
   }
@@ -429,6 +449,56 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       }
       HIPCHK(c, hipDeviceSynchronize());
       c->l9s = true;
+    }
+    if (!c->d_qp29 && c->passes.size() >= 2 && !getenv("LCPC_NTT_GENERAL") && ntt_lns_supported(c->NL, c->log_n)) {
+      // Ft63 / Ft127 / Ft191 rows that need more than one pass: two passes on 1024-element tiles with the lazy-limb
+      // kernel (ntt_lns.hip), its twiddle table in limb form (w^i R' mod p), the clamp table and the lane-order packs
+      const unsigned k = c->log_n;
+      c->passes.clear();
+      c->passes.push_back({0, k - 10, 20 - k, 10});
+      c->passes.push_back({k - 10, 10, 0u, 10});
+      const int N = ntt_lns_limbs(c->NL), W = ntt_lns_limb_bits(c->NL), stride = ntt_lns_stride(c->NL);
+      uint64_t rp[MAXL] = {1, 0, 0, 0};                        // R' = 2^(N W) mod p, a plain integer
+      for (int i = 0; i < N * W; i++) h_add(*f, rp, rp, rp);
+      std::vector<uint32_t> tab((size_t)64 * stride, 0);
+      for (int i = 0; i < 64; i++) {                           // (i - 24) * p as normalised signed limbs (two's complement top limb)
+        const int q = i - 24;
+        uint64_t mag[5] = {0, 0, 0, 0, 0};
+        unsigned __int128 cy = 0;
+        for (int w = 0; w < 5; w++) { cy += (unsigned __int128)(w < f->L ? f->p[w] : 0) * (uint64_t)(q < 0 ? -q : q); mag[w] = (uint64_t)cy; cy >>= 64; }
+        if (q < 0) {                                           // two's complement over 320 bits
+          unsigned __int128 c2 = 1;
+          for (int w = 0; w < 5; w++) { c2 += (unsigned __int128)(~mag[w]); mag[w] = (uint64_t)c2; c2 >>= 64; }
+        }
+        for (int l = 0; l < N; l++) {
+          const int b = W * l, w = b / 64, sh = b % 64;
+          uint64_t x = mag[w] >> sh;
+          if (sh) x |= mag[w + 1] << (64 - sh);
+          tab[(size_t)i * stride + l] = l + 1 < N ? (uint32_t)(x & (((uint64_t)1 << W) - 1)) : (uint32_t)x;   // top limb: sign-extended
+        }
+      }
+      const size_t n_roots = (size_t)1 << (k - 1);
+      uint32_t* d_rp = nullptr;
+      if ((rc = dev_alloc(err, &d_rp, 8 * f->L))) return rc;
+      if ((rc = dev_alloc(err, &c->d_rootsl, n_roots * stride * 4)) || (rc = dev_alloc(err, &c->d_qpl, tab.size() * 4))) { dev_free(d_rp); return rc; }
+      hipError_t he = hipMemcpy(d_rp, rp, 8 * f->L, hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = hipMemcpy(c->d_qpl, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = launch_ntt_lns_roots(c->NL, c->d_roots, n_roots, d_rp, c->d_rootsl, nullptr);
+      if (he == hipSuccess) he = hipDeviceSynchronize();
+      dev_free(d_rp);
+      if (he != hipSuccess) return fail_hip(err, he, "ntt_lns tables");
+      for (int i = 0; i < 2; i++) {
+        const Pass& ps = c->passes[i];
+        const bool first = i == 0;
+        NttPassArgs a{};
+        a.roots29 = c->d_rootsl; a.log_n = k; a.t0 = ps.t0; a.s = ps.s; a.log_tj = ps.log_tj;
+        c->pack_info[i] = ntt_lns_pack_info(c->NL, ps.s, first);
+        const uint32_t n_classes = first ? 1u << (k - 10) : 1u;
+        if ((rc = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return rc;
+        HIPCHK(c, launch_ntt_lns_pack(c->NL, a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
+      }
+      HIPCHK(c, hipDeviceSynchronize());
+      c->lns = true;
     }
     return 0;
   }

@@ -82,6 +82,10 @@ struct lcpc_ctx {
   uint32_t* d_pack[2] = {nullptr, nullptr};   // Ft255 two-pass plans: lane-order twiddle packs of the specialised kernel (ntt_l9s.hip)
   lcpc::NttPackInfo pack_info[2]{};
   bool l9s = false;
+  // Ft63 / Ft127 / Ft191 two-pass plans: the lazy-limb kernel of ntt_lns.hip (packs in d_pack / pack_info as well)
+  bool lns = false;
+  uint32_t* d_rootsl = nullptr;    // w^i * R' mod p as N limbs of W bits (field_ln.h), ntt_lns_stride words per entry
+  uint32_t* d_qpl = nullptr;       // (i - 24) * p, i < 64, same form (ln::clamp_*)
   // Brakedown
   lcpc::SdigSpec spec{};
   std::vector<lcpc::LevelDims> pre_dims, post_dims;

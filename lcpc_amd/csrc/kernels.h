@@ -40,6 +40,18 @@ NttPackInfo ntt_l9s_pack_info(uint32_t s, bool first);
 hipError_t launch_ntt_l9s_pack(const NttPassArgs& a, bool first, const NttPackInfo& pi, uint32_t n_classes, uint32_t* pack, hipStream_t st);
 hipError_t launch_ntt_pass_l9s(const NttPassArgs& a, bool first, const uint32_t* pack, const NttPackInfo& pi, hipStream_t st);
 
+// ---- shape-specialised lazy-limb NTT for Ft63 / Ft127 / Ft191, two-pass plans on 1024-element tiles (ntt_lns.hip) ----
+// nl = 2 / 4 / 6.  a.roots29 = the limb-form twiddle table (w^i R' mod p, ntt_lns_stride words per entry), a.qp29 = the
+// (i - 24) p table (64 rows, same stride)
+bool ntt_lns_supported(int nl, uint32_t log_n);
+int ntt_lns_limbs(int nl);
+int ntt_lns_limb_bits(int nl);
+int ntt_lns_stride(int nl);
+NttPackInfo ntt_lns_pack_info(int nl, uint32_t s, bool first);
+hipError_t launch_ntt_lns_roots(int nl, const uint32_t* roots, uint64_t n, const uint32_t* rprime, uint32_t* out, hipStream_t st);
+hipError_t launch_ntt_lns_pack(int nl, const NttPassArgs& a, bool first, const NttPackInfo& pi, uint32_t n_classes, uint32_t* pack, hipStream_t st);
+hipError_t launch_ntt_pass_lns(int nl, const NttPassArgs& a, bool first, const uint32_t* pack, const NttPackInfo& pi, hipStream_t st);
+
 // device-side precomp_fft: roots[i] = w^i (i < 2^log_half) from pw[j] = w^(2^j); roots29 (Ft255) may be null
 hipError_t launch_roots(int nl, const uint32_t* pw, uint32_t log_half, const uint32_t* one, uint32_t* roots, uint32_t* roots29,
                         uint32_t* roots29c, hipStream_t st);

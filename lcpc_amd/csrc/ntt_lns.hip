@@ -1,0 +1,376 @@
+// lcpc_amd/csrc/ntt_lns.hip -- K1n: the shape-specialised lazy-limb row NTT for Ft63 / Ft127 / Ft191
+// (LcEncoding::encode for Ligero, lcpc-ligero-pc/src/lib.rs:162-164 = fffft fft_io_pc [3P]; the reference benches Ft127
+// besides Ft255: lcpc-ligero-pc/src/bench.rs:178-204), for the two-pass plans on 1024-element tiles (2^11 <= n_cols <= 2^18).
+//
+// The structure is that of K1s (ntt_l9s.hip, Ft255): radix-4 DIF rounds on a tile that lives in LDS in the multiplier's own
+// format -- here N signed limbs of W bits (field_ln.h: 3 x 26, 5 x 29, 7 x 29) --, the pass shape as template parameters,
+// twiddles from lane-order packs, normalise + clamp of the pure-sum output in one carry pass, an odd stage count peeled as
+// a radix-2 round at stage 0 where a zero-padded row needs no additions.  What the smaller fields change:
+//   * occupancy: 12 / 20 / 28 bytes of LDS per element and 64 / 96 / 128 VGPRs give 8 / 5 / 4 waves per SIMD;
+//   * comm stays in Montgomery form (no canonical-output twiddle set: the column hash's per-element reduction is 2-6
+//     multiply-adds for these fields, not the 72 of Ft255);
+//   * the first pass stores values in [0, p + 64 B) < 2^(32 NL) without the final conditional subtract, the last pass
+//     subtracts under a wave-level __any (Ft63 / Ft127: most waves; Ft191: rarely).
+// Exact modular arithmetic: any stage grouping gives the same fully-reduced bits as the reference's radix-2 loop.
+// The general kernel (kernels.hip ntt_pass_kernel) remains for one-pass rows, three-pass plans and as the A/B reference
+// (LCPC_NTT_GENERAL=1; tests/test_gpu_ntt_shapes.py).
+#include "kernels.h"
+#include "field_ln.h"
+
+namespace lcpc {
+
+namespace {
+
+// ---- an array of `cnt` elements in planes: limbs 0-3 as uint4 (N >= 5), then a uint2 plane (N = 3: limbs 0-1; N = 7:
+//      limbs 4-5), then the top limb as u32.  Used for the LDS tile (cnt = 1024: unit-stride lanes are conflict-free in
+//      every plane) and for the twiddle packs (cnt = variants x period) -------------------------------------------------
+template <class FT> LCPC_DEV LN<FT::N> planes_get(const u32* base, u32 cnt, u32 e) {
+  constexpr int N = FT::N;
+  LN<N> r;
+  if constexpr (N == 3) {
+    const uint2 a = *reinterpret_cast<const uint2*>(base + (size_t)e * 2);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = base[(size_t)cnt * 2 + e];
+  } else {
+    const uint4 a = *reinterpret_cast<const uint4*>(base + (size_t)e * 4);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    if constexpr (N == 5) r.v[4] = base[(size_t)cnt * 4 + e];
+    else {
+      const uint2 b = *reinterpret_cast<const uint2*>(base + (size_t)cnt * 4 + (size_t)e * 2);
+      r.v[4] = b.x; r.v[5] = b.y; r.v[6] = base[(size_t)cnt * 6 + e];
+    }
+  }
+  return r;
+}
+template <class FT> LCPC_DEV void planes_put(u32* base, u32 cnt, u32 e, const LN<FT::N>& x) {
+  constexpr int N = FT::N;
+  if constexpr (N == 3) {
+    *reinterpret_cast<uint2*>(base + (size_t)e * 2) = make_uint2(x.v[0], x.v[1]);
+    base[(size_t)cnt * 2 + e] = x.v[2];
+  } else {
+    *reinterpret_cast<uint4*>(base + (size_t)e * 4) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    if constexpr (N == 5) base[(size_t)cnt * 4 + e] = x.v[4];
+    else {
+      *reinterpret_cast<uint2*>(base + (size_t)cnt * 4 + (size_t)e * 2) = make_uint2(x.v[4], x.v[5]);
+      base[(size_t)cnt * 6 + e] = x.v[6];
+    }
+  }
+}
+// one entry of the limb-form twiddle table / of the q*p table (STRIDE words per entry)
+template <class FT> LCPC_DEV LN<FT::N> tab_entry(const u32* tab, u32 idx) {
+  LN<FT::N> t;
+#pragma unroll
+  for (int k = 0; k < FT::N; k++) t.v[k] = tab[(size_t)idx * FT::STRIDE + k];
+  return t;
+}
+
+// round structure of a pass with S stages on tiles of 2^S x 2^LBT slots (as in ntt_l9s.hip)
+template <int S, int LBT> struct Shape {
+  static constexpr int U0 = S & 1;
+  static constexpr int NR4 = S / 2;
+  static constexpr u32 period2 = 1u << (S - 1 + LBT);
+  static constexpr u32 period4(int r) { return 1u << (S - U0 - 2 * r - 2 + LBT); }
+};
+
+constexpr u32 TILE = 1024;
+
+template <class FT, int S, int LTJ, bool FIRST>
+__global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArgs a, const u32* __restrict__ pack, NttPackInfo pi) {
+  constexpr int N = FT::N, NL = FT::NL, LBT = LTJ;
+  constexpr bool LAST = !FIRST;
+  static_assert(S + LTJ == 10, "1024-element tiles: one radix-4 quad (two radix-2 pairs) per thread and round");
+  static_assert(FIRST || (LTJ == 0 && S % 2 == 0), "the last pass works on contiguous tiles and ends with the trivial stages k-2, k-1");
+  using SH = Shape<S, LBT>;
+  using E = LN<N>;
+  constexpr u32 T = TILE;
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  u32* nqp = lds + (size_t)T * N;                            // NEGATED q*p rows (ln::clamp_apply)
+  const u32 k = a.log_n;
+  const u32 tiles_per_row = 1u << (k - 10);
+  u64 row;
+  u32 tile;
+  if (tiles_per_row >= 8) {                                  // XCD-aware order, as in ntt_pass_kernel
+    const u32 xcd = blockIdx.x & 7u;
+    const u64 qq = blockIdx.x >> 3;
+    tile = (u32)(qq / a.n_rows) * 8u + xcd;
+    row = qq % a.n_rows;
+  } else {
+    row = blockIdx.x / tiles_per_row;
+    tile = blockIdx.x % tiles_per_row;
+  }
+  const u32 tid = threadIdx.x;
+  const u32 lb = FIRST ? k - S : 0u;                         // index bits below the pass's stage field
+  // element index of LDS slot e = (i << LBT) | lp.  First pass: (i << lb) | (tile << LTJ) | lp; last pass: tile * 2^S + i
+  auto gindex = [&](u32 e) -> u32 {
+    if constexpr (FIRST) return ((e >> LBT) << lb) | (tile << LTJ) | (e & ((1u << LBT) - 1));
+    else return (tile << S) | e;
+  };
+  for (u32 i = tid; i < 64 * FT::STRIDE; i += 256) nqp[i] = 0u - a.qp29[i];
+  const u32* src = a.src + row * a.src_stride * NL;
+#pragma unroll
+  for (u32 e = tid; e < T; e += 256) {
+    const u32 g = gindex(e);
+    Fe<NL> v;
+    if constexpr (FIRST) {        // zero padding, the ragged tail of the caller's vector and the coeffs copy exist here only
+      v = (g < a.n_valid && row * a.src_stride + g < a.n_src_total) ? fe_load<NL>(src + (size_t)g * NL) : fe_zero<NL>();
+      if (a.copy_dst != nullptr && g < a.n_valid) fe_store<NL>(a.copy_dst + (row * a.src_stride + g) * NL, v);
+    } else {
+      v = fe_load<NL>(src + (size_t)g * NL);                 // < 2^(32 NL) (the first pass's store), not necessarily < p
+    }
+    planes_put<FT>(lds, T, e, ln::from_packed<FT>(v));
+  }
+  __syncthreads();
+  const u32* cls_pack = pack + (size_t)(FIRST ? tile : 0u) * pi.class_words;
+  const bool zero_hi = FIRST && a.n_valid <= (1ull << (k - 1));
+
+  if constexpr (SH::U0 == 1) {
+    // ---- radix-2 round at stage 0 (odd S): pairs (e1, e1 + half), twiddle w^(index of e1); inputs straight from the loads
+    constexpr u32 half = 1u << (S - 1 + LBT);
+    const u32* blk = cls_pack + pi.round_off[0];
+#pragma unroll
+    for (u32 pp = 0; pp < 2; pp++) {
+      const u32 e1 = tid + 256u * pp;                        // slots with the top stage bit clear are [0, half)
+      const E w = planes_get<FT>(blk, SH::period2, e1);
+      const E x = planes_get<FT>(lds, T, e1);
+      if (zero_hi) {
+        planes_put<FT>(lds, T, e1 + half, ln::mul<FT>(x, w));         // (x, 0) -> (x, x w)
+      } else {
+        const E y = planes_get<FT>(lds, T, e1 + half);
+        E sum = ln::add(x, y);                               // [0, 2p + 128 B)
+        ln::normalize<FT>(sum);
+        planes_put<FT>(lds, T, e1, sum);
+        planes_put<FT>(lds, T, e1 + half, ln::mul<FT>(ln::sub(x, y), w));
+      }
+    }
+    __syncthreads();
+  }
+
+  const u32 q = tid;                                         // one quad per thread per radix-4 round (T / 4 == 256)
+#pragma unroll
+  for (int r = 0; r < SH::NR4; r++) {
+    const int u = SH::U0 + 2 * r, hb = S - u - 1;            // stages (u, u + 1) of this pass; pair bit of stage u
+    const bool last_two = LAST && (r == SH::NR4 - 1);        // stages k-2, k-1: twiddles 1, w^(n/4), 1
+    const u32 lp = q & ((1u << LBT) - 1), j = q >> LBT;
+    const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+    const u32 e0 = (i0 << LBT) | lp;
+    constexpr u32 one = 1u;
+    const u32 dq = one << (hb - 1 + LBT);
+    const u32 period = one << (hb - 1 + LBT);                // quads q and q + period share their twiddles
+    const u32 jl = q & (period - 1);
+    const u32* blk = cls_pack + pi.round_off[SH::U0 + r];
+    if (u == 0 && zero_hi) {
+      // zero-padded first round (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x w); inputs < 4p
+      const E w0 = planes_get<FT>(blk, 3 * period, jl), w2 = planes_get<FT>(blk, 3 * period, 2 * period + jl);
+      if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
+        const E x0 = planes_get<FT>(lds, T, e0);
+        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(x0, w2));
+        const E b2 = ln::mul<FT>(x0, w0);
+        planes_put<FT>(lds, T, e0 + 2 * dq, b2);
+        planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(b2, w2));
+      } else {
+        const E w1 = planes_get<FT>(blk, 3 * period, period + jl);
+        const E x0 = planes_get<FT>(lds, T, e0), x1 = planes_get<FT>(lds, T, e0 + dq);
+        E c0 = ln::add(x0, x1);
+        ln::normalize<FT>(c0);
+        planes_put<FT>(lds, T, e0, c0);
+        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(x0, x1), w2));
+        const E b2 = ln::mul<FT>(x0, w0), b3 = ln::mul<FT>(x1, w1);                          // (-p - eps, eps]
+        E c2 = ln::add(b2, b3);
+        ln::normalize<FT>(c2);
+        planes_put<FT>(lds, T, e0 + 2 * dq, c2);
+        planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(ln::sub(b2, b3), w2));
+      }
+      __syncthreads();
+      continue;
+    }
+    const E x0 = planes_get<FT>(lds, T, e0), x1 = planes_get<FT>(lds, T, e0 + dq);
+    const E x2 = planes_get<FT>(lds, T, e0 + 2 * dq), x3 = planes_get<FT>(lds, T, e0 + 3 * dq);   // I: normalised, |value| < 4p
+    const E b0 = ln::add(x0, x2), b1 = ln::add(x1, x3);                                           // limbs [0, 2^(W+1)), |value| < 8p
+    E c0 = ln::add(b0, b1);                                                                       // limbs [0, 2^(W+2)), |value| < 16p
+    if (last_two) ln::normalize<FT>(c0);                                                          // (the store path clamps every slot)
+    else ln::clamp_apply<FT>(c0, ln::clamp_row<FT>(nqp, ln::clamp_q<FT>(c0.v[N - 1])));           // [0, p + 64 B)
+    planes_put<FT>(lds, T, e0, c0);
+    if (last_two) {
+      // outputs go straight to the store path (normalised, |value| < 16p)
+      const E wq = tab_entry<FT>(a.roots29, 1u << (k - 2));                                       // wave-uniform
+      E c1 = ln::sub(b0, b1);
+      const E b2 = ln::sub(x0, x2);
+      const E b3 = ln::mul<FT>(ln::sub(x1, x3), wq);
+      E c2 = ln::add(b2, b3);
+      E c3 = ln::sub(b2, b3);
+      ln::normalize<FT>(c1); ln::normalize<FT>(c2); ln::normalize<FT>(c3);
+      planes_put<FT>(lds, T, e0 + dq, c1);
+      planes_put<FT>(lds, T, e0 + 2 * dq, c2);
+      planes_put<FT>(lds, T, e0 + 3 * dq, c3);
+    } else {
+      const E w0 = planes_get<FT>(blk, 3 * period, jl), w1 = planes_get<FT>(blk, 3 * period, period + jl);
+      const E w2 = planes_get<FT>(blk, 3 * period, 2 * period + jl);
+      planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(b0, b1), w2));                          // in: |value| < 16p
+      const E b2 = ln::mul<FT>(ln::sub(x0, x2), w0);                                              // in: |value| < 8p
+      const E b3 = ln::mul<FT>(ln::sub(x1, x3), w1);
+      E c2 = ln::add(b2, b3);                                                                     // (-2p - 2 eps, 2 eps]
+      ln::normalize<FT>(c2);
+      planes_put<FT>(lds, T, e0 + 2 * dq, c2);
+      planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(ln::sub(b2, b3), w2));
+    }
+    __syncthreads();
+  }
+
+  u32* dst = a.dst + row * a.dst_stride * NL;
+#pragma unroll
+  for (u32 e = tid; e < T; e += 256) {
+    const u32 g = gindex(e);
+    E x = planes_get<FT>(lds, T, e);                                            // normalised, |value| < 16p
+    ln::clamp_apply<FT>(x, ln::clamp_row<FT>(nqp, ln::clamp_q<FT>(x.v[N - 1])));  // [0, p + 64 B) < 2^(32 NL)
+    u32 w[NL];
+    ln::to_packed<FT>(w, x.v);
+    Fe<NL> v;
+    if constexpr (LAST) {
+      // -> [0, p): after the clamp, value >= p needs the top limb to reach floor(p / B)
+      if (__any((int)(x.v[N - 1] >= FT::limb(N - 1)))) v = fe_reduce_once<NL>(w, 0u);
+      else {
+#pragma unroll
+        for (int i = 0; i < NL; i++) v.v[i] = w[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; i++) v.v[i] = w[i];
+    }
+    fe_store<NL>(dst + (size_t)g * NL, v);
+  }
+}
+
+// one thread per (class, round slot, position): copies the table entries a quad / pair will ask for into lane order
+template <class FT, int S, int LBT>
+__global__ void __launch_bounds__(256) ntt_lns_pack_kernel(NttPassArgs a, NttPackInfo pi, u32 n_classes, bool first, u32* pack) {
+  using SH = Shape<S, LBT>;
+  constexpr u32 n_slots = SH::U0 + SH::NR4;
+  constexpr u32 PMAX = 1u << (S - 1 + LBT);                  // >= every period
+  const u32 k = a.log_n, t0 = a.t0;
+  const u32 lb = first ? k - S : 0u;
+  const u64 total = (u64)n_classes * n_slots * PMAX;
+  for (u64 id = (u64)blockIdx.x * 256 + threadIdx.x; id < total; id += (u64)gridDim.x * 256) {
+    const u32 jl = (u32)(id % PMAX), slot = (u32)((id / PMAX) % n_slots), cls = (u32)(id / PMAX / n_slots);
+    u32* blk = pack + (size_t)cls * pi.class_words + pi.round_off[slot];
+    const u32 lo = first ? (cls << LBT) : 0u;                // first pass: the tile's own low index bits
+    if (SH::U0 == 1 && slot == 0) {                          // radix-2 round at stage t0: w^((g1 & gm) << t0), g1 = index of e1 = jl
+      const u32 lp = jl & ((1u << LBT) - 1), i = jl >> LBT;
+      const u32 g1 = (i << lb) | lo | lp;
+      const u32 gm = (1u << (k - t0 - 1)) - 1;
+      planes_put<FT>(blk, SH::period2, jl, tab_entry<FT>(a.roots29, (g1 & gm) << t0));
+      continue;
+    }
+    const u32 r = slot - SH::U0, u = SH::U0 + 2 * r, hb = S - u - 1, period = 1u << (hb - 1 + LBT);
+    const u32 t = t0 + u;
+    if (jl >= period || t + 2 == k) continue;                // (stages k-2, k-1: one wave-uniform twiddle, not packed)
+    const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
+    const u32 lp = jl & ((1u << LBT) - 1), j = jl >> LBT;
+    const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+    const u32 g0 = (i0 << lb) | lo | lp;                     // (last pass: the tile's high bits do not reach these twiddles)
+    const u32 g1 = g0 + (1u << (hb - 1 + lb));
+    const u32 idx[3] = {(g0 & gm0) << t, (g1 & gm0) << t, (g0 & gm1) << (t + 1)};
+    for (u32 v = 0; v < 3; v++) planes_put<FT>(blk, 3 * period, v * period + jl, tab_entry<FT>(a.roots29, idx[v]));
+  }
+}
+
+template <class FT, int S, int LBT> NttPackInfo pack_info_t() {
+  using SH = Shape<S, LBT>;
+  NttPackInfo pi{};
+  u32 off = 0, slot = 0;
+  if (SH::U0) { pi.round_off[slot++] = off; off += SH::period2 * FT::N; off = (off + 3) & ~3u; }
+  for (int r = 0; r < SH::NR4; r++) { pi.round_off[slot++] = off; off += 3 * SH::period4(r) * FT::N; off = (off + 3) & ~3u; }
+  pi.class_words = off;
+  return pi;
+}
+
+template <class FT, int S, int LTJ, bool FIRST>
+hipError_t launch_t(const NttPassArgs& a, const u32* pack, const NttPackInfo& pi, hipStream_t st) {
+  const u64 tiles = ((u64)1 << (a.log_n - 10)) * a.n_rows;
+  const size_t lds_bytes = ((size_t)TILE * FT::N + 64 * FT::STRIDE) * 4;
+  hipLaunchKernelGGL((ntt_pass_lns_kernel<FT, S, LTJ, FIRST>), dim3((unsigned)tiles), dim3(256), lds_bytes, st, a, pack, pi);
+  return hipGetLastError();
+}
+
+// limb-form twiddle table: out[i] = roots[i] * (R' mod p) / R = w^i R' mod p, fully reduced, as N limbs of W bits
+template <class FT>
+__global__ void __launch_bounds__(256) roots_ln_kernel(const u32* roots, u64 n, const u32* rprime, u32* out) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const Fe<FT::NL> c = fe_load<FT::NL>(rprime);
+  const Fe<FT::NL> t = fe_mul<FT::NL>(fe_load<FT::NL>(roots + i * FT::NL), c);
+  const LN<FT::N> l = ln::from_packed<FT>(t);
+#pragma unroll
+  for (int k = 0; k < FT::STRIDE; k++) out[i * FT::STRIDE + k] = k < FT::N ? l.v[k] : 0u;
+}
+
+#define LNS_FIRST_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+
+template <class FT> NttPackInfo pack_info_f(uint32_t s, bool first) {
+  if (!first) return pack_info_t<FT, 10, 0>();
+  switch (s) {
+#define X(SV) case SV: return pack_info_t<FT, SV, 10 - SV>();
+    LNS_FIRST_CASES(X)
+#undef X
+  }
+  return NttPackInfo{};
+}
+template <class FT> hipError_t launch_pack_f(const NttPassArgs& a, bool first, const NttPackInfo& pi, uint32_t n_classes, uint32_t* pack, hipStream_t st) {
+  if (!first) {
+    hipLaunchKernelGGL((ntt_lns_pack_kernel<FT, 10, 0>), dim3(64), dim3(256), 0, st, a, pi, n_classes, false, pack);
+    return hipGetLastError();
+  }
+  switch (a.s) {
+#define X(SV) case SV: hipLaunchKernelGGL((ntt_lns_pack_kernel<FT, SV, 10 - SV>), dim3(2048), dim3(256), 0, st, a, pi, n_classes, true, pack); break;
+    LNS_FIRST_CASES(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+template <class FT> hipError_t launch_pass_f(const NttPassArgs& a, bool first, const uint32_t* pack, const NttPackInfo& pi, hipStream_t st) {
+  if (!first) {
+    if (a.s != 10 || a.log_tj != 0 || a.t0 + a.s != a.log_n) return hipErrorInvalidValue;
+    return launch_t<FT, 10, 0, false>(a, pack, pi, st);
+  }
+  if (a.t0 != 0 || a.s + a.log_tj != 10 || a.s + 10 != a.log_n) return hipErrorInvalidValue;
+  switch (a.s) {
+#define X(SV) case SV: return launch_t<FT, SV, 10 - SV, true>(a, pack, pi, st);
+    LNS_FIRST_CASES(X)
+#undef X
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+#define LNS_DISPATCH(nl, EXPR)                         \
+  switch (nl) {                                        \
+    case 2: { using FT = LnField<FT63>; EXPR; }        \
+    case 4: { using FT = LnField<FT127>; EXPR; }       \
+    case 6: { using FT = LnField<FT191>; EXPR; }       \
+    default: break;                                    \
+  }
+
+bool ntt_lns_supported(int nl, uint32_t log_n) { return (nl == 2 || nl == 4 || nl == 6) && log_n >= 11 && log_n <= 18; }
+int ntt_lns_limbs(int nl) { return nl == 2 ? 3 : (nl == 4 ? 5 : (nl == 6 ? 7 : 0)); }
+int ntt_lns_limb_bits(int nl) { return nl == 2 ? 26 : 29; }
+int ntt_lns_stride(int nl) { return nl == 2 ? 4 : 8; }
+
+NttPackInfo ntt_lns_pack_info(int nl, uint32_t s, bool first) {
+  LNS_DISPATCH(nl, return pack_info_f<FT>(s, first))
+  return NttPackInfo{};
+}
+hipError_t launch_ntt_lns_roots(int nl, const uint32_t* roots, uint64_t n, const uint32_t* rprime, uint32_t* out, hipStream_t st) {
+  const dim3 grid((unsigned)((n + 255) / 256));
+  LNS_DISPATCH(nl, hipLaunchKernelGGL((roots_ln_kernel<FT>), grid, dim3(256), 0, st, roots, n, rprime, out); return hipGetLastError())
+  return hipErrorInvalidValue;
+}
+hipError_t launch_ntt_lns_pack(int nl, const NttPassArgs& a, bool first, const NttPackInfo& pi, uint32_t n_classes, uint32_t* pack, hipStream_t st) {
+  LNS_DISPATCH(nl, return launch_pack_f<FT>(a, first, pi, n_classes, pack, st))
+  return hipErrorInvalidValue;
+}
+hipError_t launch_ntt_pass_lns(int nl, const NttPassArgs& a, bool first, const uint32_t* pack, const NttPackInfo& pi, hipStream_t st) {
+  LNS_DISPATCH(nl, return launch_pass_f<FT>(a, first, pack, pi, st))
+  return hipErrorInvalidValue;
+}
+
+}  // namespace lcpc
