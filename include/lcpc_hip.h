@@ -142,6 +142,23 @@ int  lcpc_commit_device(lcpc_commit_t *cm, const uint64_t *coeffs_dev, uint64_t 
  * caller-supplied comm (n_rows x n_cols) and coeffs (n_rows x n_per_row, may be NULL), then Merkleize. */
 int  lcpc_commit_from_parts(lcpc_commit_t *cm, const uint64_t *comm_host, const uint64_t *coeffs_host,
                             uint64_t n_rows, uint8_t *root);
+/* ---- serde of LcCommit itself (lcpc-2d/src/lib.rs:186-268: `Serialize` / `Deserialize for LcCommit` through
+ * WrappedLcCommit { comm, coeffs, n_rows, n_cols, n_per_row, hashes }) in bincode 1.3's default layout -- the only way to
+ * hand a COMMITMENT to or from the reference (its fields are private; GPU commit -> reference prove, or a reference
+ * commitment -> GPU prove):
+ *   u64 len(comm) | comm: len x L u64 limbs (Montgomery form, row-major) | u64 len(coeffs) | coeffs | u64 n_rows | u64 n_cols |
+ *   u64 n_per_row | u64 len(hashes) | len x (u64 32 | 32 digest bytes)
+ * Streaming: 6 GiB at the headline never sits in one host buffer.  `write` receives consecutive pieces (<= 64 MiB each),
+ * `read` must fill exactly `len` bytes; either returns 0 to go on, anything else aborts the call (LCPC_ERR_ARG).
+ * lcpc_commit_from_bincode checks what check_comm (lib.rs:673-688) checks -- lengths against the dims and the encoder's
+ * dims_ok -- refuses limbs >= p (LCPC_ERR_COMMIT), and rebuilds the Merkle tree from `comm` on the device: digests that
+ * differ from the stream's `hashes` are refused too (the reference would carry them along and prove against a root nobody
+ * can verify).  Unsharded commitments only (LCPC_ERR_STATE otherwise). */
+typedef int (*lcpc_write_fn)(void *user, const uint8_t *data, uint64_t len);
+typedef int (*lcpc_read_fn)(void *user, uint8_t *data, uint64_t len);
+uint64_t lcpc_commit_bincode_size(const lcpc_commit_t *cm);             /* 0: nothing committed */
+int  lcpc_commit_bincode_write(lcpc_commit_t *cm, lcpc_write_fn write, void *user);
+int  lcpc_commit_from_bincode(lcpc_commit_t *cm, lcpc_read_fn read, void *user, uint8_t *root);
 int  lcpc_get_root(lcpc_commit_t *cm, uint8_t root[32]);                /* get_root lib.rs:276-281 */
 int  lcpc_commit_dims(const lcpc_commit_t *cm, uint64_t *n_rows, uint64_t *n_per_row, uint64_t *n_cols,
                       uint64_t *n_hashes);                               /* get_n_rows/.. lib.rs:283-296 */

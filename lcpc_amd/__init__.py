@@ -259,6 +259,50 @@ class LcCommit:
         cm._check(_lib.lib().lcpc_commit_from_parts(cm._h, _ptr(comm), cp, n_rows, None))
         return cm._refresh()
 
+    # ---- serde of LcCommit (lcpc-2d/src/lib.rs:186-268), bincode 1.3, streamed ----
+    def bincode_size(self):
+        return int(_lib.lib().lcpc_commit_bincode_size(self._h))
+
+    def to_bincode(self, fileobj):
+        """bincode::serialize_into(fileobj, &commit): the bytes the reference's `Deserialize for LcCommit` takes."""
+        err = []
+
+        def wr(_user, data, n):
+            try:
+                fileobj.write(C.string_at(data, n))
+                return 0
+            except Exception as e:      # never unwind through the C frame
+                err.append(e)
+                return 1
+
+        rc = _lib.lib().lcpc_commit_bincode_write(self._h, _lib.WRITE_FN(wr), None)
+        if err:
+            raise err[0]
+        self._check(rc)
+
+    @classmethod
+    def from_bincode(cls, enc, fileobj):
+        """bincode::deserialize_from(fileobj) of a commitment the reference (or to_bincode) serialised, into HBM."""
+        cm = cls(enc)
+        err = []
+
+        def rd(_user, data, n):
+            try:
+                b = fileobj.read(n)
+                if len(b) != n:
+                    return 1
+                C.memmove(data, b, n)
+                return 0
+            except Exception as e:
+                err.append(e)
+                return 1
+
+        rc = _lib.lib().lcpc_commit_from_bincode(cm._h, _lib.WRITE_FN(rd), None, None)
+        if err:
+            raise err[0]
+        cm._check(rc)
+        return cm._refresh()
+
     def get_root(self):
         out = (C.c_uint8 * 32)()
         self._check(_lib.lib().lcpc_get_root(self._h, out))

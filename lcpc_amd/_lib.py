@@ -27,6 +27,7 @@ class LcpcTimings(C.Structure):
 # every symbol include/lcpc_hip.h declares: name -> (restype, argtypes)
 _vp, _u64, _u32, _i32, _sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_size_t
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)      # lcpc_allgather_fn (include/lcpc_hip.h)
+WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)   # lcpc_write_fn / lcpc_read_fn
 
 SYMBOLS = {
     "lcpc_abi_version": (_i32, []),
@@ -48,6 +49,9 @@ SYMBOLS = {
     "lcpc_commit": (_i32, [_vp, _vp, _u64, _vp]),
     "lcpc_commit_device": (_i32, [_vp, _vp, _u64, _vp, _u32, _vp]),
     "lcpc_commit_from_parts": (_i32, [_vp, _vp, _vp, _u64, _vp]),
+    "lcpc_commit_bincode_size": (_u64, [_vp]),
+    "lcpc_commit_bincode_write": (_i32, [_vp, WRITE_FN, _vp]),
+    "lcpc_commit_from_bincode": (_i32, [_vp, WRITE_FN, _vp, _vp]),
     "lcpc_get_root": (_i32, [_vp, _vp]),
     "lcpc_commit_dims": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "lcpc_get_hashes": (_i32, [_vp, _vp]),

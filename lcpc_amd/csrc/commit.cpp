@@ -430,6 +430,125 @@ int lcpc_commit_from_parts(lcpc_commit_t* m, const uint64_t* comm, const uint64_
   LCPC_CATCH(m)
 }
 
+// ---- serde of LcCommit (lib.rs:186-268), bincode 1.3 ---------------------------------------------------------------
+uint64_t lcpc_commit_bincode_size(const lcpc_commit_t* m) {
+  if (!m || !m->committed || m->enc->prm.shard_count > 1) return 0;
+  const lcpc_ctx* c = m->enc;
+  const uint64_t eb = elem_bytes(c);
+  return 8 + m->n_rows * c->n_cols * eb + 8 + m->n_rows * c->n_per_row * eb + 24 + 8 + (2 * c->np2 - 1) * 40;
+}
+
+int lcpc_commit_bincode_write(lcpc_commit_t* m, lcpc_write_fn fn, void* user) {
+  if (!m || !fn) return LCPC_ERR_ARG;
+  if (!m->committed || m->enc->prm.shard_count > 1) return LCPC_ERR_STATE;
+  const lcpc_ctx* c = m->enc;
+  LCPC_TRY
+  const uint64_t eb = elem_bytes(c);
+  auto put64 = [&](uint64_t v) { return fn(user, reinterpret_cast<const uint8_t*>(&v), 8); };
+  // comm, then coeffs: row batches of <= 64 MiB through one staging buffer (lcpc_get_comm converts a canonical device copy
+  // back to Montgomery form and materialises Brakedown's row-major view)
+  struct Part { uint64_t per_row; int (*get)(lcpc_commit_t*, uint64_t, uint64_t, uint64_t*); };
+  const Part parts[2] = {{c->n_cols, lcpc_get_comm}, {c->n_per_row, lcpc_get_coeffs}};
+  for (const Part& p : parts) {
+    if (put64(m->n_rows * p.per_row)) return LCPC_ERR_ARG;
+    const uint64_t row_b = p.per_row * eb;
+    const uint64_t batch = std::max<uint64_t>(1, ((uint64_t)64 << 20) / row_b);
+    std::vector<uint64_t> buf((size_t)(std::min(batch, m->n_rows) * row_b / 8));
+    for (uint64_t r = 0; r < m->n_rows; r += batch) {
+      const uint64_t nb = std::min(batch, m->n_rows - r);
+      int rc = p.get(m, r, nb, buf.data());
+      if (rc) return rc;
+      for (uint64_t off = 0; off < nb * row_b; off += (uint64_t)64 << 20)      // (a single row may exceed 64 MiB)
+        if (fn(user, reinterpret_cast<const uint8_t*>(buf.data()) + off, std::min<uint64_t>((uint64_t)64 << 20, nb * row_b - off))) return LCPC_ERR_ARG;
+    }
+  }
+  if (put64(m->n_rows) || put64(c->n_cols) || put64(c->n_per_row)) return LCPC_ERR_ARG;
+  const uint64_t nh = 2 * c->np2 - 1;
+  std::vector<uint8_t> h((size_t)nh * 32), w((size_t)nh * 40);
+  int rc = lcpc_get_hashes(m, h.data());
+  if (rc) return rc;
+  for (uint64_t i = 0; i < nh; i++) {
+    const uint64_t l = 32;
+    memcpy(&w[i * 40], &l, 8);
+    memcpy(&w[i * 40 + 8], &h[i * 32], 32);
+  }
+  if (put64(nh)) return LCPC_ERR_ARG;
+  for (uint64_t off = 0; off < w.size(); off += (uint64_t)64 << 20)
+    if (fn(user, w.data() + off, std::min<uint64_t>((uint64_t)64 << 20, w.size() - off))) return LCPC_ERR_ARG;
+  return 0;
+  LCPC_CATCH(m)
+}
+
+int lcpc_commit_from_bincode(lcpc_commit_t* m, lcpc_read_fn fn, void* user, uint8_t* root) {
+  if (!m || !fn) return LCPC_ERR_ARG;
+  const lcpc_ctx* c = m->enc;
+  if (c->prm.shard_count > 1) return LCPC_ERR_STATE;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  const FieldDesc& f = *c->f;
+  const uint64_t eb = elem_bytes(c);
+  bool bad_read = false;
+  auto get64 = [&]() { uint64_t v = 0; if (fn(user, reinterpret_cast<uint8_t*>(&v), 8)) bad_read = true; return v; };
+  const uint64_t n_comm = get64();
+  if (bad_read) return LCPC_ERR_ARG;
+  if (n_comm == 0 || n_comm % c->n_cols) return LCPC_ERR_COMMIT;             // check_comm: comm.len() == n_rows * n_cols
+  const uint64_t n_rows = n_comm / c->n_cols;
+  if (n_rows > ((uint64_t)1 << 40) / c->n_cols) return LCPC_ERR_COMMIT;
+  begin_commit(m, n_rows, 0, n_rows);
+  int rc = ensure_commit_buffers(m, n_rows, true);
+  if (rc) return rc;
+  if (!m->d_comm || m->cap_comm_rows < n_rows) {           // (Brakedown, position-major path: ensure_commit_buffers leaves comm for later)
+    dev_free(m->d_comm); m->d_comm = nullptr; m->cap_comm_rows = 0;
+    if ((rc = dev_alloc(&m->err, &m->d_comm, (size_t)n_rows * c->n_cols * eb))) return rc;
+    m->cap_comm_rows = n_rows;
+  }
+  std::vector<uint64_t> buf;
+  // an element vector of the stream -> device, a piece at a time; untrusted limbs: nothing >= p reaches device arithmetic
+  auto upload = [&](uint32_t* dst, uint64_t n_elems) -> int {
+    const uint64_t piece = ((uint64_t)64 << 20) / eb;
+    buf.resize((size_t)(std::min(piece, n_elems) * eb / 8));
+    for (uint64_t e = 0; e < n_elems; e += piece) {
+      const uint64_t ne = std::min(piece, n_elems - e);
+      if (fn(user, reinterpret_cast<uint8_t*>(buf.data()), ne * eb)) return LCPC_ERR_ARG;
+      std::atomic<bool> ok{true};
+      parallel_for(ne, 1 << 15, [&](uint64_t b, uint64_t en) {
+        for (uint64_t i = b; i < en; i++) if (h_ge_p(f, buf.data() + i * f.L)) { ok.store(false); return; }
+      });
+      if (!ok.load()) return LCPC_ERR_COMMIT;
+      HIPCHK(m, hipMemcpy(reinterpret_cast<uint8_t*>(dst) + e * eb, buf.data(), ne * eb, hipMemcpyHostToDevice));
+    }
+    return 0;
+  };
+  if ((rc = upload(m->d_comm, n_comm))) return rc;
+  if (c->comm_canon) HIPCHK(m, launch_to_canon(c->NL, m->d_comm, n_comm, m->d_comm, nullptr));
+  const uint64_t n_coeffs = get64();
+  if (bad_read) return LCPC_ERR_ARG;
+  if (n_coeffs != n_rows * c->n_per_row) return LCPC_ERR_COMMIT;           // check_comm: coeffs.len() == n_rows * n_per_row
+  if ((rc = upload(m->d_coeffs, n_coeffs))) return rc;
+  m->coeffs_view = m->d_coeffs;
+  const uint64_t s_rows = get64(), s_cols = get64(), s_per_row = get64(), nh = get64();
+  if (bad_read) return LCPC_ERR_ARG;
+  if (s_rows != n_rows || s_cols != c->n_cols || s_per_row != c->n_per_row || !lcpc_dims_ok(c, s_per_row, s_cols) || nh != 2 * c->np2 - 1)
+    return LCPC_ERR_COMMIT;
+  std::vector<uint8_t> w((size_t)nh * 40), have((size_t)nh * 32);
+  for (uint64_t off = 0; off < w.size(); off += (uint64_t)64 << 20)
+    if (fn(user, w.data() + off, std::min<uint64_t>((uint64_t)64 << 20, w.size() - off))) return LCPC_ERR_ARG;
+  if (m->timing) { HIPCHK(m, hipEventRecord(m->ev[0], nullptr)); }
+  if ((rc = commit_tail(m, nullptr, nullptr))) return rc;              // hash_columns + merkle_tree from comm, on the device
+  m->committed = false;
+  HIPCHK(m, hipMemcpy(have.data(), m->d_hashes, have.size(), hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < nh; i++) {
+    uint64_t l;
+    memcpy(&l, &w[i * 40], 8);
+    if (l != 32 || memcmp(&w[i * 40 + 8], &have[i * 32], 32) != 0) return LCPC_ERR_COMMIT;
+  }
+  m->committed = true;
+  if (root) memcpy(root, &have[(size_t)(nh - 1) * 32], 32);
+  return 0;
+  LCPC_CATCH(m)
+}
+
 int lcpc_get_root(lcpc_commit_t* m, uint8_t root[32]) {
   if (!m || !root) return LCPC_ERR_ARG;
   if (!m->committed) return LCPC_ERR_STATE;

@@ -646,9 +646,15 @@ extern "C" {
 
 int lcpc_field_sum_device(lcpc_ctx* c, const uint64_t* parts, uint32_t n_parts, uint64_t n_elems, void* stream, uint64_t* out) {
   if (!c || !parts || !out || n_parts == 0) return LCPC_ERR_ARG;
-  HIPCHK(c, hipSetDevice(c->prm.device));
-  HIPCHK(c, launch_field_sum(c->NL, reinterpret_cast<const uint32_t*>(parts), n_parts, n_elems, reinterpret_cast<uint32_t*>(out),
-                             (hipStream_t)stream));
+  // stateless apart from the error text: callable from any thread while commitments of this encoder are busy, so a failure
+  // must not write c->err without the lock
+  hipError_t he = hipSetDevice(c->prm.device);
+  if (he == hipSuccess)
+    he = launch_field_sum(c->NL, reinterpret_cast<const uint32_t*>(parts), n_parts, n_elems, reinterpret_cast<uint32_t*>(out), (hipStream_t)stream);
+  if (he != hipSuccess) {
+    std::lock_guard<std::mutex> g(c->mu);
+    return fail_hip(&c->err, he, "lcpc_field_sum_device");
+  }
   return 0;
 }
 

@@ -1,5 +1,6 @@
 // lcpc_amd/csrc/encoding.cpp -- see encoding.h
 #include "encoding.h"
+#include <exception>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -471,9 +472,21 @@ bool sdig_generate(const FieldDesc& f, const SdigSpec& s, uint64_t n_per_row, ui
   pre.resize(t); post.resize(t);
   // level 0 carries most of the entries: it gets this thread (and, inside its parallel steps, all cores); the remaining
   // levels run beside its serial pass on a second thread (levels are independent streams, matgen.rs:38-49)
-  std::thread rest([&] { for (size_t i = 1; i < t; i++) gen_level(f, seed, i, pre_dims[i], post_dims[i], pre[i], post[i]); });
+  // Either thread may throw (std::bad_alloc from the level buffers): the helper's exception is carried back to this thread,
+  // and the helper is joined on every path -- a joinable std::thread must never be destroyed, and an exception escaping a
+  // thread body would call std::terminate past lcpc_ctx_create's LCPC_TRY / LCPC_CATCH
+  std::exception_ptr rest_ex;
+  std::thread rest([&] {
+    try {
+      for (size_t i = 1; i < t; i++) gen_level(f, seed, i, pre_dims[i], post_dims[i], pre[i], post[i]);
+    } catch (...) {
+      rest_ex = std::current_exception();
+    }
+  });
+  struct Join { std::thread& th; ~Join() { if (th.joinable()) th.join(); } } join{rest};
   gen_level(f, seed, 0, pre_dims[0], post_dims[0], pre[0], post[0]);
   rest.join();
+  if (rest_ex) std::rethrow_exception(rest_ex);
   return true;
 }
 

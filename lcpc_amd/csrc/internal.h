@@ -97,6 +97,7 @@ struct lcpc_ctx {
   uint64_t scratch_cap = 0;
   // RCCL communicator of a sharded encoder (lcpc_comm_init); opaque ncclComm_t
   void* comm = nullptr;
+  std::mutex xchg_mu;              // serialises the submission of collectives on `comm` (several commitments, several host threads)
   std::atomic<int> refs{1};        // the handle itself + one per live lcpc_commit
   std::string err;
   std::mutex mu;

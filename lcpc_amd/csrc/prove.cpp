@@ -116,6 +116,7 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
   const size_t a_t = 2 * nr * L, a_p = 2 * np * L;
   {
     std::lock_guard<std::mutex> g(m->mu);
+    HIPCHK(m, hipSetDevice(c->prm.device));      // the pinned arena belongs to the encoder's device, whatever this thread used last
     int rc = ensure_pinned(m, (a_t + 2 * a_p) * 8);
     if (rc) return rc;
   }

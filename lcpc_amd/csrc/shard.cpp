@@ -65,7 +65,17 @@ Rccl& rccl() {
   static Rccl r = [] {
     Rccl x;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-    x.h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);             // a copy already in the process (torch) wins
+    // a copy already in the process (torch bundles one) wins, under whatever name it was loaded: every candidate name with
+    // RTLD_NOLOAD first, then the global symbol scope (a copy loaded by full path with RTLD_GLOBAL), and only then a load
+    for (const char* n : names) {
+      if (x.h) break;
+      x.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    }
+    if (!x.h) {
+      Dl_info info;
+      void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+      if (sym && dladdr(sym, &info) && info.dli_fname) x.h = dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD);
+    }
     for (const char* n : names) {
       if (x.h) break;
       x.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -424,6 +434,9 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
   uint8_t* send = m->d_gather;
   uint8_t* recv = m->d_gather + slot_bytes * my_slots;
   if ((rc = commit_shard_phase(m, coeffs_local, n_rows_total, st, flags, send))) return rc;
+  // collectives of one communicator must be submitted in the same order on every rank: two commitments under this encoder
+  // driven from different host threads take turns here (from GroupStart to GroupEnd)
+  std::lock_guard<std::mutex> xg(c->xchg_mu);
   int nrc = rccl().GroupStart();
   if (nrc == 0) nrc = rccl().AllGather(send, recv, (size_t)slot_bytes, NCCL_UINT8, c->comm, st);
   uint32_t x = G;

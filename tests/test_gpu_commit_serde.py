@@ -1,0 +1,87 @@
+"""serde of LcCommit itself (lcpc-2d/src/lib.rs:186-268: WrappedLcCommit in bincode 1.3's default layout) -- the hand-off of a
+whole COMMITMENT between this library and the reference: the streamed bytes must be exactly what the reference's
+`Serialize for LcCommit` writes for the oracle's commitment of the same coefficients, and a commitment read back from such
+bytes must prove to the same proof bytes."""
+import io
+import struct
+
+import numpy as np
+import pytest
+
+import lcpc_amd
+from common import mk_transcript
+from lcpc_amd import LcCommit, LcpcError, LigeroEncoding, SdigEncoding, Transcript
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_bincode(oc):
+    """bincode 1.3 of WrappedLcCommit built from the oracle's fields: Vec<F> = u64 len + raw Montgomery limbs; usize = u64;
+    Vec<WrappedOutput> = u64 len + (u64 32 + 32 bytes) each."""
+    comm, coeffs, hashes = oc.comm(), oc.coeffs(), oc.hashes()
+    out = [struct.pack("<Q", comm.shape[0]), comm.tobytes(), struct.pack("<Q", coeffs.shape[0]), coeffs.tobytes(),
+           struct.pack("<QQQ", oc.n_rows, oc.n_cols, oc.n_per_row), struct.pack("<Q", hashes.shape[0])]
+    for h in hashes:
+        out.append(struct.pack("<Q", 32) + bytes(h))
+    return b"".join(out)
+
+
+CASES = [("ligero", 3, 1 << 20, None), ("ligero", 3, (1 << 16) - 77, None), ("ligero", 0, 1 << 16, None), ("ligero", 1, 1 << 14, (1, 4)),
+         ("ligero", 2, 5000, (38, 39)), ("sdig", 3, 1 << 14, None), ("sdig", 3, 1 << 20, None), ("sdig", 1, 3000, None)]
+
+
+@pytest.mark.parametrize("kind,fid,n,rho", CASES)
+def test_commit_bincode_roundtrip(oracle, kind, fid, n, rho):
+    O = oracle
+    coeffs = O.random_elems(fid, n, 77 + fid)
+    if kind == "ligero":
+        kw = dict(rho=rho) if rho else {}
+        enc, oenc = LigeroEncoding.new(fid, n, **kw), O.Encoding.ligero(fid, n, **kw)
+    else:
+        enc, oenc = SdigEncoding.new(fid, n, 5), O.Encoding.sdig(fid, n, 5)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc)
+    want = oracle_bincode(oc)
+    buf = io.BytesIO()
+    c.to_bincode(buf)
+    assert c.bincode_size() == len(want)
+    assert buf.getvalue() == want
+    # ... and back: a commitment deserialised from the reference-format bytes proves to the oracle's proof bytes
+    d = LcCommit.from_bincode(enc, io.BytesIO(want))
+    assert d.get_root() == oc.get_root() and (d.hashes() == oc.hashes()).all()
+    assert (d.comm() == oc.comm()).all() and (d.coeffs() == oc.coeffs()).all()
+    outer = O.random_elems(fid, oc.n_rows, 9)
+    root = oc.get_root()
+    pf = d.prove(outer, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+    opf, _ = oc.prove(outer, oenc, mk_transcript(O.Transcript, root, oenc.get_n_col_opens()))
+    assert pf.to_bytes() == opf
+
+
+def test_commit_bincode_rejects_bad_streams(oracle):
+    O, fid, n = oracle, 3, 1 << 12
+    coeffs = O.random_elems(fid, n, 5)
+    enc, oenc = LigeroEncoding.new(fid, n), O.Encoding.ligero(fid, n)
+    good = oracle_bincode(O.Commit.commit(coeffs, oenc))
+    nr, npr, nc = enc.get_dims(n)
+
+    def status(b):
+        with pytest.raises(LcpcError) as e:
+            LcCommit.from_bincode(enc, io.BytesIO(b))
+        return e.value.code
+
+    assert status(good[:len(good) - 1]) == lcpc_amd.ERR_ARG                                  # truncated stream
+    bad = bytearray(good); bad[8 + 40] ^= 1                                                  # a comm element: its leaf digest no longer matches
+    assert status(bytes(bad)) == lcpc_amd.ERR_COMMIT
+    bad = bytearray(good); bad[-1] ^= 1                                                      # the root digest itself
+    assert status(bytes(bad)) == lcpc_amd.ERR_COMMIT
+    bad = bytearray(good); bad[8 + 24:8 + 32] = b"\xff" * 8                                   # a limb vector >= p
+    assert status(bytes(bad)) == lcpc_amd.ERR_COMMIT
+    off_dims = 8 + nr * nc * 32 + 8 + nr * npr * 32
+    bad = bytearray(good); bad[off_dims + 8:off_dims + 16] = struct.pack("<Q", nc * 2)       # n_cols that is not the encoder's
+    assert status(bytes(bad)) == lcpc_amd.ERR_COMMIT
+    bad = bytearray(good); bad[0:8] = struct.pack("<Q", nr * nc + 1)                         # comm.len() not a multiple of n_cols
+    assert status(bytes(bad)) == lcpc_amd.ERR_COMMIT
+    # nothing is left committed after a refused stream
+    cm = LcCommit(enc)
+    with pytest.raises(LcpcError):
+        cm.get_root()

@@ -5,7 +5,13 @@
   * sampled rows of comm == oracle encode of the same coefficient row (bit-exact);
   * sampled columns: leaf digest == oracle hash of the opened column; Merkle path folds to the root;
   * linearity: columns of commit(a + b) == columns of commit(a) + columns of commit(b) (a + b formed on the GPU);
-  * prove at full size -> the *oracle's* verify accepts and returns the true evaluation."""
+  * prove at full size -> the *oracle's* verify accepts and returns the true evaluation, and (wherever the oracle holds the
+    whole commitment anyway) the proof bytes == the oracle prover's bytes on the same transcript;
+  * the reference's other two published rate series (lcpc-ligero-pc/src/tests.rs:59-98: rho = 1/4 default, 38/39 "isz") at
+    2^26 and 2^25, whole tree + proof bytes.
+A whole-tree comparison that cannot run for lack of host memory FAILS (it used to skip): a skipped comparison would silently
+downgrade a full-size parity claim to a sampled one; at 2^28 (needs ~40 GB) it runs when the host has >= 48 GB free and the
+test's last line records which of the two happened."""
 import random
 
 import numpy as np
@@ -47,18 +53,22 @@ def host_memory_available():
     return avail
 
 
-def check_whole_tree(O, c, coeffs_dev, oenc, n_threads=16):
-    """the oracle commits the same coefficients on the host; every digest of LcCommit.hashes must agree."""
+def check_whole_tree(O, c, coeffs_dev, oenc, n_threads=16, need_factor=12, must=True):
+    """the oracle commits the same coefficients on the host; every digest of LcCommit.hashes must agree.  Returns the oracle's
+    commitment (for proof-byte comparisons), or None when must=False and host memory does not allow it."""
     n = coeffs_dev.shape[0]
-    need = 12 * n * 8 * coeffs_dev.shape[1]          # coeffs (numpy + oracle copy) + comm at rate 1/2 (+ slack)
+    need = need_factor * n * 8 * coeffs_dev.shape[1]          # coeffs (numpy + oracle copy) + comm (+ slack)
     avail = host_memory_available()
     if avail is not None and avail < need + (6 << 30):
-        pytest.skip("not enough host memory for the oracle at this size (%d GB free)" % (avail >> 30))
+        if must:
+            pytest.fail("not enough host memory for the oracle's whole-tree comparison at this size (%d GB free, %d GB needed): "
+                        "the full-size parity claim cannot be checked on this box" % (avail >> 30, (need + (6 << 30)) >> 30))
+        return None
     host = coeffs_dev.cpu().numpy().view(np.uint64)
     oc = O.Commit.commit(host, oenc, n_threads=n_threads)
     assert c.get_root() == oc.get_root()
     assert (c.hashes() == oc.hashes()).all()
-    del oc
+    return oc
 
 
 def check_sampled(O, fid, enc, oenc, c, coeffs_host_rows, rnd, n_row_samples=2, n_col_samples=24):
@@ -82,20 +92,22 @@ def check_sampled(O, fid, enc, oenc, c, coeffs_host_rows, rnd, n_row_samples=2, 
     assert bytes(hashes[-1]) == root
 
 
-@pytest.mark.parametrize("log_len", [24, 26, 28])
-def test_ligero_ft255_fullsize(oracle, log_len):
-    """BASELINE configs[1] (2^24), the headline / configs[4] (2^26) and configs[3]'s commitment (2^28, here on ONE
-    GPU: 8 + 16 GiB, 33 BLAKE3 chunks per leaf, 64 KiB NTT tiles): commit + prove at full size."""
-    O, fid = oracle, 3
-    rnd = random.Random(log_len)
+def run_ligero_fullsize(O, log_len, rho, dims, linearity):
+    fid = 3
+    rnd = random.Random(log_len * 100 + rho[1])
     n = 1 << log_len
-    enc = LigeroEncoding.new(fid, n)
+    enc = LigeroEncoding.new(fid, n, rho=rho)
     nr, npr, nc = enc.get_dims(n)
-    assert (nr, npr, nc) == {24: (256, 65536, 131072), 26: (512, 131072, 262144), 28: (1024, 262144, 524288)}[log_len]
+    assert (nr, npr, nc) == dims
     coeffs = device_random_coeffs(fid, n, 5)
     c = LcCommit.commit_device(coeffs.data_ptr(), n, enc, torch.cuda.current_stream().cuda_stream)
-    oenc = O.Encoding.ligero_from_dims(fid, npr, nc)
-    rows = {r: coeffs[r * npr:(r + 1) * npr].cpu().numpy().view(np.uint64) for r in (0, rnd.randrange(nr), nr - 1)}
+    oenc = O.Encoding.ligero_from_dims(fid, npr, nc, rho=rho)
+    rows = {}
+    for r in (0, rnd.randrange(nr), nr - 1):
+        row = np.zeros((npr, 4), np.uint64)
+        chunk = coeffs[r * npr:min(n, (r + 1) * npr)].cpu().numpy().view(np.uint64)
+        row[:chunk.shape[0]] = chunk
+        rows[r] = row
     check_sampled(O, fid, enc, oenc, c, rows, rnd)
     # prove at full size; the oracle's verifier (CPU, sub-linear) must accept
     import pyref as P
@@ -112,9 +124,17 @@ def test_ligero_ft255_fullsize(oracle, log_len):
     # the evaluation equals <inner, eval_outer(outer)> recomputed by the oracle from the proof's p_eval
     ev_prod = pf.verify(root, outer, inner, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
     assert (ev_prod == ev).all()
-    if log_len > 26:
+    # whole tree, and the oracle PROVER's bytes on the same transcript (lcpc-2d/src/lib.rs:1004-1093).  2^28: ~40 GB of host
+    # memory for the oracle's commitment -- done when the box has it
+    big = log_len > 26
+    oc = check_whole_tree(O, c, coeffs, oenc, need_factor=(5 if big else 12), must=not big)
+    WHOLE_TREE_DONE[(log_len, rho)] = oc is not None
+    if oc is not None:
+        opf, _ = oc.prove(outer, oenc, mk_transcript(O.Transcript, root, oenc.get_n_col_opens()))
+        assert pf.to_bytes() == opf, "proof bytes differ from the oracle prover's"
+        del oc, opf
+    if not linearity:
         return
-    check_whole_tree(O, c, coeffs, oenc)
     # linearity of commit on sampled columns: comm(a + b) == comm(a) + comm(b), with a + b formed on the GPU
     # (lcpc_field_sum_device) and the column sums on the host (oracle field add)
     cols = [0, nc - 1] + [rnd.randrange(nc) for _ in range(8)]
@@ -138,6 +158,31 @@ def test_ligero_ft255_fullsize(oracle, log_len):
     assert not (vs.reshape(-1, 4) == a_h).all()
 
 
+WHOLE_TREE_DONE = {}
+
+
+@pytest.mark.parametrize("log_len", [24, 26, 28])
+def test_ligero_ft255_fullsize(oracle, log_len):
+    """BASELINE configs[1] (2^24), the headline / configs[4] (2^26) and configs[3]'s commitment (2^28, here on ONE
+    GPU: 8 + 16 GiB, 33 BLAKE3 chunks per leaf): commit + prove at full size, whole tree and proof bytes against the oracle."""
+    dims = {24: (256, 65536, 131072), 26: (512, 131072, 262144), 28: (1024, 262144, 524288)}[log_len]
+    run_ligero_fullsize(oracle, log_len, (1, 2), dims, linearity=log_len <= 26)
+    if log_len <= 26:
+        assert WHOLE_TREE_DONE[(log_len, (1, 2))]
+    else:
+        print("2^28 whole-tree comparison against the oracle: %s" % ("done" if WHOLE_TREE_DONE[(28, (1, 2))] else
+              "NOT done (host memory < 48 GB): rows, columns, paths and the oracle-verified proof only"))
+
+
+@pytest.mark.parametrize("log_len,rho,dims", [(26, (1, 4), (1024, 65536, 262144)), (25, (38, 39), (132, 255422, 262144))])
+def test_ligero_ft255_fullsize_other_rates(oracle, log_len, rho, dims):
+    """the reference's other two rate series at scale (lcpc-ligero-pc/src/tests.rs:59-98; doc/benchmark-results/
+    20210807_64c_255bit_ligero_{dfl,isz}.txt): rho = 1/4 at 2^26 (8 GiB of comm, 33 chunks per leaf) and rho = 38/39 at 2^25
+    (ragged last row, no zero half in the first NTT round)."""
+    run_ligero_fullsize(oracle, log_len, rho, dims, linearity=False)
+    assert WHOLE_TREE_DONE[(log_len, rho)]
+
+
 def test_brakedown_ft255_2e24(oracle):
     """BASELINE configs[2]: 101 x 166292 -> 252931, SdigCode3, seed 0."""
     O, fid = oracle, 3
@@ -157,7 +202,16 @@ def test_brakedown_ft255_2e24(oracle):
         rows[r] = row
     check_sampled(O, fid, enc, oenc, c, rows, rnd, n_col_samples=12)
     assert (c.hashes()[nc:1 << 18] == 0).all()      # Merkle padding leaves stay zero (lcpc-2d lib.rs:656-666)
-    check_whole_tree(O, c, coeffs, oenc)
+    oc = check_whole_tree(O, c, coeffs, oenc)
+    # the oracle prover's bytes on the same transcript (6593 opened columns)
+    import pyref as P
+    x = rnd.randrange(P.FIELDS[fid].p)
+    outer = powers(O, fid, x, nr, npr)
+    root = c.get_root()
+    pf = c.prove(outer, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+    opf, _ = oc.prove(outer, oenc, mk_transcript(O.Transcript, root, oenc.get_n_col_opens()))
+    assert pf.to_bytes() == opf
+    del oc, opf
     # the whole encoded matrix of the first and last 3 rows == the oracle's (the position-major commitment read back row-major)
     host = coeffs.cpu().numpy().view(np.uint64)
     for r0 in (0, nr - 3):

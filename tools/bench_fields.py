@@ -29,6 +29,12 @@ for kind in ("ligero", "sdig"):
             LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False, into=c)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
+        c.set_timing(True)
+        LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=True, into=c)
+        tm = c.timings()
+        c.set_timing(False)
         print(json.dumps({"enc": kind, "field": name, "log_len": lg, "dims": [c.n_rows, c.n_per_row, c.n_cols],
-                          "ms_per_commit": round(dt * 1e3, 3), "elems_per_s": n / dt, "GB_per_s_coeffs": round(n * 8 * L / dt / 1e9, 1)}), flush=True)
+                          "ms_per_commit": round(dt * 1e3, 3),
+                          "group_ms": {"encode": round(tm.encode_ms, 3), "hash": round(tm.hash_ms, 3), "merkle": round(tm.merkle_ms, 3),
+                                       "encode_launches": tm.encode_launches}, "elems_per_s": n / dt, "GB_per_s_coeffs": round(n * 8 * L / dt / 1e9, 1)}), flush=True)
         del c, enc, coeffs

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""tools/bench_pvs.py [max_lgl] -- the reference's own benchmark loops on the MI355X path, one JSON line per size:
+"""tools/bench_pvs.py [max_lgl] [kinds] -- the reference's own benchmark loops on the MI355X path, one JSON line per size,
+for all three published Ligero rate series (doc/benchmark-results/20210807_64c_255bit_ligero_{hlf,dfl,isz}*.txt: rho = 1/2,
+1/4 -- the timing test's default, lcpc-ligero-pc/src/tests.rs:59-69 --, 38/39) and Brakedown, up to 2^29 (tests.rs:83):
 rough_bench (lcpc-ligero-pc/src/tests.rs:80-97, lcpc-brakedown-pc/src/tests.rs:171-190: mean commit time) and
 prove_verify_size_bench (ligero tests.rs:102-170, brakedown tests.rs:98-167: mean prove time incl. bincode, mean verify
 time, bincode proof bytes) for Ft255, len = 2^lgl, lgl = 13, 15, ... as there; encoder construction outside the timed
@@ -22,9 +24,12 @@ from lcpc_amd import LcCommit, LigeroEncoding, SdigEncoding, Transcript
 N_ITERS = 10
 
 
+RHO = {"ligero": (1, 2), "ligero_hlf": (1, 2), "ligero_dfl": (1, 4), "ligero_isz": (38, 39)}
+
+
 def run(kind, lgl):
     n = 1 << lgl
-    enc = LigeroEncoding.new(3, n) if kind == "ligero" else SdigEncoding.new(3, n, 0)
+    enc = LigeroEncoding.new(3, n, rho=RHO[kind]) if kind in RHO else SdigEncoding.new(3, n, 0)
     coeffs = B.rand_coeffs(n, 4, lgl)
     st = torch.cuda.current_stream().cuda_stream
     c = LcCommit(enc)
@@ -57,9 +62,12 @@ def run(kind, lgl):
 
 
 def main():
-    max_lgl = int(sys.argv[1]) if len(sys.argv) > 1 else 27
-    for kind in ("ligero", "sdig"):
+    max_lgl = int(sys.argv[1]) if len(sys.argv) > 1 else 29
+    kinds = sys.argv[2].split(",") if len(sys.argv) > 2 else ("ligero_hlf", "ligero_dfl", "ligero_isz", "sdig")
+    for kind in kinds:
         for lgl in range(13, max_lgl + 1, 2):
+            if kind == "sdig" and lgl > 27:
+                continue                       # (the reference's Brakedown series stops at 2^27 too)
             run(kind, lgl)
 
 
