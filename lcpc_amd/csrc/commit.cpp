@@ -299,6 +299,8 @@ void lcpc_commit_destroy(lcpc_commit_t* m) {
   for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : m->ev_batch) if (e) (void)hipEventDestroy(e);
   if (m->h_pin) (void)hipHostFree(m->h_pin);
+  if (m->s_prove) (void)hipStreamDestroy(m->s_prove);
+  if (m->ev_done) (void)hipEventDestroy(m->ev_done);
   if (m->s_copy) (void)hipStreamDestroy(m->s_copy);
   if (m->s_comp) (void)hipStreamDestroy(m->s_comp);
   ctx_unref(m->enc);

@@ -140,6 +140,8 @@ struct lcpc_commit_s {
   // timing
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t s_prove = nullptr;   // sharded prove: its device steps and the native exchange, ordered behind the commit by ev_done
+  hipEvent_t ev_done = nullptr;    // recorded on the commit's stream when a sharded commit has been enqueued completely
   hipStream_t s_copy = nullptr, s_comp = nullptr;   // lcpc_commit (host pointer): H2D of row batch b+1 overlaps the NTTs of batch b
   hipEvent_t ev_batch[16] = {nullptr};
   lcpc_timings last{};
@@ -250,9 +252,15 @@ struct ShardXchg {
   uint64_t max_bytes;
   lcpc_allgather_fn fn;
   void* user;
+  bool stream_ordered = false;     // fn only ENQUEUES the all-gather on the commitment's prove stream (the native RCCL exchange):
+                                   // no host synchronisation around it; a caller-supplied fn (torch.distributed, MPI) is host-driven
 };
-int collapse_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* tensors_full, uint32_t nt, uint64_t* polys);
-int open_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* cols, uint32_t n, uint64_t* vals, uint8_t* paths);
+// every device step of a sharded prove runs on the commitment's own stream (prove_stream), ordered behind the commit by an event;
+// polys_canon (optional): to_repr of the polynomials, converted on the device; vals_pitch: bytes between the values of
+// consecutive opened columns in `vals` (0 = packed)
+int prove_stream(lcpc_commit_t* m, hipStream_t* st);
+int collapse_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* tensors_full, uint32_t nt, uint64_t* polys, uint64_t* polys_canon);
+int open_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* cols, uint32_t n, uint64_t* vals, size_t vals_pitch, uint8_t* paths);
 
 // ---- prove.cpp --------------------------------------------------------------------------------------
 int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t** proof, uint64_t* proof_len,

@@ -100,6 +100,9 @@ hipError_t launch_gather_columns(int nl, const uint32_t* comm, uint64_t n_rows, 
 // multiply), to_canon = x * R^-1 (Montgomery reduction = PrimeField::to_repr without the byte dump)
 hipError_t launch_to_mont(int nl, const uint32_t* in, uint64_t n, const uint32_t* r2, uint32_t* out, hipStream_t st);
 hipError_t launch_to_canon(int nl, const uint32_t* in, uint64_t n, uint32_t* out, hipStream_t st);
+// sharded open_column: [rank][k][rows of rank] (blocks of block_words) -> [k][all rows]; rb: G + 1 row boundaries on the device
+hipError_t launch_assemble_columns(int nl, const uint32_t* recv, uint64_t block_words, const uint64_t* rb, uint32_t G, uint32_t n,
+                                   uint64_t n_rows, uint32_t* out, hipStream_t st);
 hipError_t launch_gather_paths(const uint32_t* hashes, uint64_t np2, uint32_t path_len, const uint64_t* cols, uint32_t n,
                                uint32_t* paths, hipStream_t st);
 

@@ -926,6 +926,26 @@ __global__ void __launch_bounds__(256) gather_paths_kernel(const u32* hashes, u6
   ld8(d, hashes + (base + node) * 8);
   st8(paths + id * 8, d);
 }
+// sharded open_column: rank g's block of the all-gather holds its rows of the n opened columns as [k][rows of g]; the proof
+// wants [k][all rows].  rb[0..G]: first row of every rank (rb[G] = n_rows), device-resident.  One element per thread.
+__global__ void __launch_bounds__(256) assemble_columns_kernel(const u32* recv, u64 block_words, const u64* rb, u32 G, u32 n, u64 n_rows,
+                                                              u32 nl, u32* out) {
+  const u64 id = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (u64)n * n_rows) return;
+  const u64 k = id / n_rows, r = id % n_rows;
+  u32 g = 0;
+  while (g + 1 < G && r >= rb[g + 1]) g++;
+  const u64 nr_g = rb[g + 1] - rb[g];
+  const u32* src = recv + (u64)g * block_words + (k * nr_g + (r - rb[g])) * nl;
+  u32* dst = out + id * nl;
+  for (u32 w = 0; w < nl; w += 2) *reinterpret_cast<uint2*>(dst + w) = *reinterpret_cast<const uint2*>(src + w);
+}
+hipError_t launch_assemble_columns(int nl, const u32* recv, u64 block_words, const u64* rb, u32 G, u32 n, u64 n_rows, u32* out, hipStream_t st) {
+  const u64 tot = (u64)n * n_rows;
+  if (tot == 0) return hipSuccess;
+  hipLaunchKernelGGL(assemble_columns_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, recv, block_words, rb, G, n, n_rows, (u32)nl, out);
+  return hipGetLastError();
+}
 hipError_t launch_gather_paths(const u32* hashes, u64 np2, u32 path_len, const u64* cols, u32 n, u32* paths, hipStream_t st) {
   const u64 tot = (u64)n * path_len;
   if (tot == 0) return hipSuccess;

@@ -16,12 +16,8 @@ namespace lcpc {
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // tr.append_message(label, to_repr(poly[i])) for every coefficient (lib.rs:1045-1047, 1066-1068).  to_repr (Montgomery ->
-// canonical little-endian, lib.rs:47-57) is independent per element: prove gets it from the device with the polynomial,
-// verify converts in parallel on the host; only the STROBE absorb itself is serial.
-static void to_canon_host(const FieldDesc& f, const uint64_t* poly, uint64_t n, uint64_t* canon) {
-  const int L = f.L;
-  parallel_for(n, 4096, [&](uint64_t b, uint64_t e) { for (uint64_t i = b; i < e; i++) h_canon(f, canon + i * L, poly + i * L); });
-}
+// canonical little-endian, lib.rs:47-57) is independent per element: prove (sharded or not) gets it from the device with the
+// polynomial, verify converts in parallel on the host; only the STROBE absorb itself is serial.
 static void absorb_canon(Transcript& tr, const uint8_t* label, const FieldDesc& f, const uint64_t* canon, uint64_t n) {
   tr.append_messages(label, 6, reinterpret_cast<const uint8_t*>(canon), 8 * f.L, n);
 }
@@ -89,9 +85,7 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
   // polynomials in Montgomery form (what the proof carries) and as canonical values (what the transcript absorbs)
   auto collapse = [&](const uint64_t* tensors, uint32_t nt, uint64_t* polys, uint64_t* canon) -> int {
     if (!xchg) return collapse_host(m, tensors, nt, polys, canon);
-    int rc = collapse_sharded(m, *xchg, tensors, nt, polys);
-    if (!rc) to_canon_host(f, polys, (uint64_t)nt * c->n_per_row, canon);
-    return rc;
+    return collapse_sharded(m, *xchg, tensors, nt, polys, canon);
   };
   if (!lcpc_dims_ok(c, c->n_per_row, c->n_cols)) return LCPC_ERR_COMMIT;      // check_comm lib.rs:1015
   if (n_outer != m->n_rows) return LCPC_ERR_OUTER_TENSOR;                     // lib.rs:1016-1018
@@ -192,12 +186,7 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
   int rc;
   uint64_t* vals0 = reinterpret_cast<uint64_t*>(out.p + head + 8);           // values of column 0; column k at + k * col_bytes
   if (xchg) {
-    std::unique_ptr<uint64_t[]> vals(new uint64_t[(size_t)n_open * nr * L + 1]);
-    rc = open_sharded(m, *xchg, cols.data(), (uint32_t)n_open, vals.get(), paths.get());
-    if (!rc)
-      parallel_for(n_open, 64, [&](uint64_t b, uint64_t e) {
-        for (uint64_t k = b; k < e; k++) memcpy(out.p + head + k * col_bytes + 8, &vals[k * nr * L], nr * L * 8);
-      });
+    rc = open_sharded(m, *xchg, cols.data(), (uint32_t)n_open, vals0, col_bytes, paths.get());   // straight into the bincode slots
   } else {
     rc = open_columns_host(m, cols.data(), (uint32_t)n_open, vals0, col_bytes, paths.get());      // lib.rs:1081-1084
   }

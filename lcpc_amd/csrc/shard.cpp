@@ -99,12 +99,13 @@ int fail_nccl(std::string* err, int rc, const char* what) {
   if (err) *err = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "nccl error") ;
   return LCPC_ERR_XCHG;
 }
-// lcpc_allgather_fn on the encoder's communicator: null stream (what collapse_sharded / open_sharded use), host-synchronous
+// lcpc_allgather_fn on the encoder's communicator: enqueued on the commitment's prove stream, nothing waits on the host
 int rccl_allgather_cb(void* user, uint64_t bytes) {
   lcpc_commit_t* m = static_cast<lcpc_commit_t*>(user);
-  int rc = rccl().AllGather(m->d_xsend, m->d_xrecv, (size_t)bytes, NCCL_UINT8, m->enc->comm, nullptr);
+  std::lock_guard<std::mutex> xg(m->enc->xchg_mu);
+  int rc = rccl().AllGather(m->d_xsend, m->d_xrecv, (size_t)bytes, NCCL_UINT8, m->enc->comm, m->s_prove);
   if (rc != 0) { fail_nccl(&m->err, rc, "ncclAllGather"); return 1; }
-  return hipStreamSynchronize(nullptr) == hipSuccess ? 0 : 1;
+  return 0;
 }
 }  // namespace
 
@@ -114,82 +115,107 @@ void comm_release(lcpc_ctx* c) {
 }
 
 // ---- sharded prove pieces ---------------------------------------------------------------------------------
-// collapse over ALL rows of a sharded commitment: local partial sums, all-gather, sum mod p (lib.rs:1095-1123 split by rows)
-int collapse_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* tensors_full, uint32_t nt, uint64_t* polys) {
+// the commitment's prove stream; (re)ordered behind whatever stream the last sharded commit was enqueued on
+int prove_stream(lcpc_commit_t* m, hipStream_t* st) {
+  if (!m->s_prove) HIPCHK(m, hipStreamCreateWithFlags(&m->s_prove, hipStreamNonBlocking));
+  if (m->ev_done) HIPCHK(m, hipStreamWaitEvent(m->s_prove, m->ev_done, 0));
+  *st = m->s_prove;
+  return 0;
+}
+
+// collapse over ALL rows of a sharded commitment: local partial sums, all-gather, sum mod p (lib.rs:1095-1123 split by rows);
+// one host synchronisation, at the end, when the host needs the polynomials
+int collapse_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* tensors_full, uint32_t nt, uint64_t* polys, uint64_t* polys_canon) {
   const lcpc_ctx* c = m->enc;
   const size_t eb = elem_bytes(c);
   const int L = c->L;
   const uint64_t bytes = (uint64_t)nt * c->n_per_row * eb;
   if (bytes > x.max_bytes) return LCPC_ERR_ARG;
+  hipStream_t st = nullptr;
+  uint32_t* d_canon = nullptr;
   {
     std::lock_guard<std::mutex> g(m->mu);
     HIPCHK(m, hipSetDevice(c->prm.device));
+    int rc = prove_stream(m, &st);
+    if (rc) return rc;
+    const size_t row_b = m->n_rows_local * eb;
+    const size_t tb = ((size_t)nt * row_b + 255) & ~(size_t)255, pb = (bytes + 255) & ~(size_t)255;
+    if ((rc = ensure_scratch(m, tb + pb + collapse_scratch_bytes(m, 2) + 512))) return rc;
+    uint32_t* d_t = m->d_scratch;
+    d_canon = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(m->d_scratch) + tb);
     if (m->n_rows_local == 0) {
-      HIPCHK(m, hipMemsetAsync(x.send_dev, 0, bytes, nullptr));
+      HIPCHK(m, hipMemsetAsync(x.send_dev, 0, bytes, st));
     } else {
-      const size_t row_b = m->n_rows_local * eb;
-      const size_t tb = ((size_t)nt * row_b + 255) & ~(size_t)255;
-      int rc = ensure_scratch(m, tb + collapse_scratch_bytes(m, 2) + 512);
-      if (rc) return rc;
-      uint32_t* d_t = m->d_scratch;
       for (uint32_t t = 0; t < nt; t++)      // this rank's slice of every tensor, straight from the caller's buffer
         HIPCHK(m, hipMemcpyAsync(reinterpret_cast<uint8_t*>(d_t) + (size_t)t * row_b, tensors_full + ((size_t)t * m->n_rows + m->row_begin) * L, row_b,
-                                 hipMemcpyHostToDevice, nullptr));
-      if ((rc = collapse_run(m, d_t, nt, nullptr, reinterpret_cast<uint32_t*>(x.send_dev)))) return rc;
+                                 hipMemcpyHostToDevice, st));
+      if ((rc = collapse_run(m, d_t, nt, st, reinterpret_cast<uint32_t*>(x.send_dev)))) return rc;
     }
-    HIPCHK(m, hipStreamSynchronize(nullptr));
+    if (!x.stream_ordered) HIPCHK(m, hipStreamSynchronize(st));       // a host-driven exchange reads send_dev next
   }
   if (x.fn(x.user, bytes) != 0) return LCPC_ERR_XCHG;
   std::lock_guard<std::mutex> g(m->mu);
   HIPCHK(m, hipSetDevice(c->prm.device));
   HIPCHK(m, launch_field_sum(c->NL, reinterpret_cast<const uint32_t*>(x.recv_dev), std::max<uint32_t>(1, c->prm.shard_count), (uint64_t)nt * c->n_per_row,
-                             reinterpret_cast<uint32_t*>(x.send_dev), nullptr));
-  HIPCHK(m, hipMemcpy(polys, x.send_dev, bytes, hipMemcpyDeviceToHost));
+                             reinterpret_cast<uint32_t*>(x.send_dev), st));
+  HIPCHK(m, hipMemcpyAsync(polys, x.send_dev, bytes, hipMemcpyDeviceToHost, st));
+  if (polys_canon) {
+    HIPCHK(m, launch_to_canon(c->NL, reinterpret_cast<const uint32_t*>(x.send_dev), (uint64_t)nt * c->n_per_row, d_canon, st));
+    HIPCHK(m, hipMemcpyAsync(polys_canon, d_canon, bytes, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(m, hipStreamSynchronize(st));
   return 0;
 }
 
 // open_column for n columns of a sharded commitment: every rank gathers its rows straight into the send buffer, one
-// all-gather, columns assembled in row order on the host; the Merkle paths come from the (replicated) tree
-int open_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* cols, uint32_t n, uint64_t* vals, uint8_t* paths) {
+// all-gather, the columns are put in row order on the device and land in the caller's (strided) buffer by one copy;
+// the Merkle paths come from the (replicated) tree
+int open_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* cols, uint32_t n, uint64_t* vals, size_t vals_pitch, uint8_t* paths) {
   const lcpc_ctx* c = m->enc;
   const size_t eb = elem_bytes(c);
   const uint32_t G = std::max<uint32_t>(1, c->prm.shard_count);
   for (uint32_t i = 0; i < n; i++)
     if (cols[i] >= c->n_cols) return LCPC_ERR_COLUMN_NUMBER;
-  std::vector<uint64_t> rb(G), re(G);
+  std::vector<uint64_t> rb(G + 1);
   uint64_t max_rows = 0;
   for (uint32_t g = 0; g < G; g++) {
-    uint64_t cb, ce, nch;
-    shard_layout_of(c, g, m->n_rows, &rb[g], &re[g], &cb, &ce, &nch);
-    max_rows = std::max(max_rows, re[g] - rb[g]);
+    uint64_t re, cb, ce, nch;
+    shard_layout_of(c, g, m->n_rows, &rb[g], &re, &cb, &ce, &nch);
+    max_rows = std::max(max_rows, re - rb[g]);
+    rb[g + 1] = re;
   }
   const uint64_t bytes = (uint64_t)n * max_rows * eb;
   if (bytes > x.max_bytes) return LCPC_ERR_ARG;
+  hipStream_t st = nullptr;
+  uint32_t* d_out = nullptr;
+  uint64_t* d_rb = nullptr;
+  const size_t col_b = (size_t)m->n_rows * eb;
   {
     std::lock_guard<std::mutex> g(m->mu);
     HIPCHK(m, hipSetDevice(c->prm.device));
-    const size_t cb = (((size_t)n * 8) + 255) & ~(size_t)255, pb = (((size_t)n * c->path_len * 32) + 255) & ~(size_t)255;
-    int rc = ensure_scratch(m, cb + pb);
+    int rc = prove_stream(m, &st);
     if (rc) return rc;
-    uint64_t* d_cols = reinterpret_cast<uint64_t*>(m->d_scratch);
-    uint32_t* d_paths = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(m->d_scratch) + cb);
-    HIPCHK(m, hipMemcpyAsync(d_cols, cols, (size_t)n * 8, hipMemcpyHostToDevice, nullptr));
-    if ((rc = open_columns_device(m, d_cols, n, reinterpret_cast<uint32_t*>(x.send_dev), paths ? d_paths : nullptr, nullptr))) return rc;
-    if (paths && c->path_len) HIPCHK(m, hipMemcpyAsync(paths, d_paths, (size_t)n * c->path_len * 32, hipMemcpyDeviceToHost, nullptr));
-    HIPCHK(m, hipStreamSynchronize(nullptr));
+    const size_t cb = (((size_t)n * 8) + 255) & ~(size_t)255, pb = (((size_t)n * c->path_len * 32) + 255) & ~(size_t)255;
+    const size_t rbb = (((size_t)(G + 1) * 8) + 255) & ~(size_t)255, ob = (((size_t)n * col_b) + 255) & ~(size_t)255;
+    if ((rc = ensure_scratch(m, cb + pb + rbb + ob))) return rc;
+    uint8_t* base = reinterpret_cast<uint8_t*>(m->d_scratch);
+    uint64_t* d_cols = reinterpret_cast<uint64_t*>(base);
+    uint32_t* d_paths = reinterpret_cast<uint32_t*>(base + cb);
+    d_rb = reinterpret_cast<uint64_t*>(base + cb + pb);
+    d_out = reinterpret_cast<uint32_t*>(base + cb + pb + rbb);
+    HIPCHK(m, hipMemcpyAsync(d_cols, cols, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(m, hipMemcpyAsync(d_rb, rb.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice, st));
+    if ((rc = open_columns_device(m, d_cols, n, reinterpret_cast<uint32_t*>(x.send_dev), paths ? d_paths : nullptr, st))) return rc;
+    if (paths && c->path_len) HIPCHK(m, hipMemcpyAsync(paths, d_paths, (size_t)n * c->path_len * 32, hipMemcpyDeviceToHost, st));
+    if (!x.stream_ordered) HIPCHK(m, hipStreamSynchronize(st));
   }
   if (x.fn(x.user, bytes) != 0) return LCPC_ERR_XCHG;
-  std::vector<uint8_t> all((size_t)G * bytes);
-  {
-    std::lock_guard<std::mutex> g(m->mu);
-    HIPCHK(m, hipSetDevice(c->prm.device));
-    HIPCHK(m, hipMemcpy(all.data(), x.recv_dev, all.size(), hipMemcpyDeviceToHost));
-  }
-  for (uint32_t g = 0; g < G; g++) {
-    const uint64_t nr_g = re[g] - rb[g];
-    for (uint32_t k = 0; k < n && nr_g; k++)       // rank g's block: [k][its rows], contiguous
-      memcpy(reinterpret_cast<uint8_t*>(vals) + ((size_t)k * m->n_rows + rb[g]) * eb, &all[(size_t)g * bytes + (size_t)k * nr_g * eb], nr_g * eb);
-  }
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  HIPCHK(m, launch_assemble_columns(c->NL, reinterpret_cast<const uint32_t*>(x.recv_dev), bytes / 4, d_rb, G, n, m->n_rows, d_out, st));
+  if (vals_pitch == 0 || vals_pitch == col_b) HIPCHK(m, hipMemcpyAsync(vals, d_out, (size_t)n * col_b, hipMemcpyDeviceToHost, st));
+  else HIPCHK(m, hipMemcpy2DAsync(vals, vals_pitch, d_out, col_b, col_b, n, hipMemcpyDeviceToHost, st));
+  HIPCHK(m, hipStreamSynchronize(st));        // (also keeps `rb` and `cols` alive until their copies are done)
   return 0;
 }
 
@@ -319,6 +345,9 @@ static int commit_finish_phase(lcpc_commit_t* m, uint8_t* gathered, uint64_t n_r
     m->last.encode_launches = m->launches[0]; m->last.hash_launches = m->launches[1]; m->last.merkle_launches = m->launches[2];
   }
   m->committed = true;
+  // a prove on this commitment runs on its own stream: it waits for this point of the commit's stream
+  if (!m->ev_done) HIPCHK(m, hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
+  HIPCHK(m, hipEventRecord(m->ev_done, st));
   if (root) {
     HIPCHK(m, hipMemcpyAsync(root, m->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(m, hipStreamSynchronize(st));
@@ -496,7 +525,14 @@ int lcpc_prove_sharded_rccl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_
       m->xchg_cap = nb;
     }
   }
-  const ShardXchg x{m->d_xsend, m->d_xrecv, m->xchg_cap, rccl_allgather_cb, m};
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    hipStream_t st;
+    int rc = prove_stream(m, &st);              // the callback enqueues on m->s_prove: it must exist before the first exchange
+    if (rc) return rc;
+  }
+  ShardXchg x{m->d_xsend, m->d_xrecv, m->xchg_cap, rccl_allgather_cb, m};
+  x.stream_ordered = true;
   return prove_impl(m, outer, n_outer, trw, proof, proof_len, cols_opened, &x);
   LCPC_CATCH(m)
 }
