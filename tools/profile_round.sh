@@ -4,7 +4,7 @@
 #   bench_kernel_stats.txt    rocprofv3 --kernel-trace --stats of the same command (no CPU baseline)
 #   bench_pmc_{fetch,write,sq}.txt + pmc.json     separate --pmc passes (never combined with traces)
 #   clock_power.txt           rocm-smi sclk / socket power sampled while the bench loops
-#   configs.jsonl, c3_kernel_stats.txt, c3_dispatches.txt, c5_kernel_stats.txt, c4_rank.jsonl   the other BASELINE.json configs
+#   configs.jsonl, c3_kernel_stats.txt, c3_dispatches.txt, c3_pmc.json, c5_kernel_stats.txt, c4_rank.jsonl, fields.jsonl, pvs.jsonl   the other BASELINE.json configs, fields, the reference's loops
 # Run on the MI355X box:  gpurun -- 'bash tools/profile_round.sh r01f'
 TAG=${1:-latest}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -39,7 +39,14 @@ python $R/tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.log
 rocprofv3 --kernel-trace --stats -d $O/c3 -o c3 -- python $R/tools/bench_configs.py c3 > $O/c3.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/c3) > $O/c3_kernel_stats.txt
 python $R/tools/rocpd_dispatches.py $(db $O/c3) | tail -24 > $O/c3_dispatches.txt      # the last commit, launch by launch
+# HBM traffic and VALU counters of the Brakedown commit's kernels (separate --pmc passes, never combined with traces)
+rocprofv3 --pmc FETCH_SIZE -d $O/c3f -o c3 -- python $R/tools/bench_configs.py c3 > $O/c3f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/c3w -o c3 -- python $R/tools/bench_configs.py c3 > $O/c3w.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/c3s -o c3 -- python $R/tools/bench_configs.py c3 > $O/c3s.log 2>&1
+python $R/tools/pmc_to_json.py $(db $O/c3f) $(db $O/c3w) $O/c3_pmc.json $(db $O/c3s) > /dev/null
+rm -rf $O/c3f $O/c3w $O/c3s
 python $R/tools/bench_c4_rank.py > $O/c4_rank.jsonl 2> $O/c4_rank.log
+python $R/tools/bench_fields.py 24 > $O/fields.jsonl 2> $O/fields.log                   # all four test fields, Ligero and Brakedown, 2^24
 python $R/tools/bench_pvs.py > $O/pvs.jsonl 2> $O/pvs.log                              # the reference's rough_bench / prove_verify_size_bench loops
 rocprofv3 --kernel-trace --stats -d $O/c5 -o c5 -- python $R/tools/bench_configs.py c5 > $O/c5.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/c5) > $O/c5_kernel_stats.txt
