@@ -28,9 +28,12 @@ namespace {
 // radix-4 rounds: variants 0 w0, 1 w1, 2 w2 (plain table, w^i * 2^261) and 3, 4, 5 the same from the converting table
 // (w^i * 2^5); the radix-2 round: 0 w, 1 converting w.
 template <u32 NV> LCPC_DEV Fe29 pk_load(const u32* blk, u32 period, u32 variant, u32 jl) {
-  const uint4 a = *reinterpret_cast<const uint4*>(blk + ((size_t)(variant * 2 + 0) * period + jl) * 4);
-  const uint4 b = *reinterpret_cast<const uint4*>(blk + ((size_t)(variant * 2 + 1) * period + jl) * 4);
-  const u32 c = blk[(size_t)NV * 2 * period * 4 + (size_t)variant * period + jl];
+  // 32-bit byte offsets from the (wave-uniform) block pointer: scalar base + vector offset addressing, no 64-bit VALU adds
+  // (a class block is < 2^20 words)
+  const char* base = reinterpret_cast<const char*>(blk);
+  const uint4 a = *reinterpret_cast<const uint4*>(base + (((variant * 2 + 0) * period + jl) << 4));
+  const uint4 b = *reinterpret_cast<const uint4*>(base + (((variant * 2 + 1) * period + jl) << 4));
+  const u32 c = *reinterpret_cast<const u32*>(base + ((NV * 2 * period * 4 + variant * period + jl) << 2));
   Fe29 t;
   t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w; t.v[4] = b.x; t.v[5] = b.y; t.v[6] = b.z; t.v[7] = b.w; t.v[8] = c;
   return t;

@@ -1,5 +1,5 @@
 """Seeded random sweep of commit shapes against the oracle: field x rate x length for Ligero (every pass plan the
-planner can produce up to 2^17 columns, ragged last rows, 1..600 rows), field x code x length for Brakedown.  Each
+planner can produce up to 2^18 columns, all four fields (the specialised two-pass kernels K1s / K1n and the general kernel), ragged last rows, 1..600 rows), field x code x length for Brakedown.  Each
 case checks comm, coeffs, every digest of the tree and one collapse; a few also run prove and compare proof bytes."""
 import random
 
@@ -33,7 +33,7 @@ def test_fuzz_ligero(oracle, seed):
     for i in range(20):
         fid = rnd.choice([0, 1, 2, 3, 3, 3])
         rho = rnd.choice([(1, 2), (1, 2), (1, 4), (3, 4), (38, 39)])
-        log_n = rnd.randrange(1, 19 if fid == 3 else 15)
+        log_n = rnd.randrange(1, 19)
         n_cols = 1 << log_n
         n_per_row = max(1, min(n_cols - 1, n_cols * rho[0] // rho[1] - rnd.choice([0, 0, 1, 3])))
         max_rows = max(1, min(600, (1 << 19) // n_cols))

@@ -15,7 +15,7 @@ from lcpc_amd import LcCommit, LigeroEncoding, SdigEncoding
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 n = 1 << lg
-for kind in ("ligero", "sdig"):
+for kind in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("ligero", "sdig")):
     for fid, name, L in ((0, "ft63", 1), (1, "ft127", 2), (2, "ft191", 3), (3, "ft255", 4)):
         enc = LigeroEncoding.new(fid, n) if kind == "ligero" else SdigEncoding.new(fid, n, 0)
         coeffs = B.rand_coeffs(n, L, 7 + fid)
