@@ -28,13 +28,13 @@ from . import _lib
 
 
 def chunk_split(n_chunks, world):
-    """chunks [c_g, c_{g+1}) owned by rank g -- must match shard_layout() in csrc/lcpc_hip.cpp."""
+    """chunks [c_g, c_{g+1}) owned by rank g -- must match shard_layout_of() in csrc/shard.cpp."""
     return [(n_chunks * g // world, n_chunks * (g + 1) // world) for g in range(world)]
 
 
 def aligned_nodes(c0, c1):
     """[c0, c1) as maximal aligned power-of-two blocks [(first_chunk, log2 size)] -- must match shard_nodes()
-    in csrc/lcpc_hip.cpp (checked against lcpc_shard_nodes by tests/test_abi.py)."""
+    in csrc/shard.cpp (checked against lcpc_shard_nodes by tests/test_abi.py)."""
     out, pos = [], c0
     while pos < c1:
         l = 0
