@@ -26,7 +26,7 @@ template <> struct LnField<FT63> {
   static constexpr u32 limb(int k) { return (u32)(((((u64)Mod<2>::P[1] << 32) | Mod<2>::P[0]) >> (26 * k)) & ((1u << 26) - 1)); }
 };
 template <> struct LnField<FT127> {
-  static constexpr int FID = FT127, N = 5, W = 29, NL = 4, WAVES = 5, STRIDE = 8;
+  static constexpr int FID = FT127, N = 5, W = 29, NL = 4, WAVES = 7, STRIDE = 8;
   static constexpr u32 limb(int k) {
     const int b = 29 * k, w = b / 32, sh = b % 32;
     const u64 lo = Mod<4>::P[w], hi = (w + 1 < 4) ? Mod<4>::P[w + 1] : 0;
@@ -34,7 +34,7 @@ template <> struct LnField<FT127> {
   }
 };
 template <> struct LnField<FT191> {
-  static constexpr int FID = FT191, N = 7, W = 29, NL = 6, WAVES = 4, STRIDE = 8;
+  static constexpr int FID = FT191, N = 7, W = 29, NL = 6, WAVES = 5, STRIDE = 8;
   static constexpr u32 limb(int k) {
     const int b = 29 * k, w = b / 32, sh = b % 32;
     const u64 lo = Mod<6>::P[w], hi = (w + 1 < 6) ? Mod<6>::P[w + 1] : 0;

@@ -6,7 +6,7 @@
 // format -- here N signed limbs of W bits (field_ln.h: 3 x 26, 5 x 29, 7 x 29) --, the pass shape as template parameters,
 // twiddles from lane-order packs, normalise + clamp of the pure-sum output in one carry pass, an odd stage count peeled as
 // a radix-2 round at stage 0 where a zero-padded row needs no additions.  What the smaller fields change:
-//   * occupancy: 12 / 20 / 28 bytes of LDS per element and 64 / 96 / 128 VGPRs give 8 / 5 / 4 waves per SIMD;
+//   * occupancy: 12 / 20 / 28 bytes of LDS per element and 64 / 72 / 96 VGPRs give 8 / 7 / 5 waves per SIMD;
 //   * comm stays in Montgomery form (no canonical-output twiddle set: the column hash's per-element reduction is 2-6
 //     multiply-adds for these fields, not the 72 of Ft255);
 //   * the first pass stores values in [0, p + 64 B) < 2^(32 NL) without the final conditional subtract, the last pass
