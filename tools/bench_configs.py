@@ -51,7 +51,7 @@ def time_commit(name, enc, n, L, iters=5):
 
 
 def main():
-    which = sys.argv[1:] or ["c1", "c2", "c3", "head", "c5", "c4"]
+    which = sys.argv[1:] or ["c1", "c2", "c3", "head", "c5", "c5s", "c4"]
     if "c1" in which:
         time_commit("C1 ligero ft63 2^16", LigeroEncoding.new(0, 1 << 16), 1 << 16, 1, 20)
     if "c2" in which:
@@ -104,6 +104,36 @@ def main():
                               "collapse2_incl_copies_ms": round(t_col * 1e3, 2), "open309_incl_copies_ms": round(t_open * 1e3, 2),
                               "proof_bytes": len(pf.to_bytes())}), flush=True)
         del enc, c, coeffs
+    if "c5s" in which:
+        # the SHARDED prover's code path at world = 1 (RCCL communicator of one rank: the three all-gathers are self-copies):
+        # what the exchange plumbing of lcpc_prove_sharded_rccl costs next to the plain prover on the same commitment
+        import oracle_lib as O
+        from common import mk_transcript, powers
+        import pyref as P
+        from lcpc_amd.distributed import HipShardEngine
+        n = 1 << 26
+        nr, npr, nc = lcpc_amd.static_get_dims(3, lcpc_amd.ENC_LIGERO, n)
+        enc = LigeroEncoding.new_from_dims(3, npr, nc, shard=(0, 1))
+        eng = HipShardEngine(enc)
+        eng.comm_init()
+        coeffs = rand_coeffs(n, 4, 1)
+        x = 0x123456789abcdef % P.FT255.p
+        outer = powers(O, 3, x, nr, npr)
+        ts, tp = [], []
+        for rep in range(4):
+            root = eng.commit_native(coeffs, nr)
+            t0 = time.perf_counter()
+            data, _ = eng.prove_native(outer, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+            t1 = time.perf_counter()
+            pf = eng.cm.prove(outer, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+            t2 = time.perf_counter()
+            assert pf.to_bytes() == data
+            if rep:
+                ts.append(t1 - t0); tp.append(t2 - t1)
+        print(json.dumps({"config": "C5 prove through the sharded path, world = 1 (RCCL self-exchange), ft255 2^26",
+                          "sharded_prove_ms": round(sum(ts) / len(ts) * 1e3, 2), "sharded_prove_min_ms": round(min(ts) * 1e3, 2),
+                          "plain_prove_same_commit_ms": round(sum(tp) / len(tp) * 1e3, 2), "proof_bytes_equal": True}), flush=True)
+        del eng, enc, coeffs
     if "c4" in which:
         torch.cuda.empty_cache()
         time_commit("C4-on-1-GPU ligero ft255 2^28", LigeroEncoding.new(3, 1 << 28), 1 << 28, 4, 3)
