@@ -517,6 +517,14 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
   c->n_per_row = npr;
   c->n_cols = sdig_codeword_length(c->pre_dims, c->post_dims);
   if (p->n_per_row && p->n_cols && p->n_cols != c->n_cols) return LCPC_ERR_DIMS;   // new_from_dims assert
+  uint32_t* d_rprime = nullptr;          // R' = 2^(N W) mod p as a plain integer (Ft127 / Ft191 limb form)
+  if ((f->L == 2 || f->L == 3) && !getenv("LCPC_SDIG_WIDE")) {
+    uint64_t rp[MAXL] = {1, 0, 0, 0};
+    for (int i = 0; i < ntt_lns_limbs(c->NL) * ntt_lns_limb_bits(c->NL); i++) h_add(*f, rp, rp, rp);
+    if ((rc = dev_alloc(err, &d_rprime, 8 * f->L))) return rc;
+    HIPCHK(c, hipMemcpy(d_rprime, rp, 8 * f->L, hipMemcpyHostToDevice));
+  }
+  struct FreeRp { uint32_t*& p; ~FreeRp() { if (p) { (void)hipDeviceSynchronize(); dev_free(p); p = nullptr; } } } free_rp{d_rprime};
   auto upload = [&](const CsrMatrix& m, DevCsr& d) -> int {
     d.n_in = m.n_in; d.n_out = m.n_out;
     int r;
@@ -531,6 +539,13 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       if ((r = dev_alloc(err, &d.vals29, (nnz + 1) * 48))) return r;
       HIPCHK(c, launch_to_r29(d.vals, nnz, d.vals29, nullptr));
       HIPCHK(c, hipMemsetAsync(d.vals29 + nnz * 12, 0, 48, nullptr));      // one entry of slack for the one-ahead prefetch
+    } else if ((f->L == 2 || f->L == 3) && d_rprime) {
+      // Ft127 / Ft191: values as 5 / 7 limbs of 29 bits in the R'-Montgomery form (ln::lazy_mac), v R' mod p = mont_mul(v R, R')
+      const size_t nnz = m.colidx.size();
+      const size_t stride = (size_t)ntt_lns_stride(c->NL);
+      if ((r = dev_alloc(err, &d.vals29, (nnz + 1) * stride * 4))) return r;
+      HIPCHK(c, launch_ntt_lns_roots(c->NL, d.vals, nnz, d_rprime, d.vals29, nullptr));
+      HIPCHK(c, hipMemsetAsync(d.vals29 + nnz * stride, 0, stride * 4, nullptr));
     }
     return 0;
   };

@@ -151,6 +151,59 @@ template <class FT> LCPC_DEV LN<FT::N> mul(const LN<FT::N>& a, const LN<FT::N>& 
   else ln_mul1s_ft191(a.v, w.v, r.v);
   return r;
 }
+// ---- carry-free lazy dot product (Brakedown SpMM for Ft127 / Ft191): field_dev.h's lazy29_* for N limbs of W bits ------
+// acc += x * v with x, v as N unsigned W-bit limbs (x: a packed element < p split by from_packed; v: a matrix value in the
+// R'-Montgomery form, v R' mod p): N^2 v_mad_u64_u32 into 2N u64 columns, no carries.  A column receives <= N products
+// < 2^(2W) per term: 6 terms fit (6 * 7 * 2^58 < 2^64) before lazy_normalize() must move the excess up; the value is
+// Montgomery-reduced once per <= 60 terms: (sum + m p) / R' < 60 p^2 / R' + p < 2p since R' / p > 2^12.
+template <class FT> struct LazyN {
+  u64 c[2 * FT::N];
+};
+template <class FT> LCPC_DEV void lazy_zero(LazyN<FT>& a) {
+#pragma unroll
+  for (int k = 0; k < 2 * FT::N; k++) a.c[k] = 0;
+}
+template <class FT> LCPC_DEV void lazy_mac(LazyN<FT>& a, const LN<FT::N>& x, const LN<FT::N>& v) {
+#pragma unroll
+  for (int i = 0; i < FT::N; i++)
+#pragma unroll
+    for (int j = 0; j < FT::N; j++) a.c[i + j] += (u64)x.v[i] * v.v[j];
+}
+template <class FT> LCPC_DEV void lazy_normalize(LazyN<FT>& a) {
+#pragma unroll
+  for (int k = 0; k + 1 < 2 * FT::N; k++) {
+    a.c[k + 1] += a.c[k] >> FT::W;
+    a.c[k] &= (1u << FT::W) - 1;
+  }
+}
+// value / R' mod p, fully reduced, packed
+template <class FT> LCPC_DEV Fe<FT::NL> lazy_reduce(LazyN<FT>& a) {
+  constexpr int N = FT::N, W = FT::W;
+  constexpr u32 M = (1u << W) - 1;
+  lazy_normalize<FT>(a);
+  u32 m[N], r[N];
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * N; k++) {
+    acc += a.c[k];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int j = k - i;
+      if (i < k && j >= 1 && j < N) acc += (u64)m[i] * FT::limb(j);
+    }
+    if (k < N) {
+      m[k] = (0u - (u32)acc) & M;          // p == 1 mod 2^W: the quotient digit is a negate-and-mask
+      acc += m[k];
+      acc >>= W;
+    } else {
+      r[k - N] = (u32)acc & M;
+      acc >>= W;
+    }
+  }
+  u32 t[FT::NL];
+  to_packed<FT>(t, r);
+  return fe_reduce_once<FT::NL>(t, 0u);    // < 2p < 2^(32 NL)
+}
 }  // namespace ln
 
 }  // namespace lcpc

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "field_dev.h"
 #include "ntt_l9_dev.h"
+#include "field_ln.h"
 #include "blake3_dev.h"
 #include <algorithm>
 
@@ -1169,15 +1170,54 @@ __device__ __forceinline__ Fe<NL> spmm_t_terms(const SpmmTArgs& a, const u32* xi
       res = fe_add<NL>(res, lazy29_reduce(acc));
     }
   } else {
-    for (u32 kb = k0; kb < k1; kb += 8) {
-      Wide<NL> w = wide_zero<NL>();
-      const u32 ke = kb + 8 < k1 ? kb + 8 : k1;
-      for (u32 k = kb; k < ke; k++) {
-        const u32 col = __builtin_amdgcn_readfirstlane(a.colidx[k]);
-        const Fe<NL> v = fe_load<NL>(a.vals + (size_t)k * NL);
-        wide_mac<NL>(w, v, fe_load<NL>(xin + (size_t)col * pstride));
+    bool done = false;
+    if constexpr (NL == 4 || NL == 6) {
+      if (a.vals29 != nullptr) {
+        done = true;
+        // Ft127 / Ft191: the same carry-free limb dot product on 5 / 7 limbs of 29 bits (field_ln.h); matrix values in the
+        // R'-Montgomery limb form (8-word stride), read as scalar loads like the Ft255 stream above
+        using FT = LnField<NL == 4 ? FT127 : FT191>;
+        constexpr int N = FT::N;
+        const ConstU32* cidx = (const ConstU32*)a.colidx;
+        const ConstU32* cvl = (const ConstU32*)a.vals29;
+        for (u32 kb = k0; kb < k1; kb += 60) {
+          const u32 ke = kb + 60 < k1 ? kb + 60 : k1;
+          ln::LazyN<FT> acc;
+          ln::lazy_zero<FT>(acc);
+          u32 since = 0;
+          Fe<NL> x = fe_load<NL>(xin + (size_t)cidx[kb] * pstride);
+          u32 cn = cidx[kb + 1 < ke ? kb + 1 : kb];
+          LN<N> v;
+#pragma unroll
+          for (int i = 0; i < N; i++) v.v[i] = cvl[(size_t)kb * FT::STRIDE + i];
+          for (u32 k = kb; k < ke; k++) {
+            Fe<NL> xn = x;
+            if (k + 1 < ke) xn = fe_load<NL>(xin + (size_t)cn * pstride);
+            const u32 kn = k + 1 < ke ? k + 1 : k, kn2 = k + 2 < ke ? k + 2 : k;
+            cn = cidx[kn2];
+            LN<N> vn;
+#pragma unroll
+            for (int i = 0; i < N; i++) vn.v[i] = cvl[(size_t)kn * FT::STRIDE + i];
+            ln::lazy_mac<FT>(acc, ln::from_packed<FT>(x), v);
+            v = vn;
+            if (++since == 6) { ln::lazy_normalize<FT>(acc); since = 0; }
+            x = xn;
+          }
+          res = fe_add<NL>(res, ln::lazy_reduce<FT>(acc));
+        }
       }
-      res = fe_add<NL>(res, wide_reduce<NL>(w));
+    }
+    if (!done) {
+      for (u32 kb = k0; kb < k1; kb += 8) {
+        Wide<NL> w = wide_zero<NL>();
+        const u32 ke = kb + 8 < k1 ? kb + 8 : k1;
+        for (u32 k = kb; k < ke; k++) {
+          const u32 col = __builtin_amdgcn_readfirstlane(a.colidx[k]);
+          const Fe<NL> v = fe_load<NL>(a.vals + (size_t)k * NL);
+          wide_mac<NL>(w, v, fe_load<NL>(xin + (size_t)col * pstride));
+        }
+        res = fe_add<NL>(res, wide_reduce<NL>(w));
+      }
     }
   }
   return res;

@@ -52,7 +52,7 @@ def test_fuzz_brakedown(oracle, seed):
     O = oracle
     rnd = random.Random(2000 + seed)
     for i in range(6):
-        fid = rnd.choice([0, 1, 3, 3])
+        fid = rnd.choice([0, 1, 2, 3, 3])
         code = rnd.randrange(1, 7)
         n_per_row = rnd.randrange(60, 3000)
         n_rows = rnd.choice([1, 2, 7, 15, 16, 17, 23, 24, 25, 40, 64, 65, 90, 130])

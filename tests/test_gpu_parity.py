@@ -373,7 +373,7 @@ def test_commit_device_ragged(oracle, kind, fid, n, rho):
                                                             (3, 1200, 65, 11, 3)])
 def test_brakedown_many_rows_vs_oracle(oracle, fid, n_per_row, n_rows, seed, code):
     """>= 24 rows selects the position-major SpMM path (lane = row, wave-uniform matrix entries, R29 lazy dot
-    products for Ft255 / wide accumulators otherwise), fewer the row-major path with lanes over outputs and terms: every
+    products for Ft255, the 5- / 7-limb ones of field_ln.h for Ft127 / Ft191, wide accumulators for Ft63), fewer the row-major path with lanes over outputs and terms: every
     field, both sides of that threshold, row counts that are not multiples of the 128-lane row block, of its 64-lane waves
     (row-less waves leave early) or of the 32x32 transpose tile, a ragged last row."""
     O = oracle
@@ -511,3 +511,32 @@ def test_matgen_encode_full_length_input(oracle, n_rows):
             exp = oenc.encode(xi[r].copy())
             assert (got[r] == exp).all(), (n, r)
             assert (got[r, :n] == xi[r, :n]).all()                  # systematic part untouched
+
+
+@pytest.mark.parametrize("fid,n_per_row,n_rows", [(1, 40000, 101), (2, 40000, 72), (1, 3000, 130), (2, 2500, 64)])
+def test_brakedown_limb_dot_product_small_fields(oracle, fid, n_per_row, n_rows):
+    """Ft127 / Ft191 on the position-major path accumulate their dot products carry-free on 5 / 7 limbs of 29 bits
+    (field_ln.h lazy_mac, matrix values in the R'-Montgomery limb form) like Ft255's lazy29: a level wide enough for the
+    4-outputs-per-workgroup kernel and sliced ones, random rows plus rows of all p-1 (every product at its largest), against
+    the oracle and against the wide-accumulator path (LCPC_SDIG_WIDE=1)."""
+    import os
+    import pyref as P
+    O = oracle
+    F = P.FIELDS[fid]
+    oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 21, 3)
+    _, _, n_cols = oenc.get_dims(n_per_row)
+    n = n_per_row * n_rows - 5
+    coeffs = O.random_elems(fid, n, 71)
+    coeffs[:2 * n_per_row] = O.to_mont(fid, [F.p - 1])[0]          # two rows of p - 1
+    enc = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 21, 3)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+    assert (c.comm() == oc.comm()).all()
+    assert (c.hashes() == oc.hashes()).all() and c.get_root() == oc.get_root()
+    os.environ["LCPC_SDIG_WIDE"] = "1"
+    try:
+        enc_w = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 21, 3)
+    finally:
+        del os.environ["LCPC_SDIG_WIDE"]
+    w = LcCommit.commit(coeffs, enc_w)
+    assert w.get_root() == c.get_root() and (w.hashes() == c.hashes()).all()
