@@ -1,6 +1,6 @@
 // lcpc_amd/csrc/ntt_lns.hip -- K1n: the shape-specialised lazy-limb row NTT for Ft63 / Ft127 / Ft191
 // (LcEncoding::encode for Ligero, lcpc-ligero-pc/src/lib.rs:162-164 = fffft fft_io_pc [3P]; the reference benches Ft127
-// besides Ft255: lcpc-ligero-pc/src/bench.rs:178-204), for the two-pass plans on 1024-element tiles (2^11 <= n_cols <= 2^18).
+// besides Ft255: lcpc-ligero-pc/src/bench.rs:178-204), for the two-pass plans on 1024-element tiles (2^11 <= n_cols <= 2^20).
 //
 // The structure is that of K1s (ntt_l9s.hip, Ft255): radix-4 DIF rounds on a tile that lives in LDS in the multiplier's own
 // format -- here N signed limbs of W bits (field_ln.h: 3 x 26, 5 x 29, 7 x 29) --, the pass shape as template parameters,
@@ -350,7 +350,15 @@ template <class FT> hipError_t launch_pass_f(const NttPassArgs& a, bool first, c
     default: break;                                    \
   }
 
-bool ntt_lns_supported(int nl, uint32_t log_n) { return (nl == 2 || nl == 4 || nl == 6) && log_n >= 11 && log_n <= 18; }
+// n_cols up to 2^19 (Ft63) / 2^20 (Ft127, Ft191): measured against the general kernel's three-pass plans on 2^25-element
+// matrices (round 3): 2^19 columns 0.73 / 1.43 / 2.30 ms against 0.76 / 1.63 / 2.90; 2^20 columns 1.97 / 2.26 ms against
+// 2.02 / 3.26 for Ft127 / Ft191, while Ft63's 8-byte first-pass runs lose there (1.08 against 0.79 ms).
+// LCPC_NTT_LNS_MAXK lowers the bound (A/B).
+bool ntt_lns_supported(int nl, uint32_t log_n) {
+  const char* ev = getenv("LCPC_NTT_LNS_MAXK");
+  const uint32_t maxk = ev ? (uint32_t)atoi(ev) : 20;
+  return (nl == 2 || nl == 4 || nl == 6) && log_n >= 11 && log_n <= maxk && log_n <= (nl == 2 ? 19u : 20u);
+}
 int ntt_lns_limbs(int nl) { return nl == 2 ? 3 : (nl == 4 ? 5 : (nl == 6 ? 7 : 0)); }
 int ntt_lns_limb_bits(int nl) { return nl == 2 ? 26 : 29; }
 int ntt_lns_stride(int nl) { return nl == 2 ? 4 : 8; }

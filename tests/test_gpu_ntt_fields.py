@@ -1,5 +1,5 @@
 """K1n (ntt_lns.hip): the shape-specialised lazy-limb row NTT of Ft63 / Ft127 / Ft191 -- two-pass plans on 1024-element
-tiles, n_cols = 2^11 .. 2^18 wherever the general plan needs more than one pass.  For each: commit (coeffs copy fused into
+tiles, n_cols = 2^11 .. 2^20 wherever the general plan needs more than one pass.  For each: commit (coeffs copy fused into
 pass 1, ragged last row) and encode_rows against the oracle at the rates the reference uses (1/2, 1/4, 38/39) and 3/4; the
 general kernel (LCPC_NTT_GENERAL=1) must give the same bytes; inputs that push the signed lazy-limb bounds (all p-1,
 saturated limbs, alternating 0 / p-1)."""
@@ -45,6 +45,24 @@ def test_commit_all_two_pass_shapes_small_fields(oracle, fid, log_n, rate):
     rows[:n_per_row] = coeffs[n_per_row:2 * n_per_row]
     rows[n_cols:n_cols + (n - 2 * n_per_row)] = coeffs[2 * n_per_row:]
     assert (enc.encode(rows) == oc.comm()[n_cols:]).all()
+
+
+@pytest.mark.parametrize("fid,log_n", [(0, 19), (1, 19), (1, 20), (2, 19), (2, 20)])
+@pytest.mark.parametrize("rate", ["1/2", "38/39"])
+def test_commit_long_rows_small_fields(oracle, fid, log_n, rate):
+    """2^19 / 2^20 columns: first passes of 9 / 10 stages whose runs are 2 / 1 elements (still ahead of the general kernel's
+    three-pass plan there, except Ft63 at 2^20, which stays on it)"""
+    O = oracle
+    n_cols = 1 << log_n
+    n_per_row, rho = {"1/2": (n_cols // 2, (1, 2)), "38/39": (n_cols * 38 // 39, (38, 39))}[rate]
+    n = n_per_row + n_per_row // 5
+    coeffs = O.random_elems(fid, n, log_n + fid)
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, rho=rho)
+    oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols, rho=rho)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+    assert c.get_root() == oc.get_root() and (c.hashes() == oc.hashes()).all()
+    assert (c.comm() == oc.comm()).all() and (c.coeffs() == oc.coeffs()).all()
 
 
 @pytest.mark.parametrize("fid,log_n", [(0, 13), (0, 16), (0, 18), (1, 12), (1, 16), (2, 11), (2, 17)])
