@@ -26,7 +26,7 @@ static void ctx_free(lcpc_ctx* c) {
   (void)hipSetDevice(c->prm.device);
   comm_release(c);
   dev_free(c->d_pack[0]); dev_free(c->d_pack[1]);
-  dev_free(c->d_rootsl); dev_free(c->d_qpl); dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
+  dev_free(c->d_rootsl); dev_free(c->d_rootslc); dev_free(c->d_qpl); dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
   dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->ws.d_mid); dev_free(c->d_scratch);
   if (c->h_varena) (void)hipHostFree(c->h_varena);
   for (auto* v : {&c->d_pre, &c->d_post})
@@ -149,6 +149,8 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.src = first ? j.src : j.dst;
       a.dst = j.dst;
       a.roots = c->d_roots; a.roots29 = c->d_rootsl; a.qp29 = c->d_qpl;
+      a.roots29c = j.canon_out ? c->d_rootslc : nullptr;
+      a.mont_prefix = (j.canon_out && !first) ? 4u : 0u;       // the last pass ends with a radix-4 round (10 stages)
       a.src_stride = first ? j.src_stride : c->n_cols;
       a.dst_stride = c->n_cols;
       a.n_valid = first ? j.n_valid : c->n_cols;
@@ -478,20 +480,26 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
         }
       }
       const size_t n_roots = (size_t)1 << (k - 1);
-      uint32_t* d_rp = nullptr;
+      uint64_t rpc[MAXL];
+      h_canon(*f, rpc, rp);                                    // R' R^-1 mod p: the converting table is w^i R' R^-1 = mont_mul(w^i R, R' R^-1)
+      uint32_t *d_rp = nullptr, *d_rpc = nullptr;
       if ((rc = dev_alloc(err, &d_rp, 8 * f->L))) return rc;
-      if ((rc = dev_alloc(err, &c->d_rootsl, n_roots * stride * 4)) || (rc = dev_alloc(err, &c->d_qpl, tab.size() * 4))) { dev_free(d_rp); return rc; }
+      if ((rc = dev_alloc(err, &d_rpc, 8 * f->L))) { dev_free(d_rp); return rc; }
+      if ((rc = dev_alloc(err, &c->d_rootsl, n_roots * stride * 4)) || (rc = dev_alloc(err, &c->d_rootslc, n_roots * stride * 4)) ||
+          (rc = dev_alloc(err, &c->d_qpl, tab.size() * 4))) { dev_free(d_rp); dev_free(d_rpc); return rc; }
       hipError_t he = hipMemcpy(d_rp, rp, 8 * f->L, hipMemcpyHostToDevice);
+      if (he == hipSuccess) he = hipMemcpy(d_rpc, rpc, 8 * f->L, hipMemcpyHostToDevice);
       if (he == hipSuccess) he = hipMemcpy(c->d_qpl, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
       if (he == hipSuccess) he = launch_ntt_lns_roots(c->NL, c->d_roots, n_roots, d_rp, c->d_rootsl, nullptr);
+      if (he == hipSuccess) he = launch_ntt_lns_roots(c->NL, c->d_roots, n_roots, d_rpc, c->d_rootslc, nullptr);
       if (he == hipSuccess) he = hipDeviceSynchronize();
-      dev_free(d_rp);
+      dev_free(d_rp); dev_free(d_rpc);
       if (he != hipSuccess) return fail_hip(err, he, "ntt_lns tables");
       for (int i = 0; i < 2; i++) {
         const Pass& ps = c->passes[i];
         const bool first = i == 0;
         NttPassArgs a{};
-        a.roots29 = c->d_rootsl; a.log_n = k; a.t0 = ps.t0; a.s = ps.s; a.log_tj = ps.log_tj;
+        a.roots29 = c->d_rootsl; a.roots29c = c->d_rootslc; a.log_n = k; a.t0 = ps.t0; a.s = ps.s; a.log_tj = ps.log_tj;
         c->pack_info[i] = ntt_lns_pack_info(c->NL, ps.s, first);
         const uint32_t n_classes = first ? 1u << (k - 10) : 1u;
         if ((rc = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return rc;
@@ -499,6 +507,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       }
       HIPCHK(c, hipDeviceSynchronize());
       c->lns = true;
+      c->comm_canon = !getenv("LCPC_COMM_MONT");               // commits keep comm canonical on the device, as for Ft255
     }
     return 0;
   }

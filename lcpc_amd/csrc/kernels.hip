@@ -494,11 +494,11 @@ __device__ __forceinline__ void leaf_build_block(u32 m[16], const LeafRaw<NL, PH
 #pragma unroll
   for (int p = 0; p < 16; p++) m[p] = c[(PH + p) / NL].v[(PH + p) % NL];
 }
-template <int NL, int PH>
+template <int NL, int PH, bool CANON = false>
 __device__ __forceinline__ void leaf_fill_block(u32 m[16], const LeafArgs& a, u64 col, int64_t row0) {
   LeafRaw<NL, PH> r;
   leaf_load_raw<NL, PH>(r, a, col, row0);
-  leaf_build_block<NL, PH>(m, r);
+  leaf_build_block<NL, PH, CANON>(m, r);
 }
 
 template <int NL, bool CANON = false>
@@ -540,9 +540,9 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
       int ph;
       const int64_t row0 = block_row0(b, ph);
       u32 m[16];
-      if (ph == 0) leaf_fill_block<NL, 0>(m, a, col, row0);
-      else if (ph == 2) leaf_fill_block<NL, 2>(m, a, col, row0);
-      else leaf_fill_block<NL, 4>(m, a, col, row0);
+      if (ph == 0) leaf_fill_block<NL, 0, CANON>(m, a, col, row0);
+      else if (ph == 2) leaf_fill_block<NL, 2, CANON>(m, a, col, row0);
+      else leaf_fill_block<NL, 4, CANON>(m, a, col, row0);
       const u32 rem = chunk_len - 64 * b;
       const u32 blen = rem < 64 ? rem : 64;
       u32 flags = (b == 0 ? B3_CHUNK_START : 0u);
@@ -559,8 +559,13 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
 static hipError_t launch_leaf_chunks_slice(int nl, const LeafArgs& a, hipStream_t st) {
   dim3 grid((unsigned)((a.n_cols + 255) / 256), a.n_chunks_local);
   if (a.canon_in) {
-    if (nl != 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((leaf_chunk_kernel<8, true>), grid, dim3(256), 0, st, a);
+    switch (nl) {
+      case 2: hipLaunchKernelGGL((leaf_chunk_kernel<2, true>), grid, dim3(256), 0, st, a); break;
+      case 4: hipLaunchKernelGGL((leaf_chunk_kernel<4, true>), grid, dim3(256), 0, st, a); break;
+      case 6: hipLaunchKernelGGL((leaf_chunk_kernel<6, true>), grid, dim3(256), 0, st, a); break;
+      case 8: hipLaunchKernelGGL((leaf_chunk_kernel<8, true>), grid, dim3(256), 0, st, a); break;
+      default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
   }
   switch (nl) {

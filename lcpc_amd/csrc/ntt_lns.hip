@@ -7,8 +7,10 @@
 // twiddles from lane-order packs, normalise + clamp of the pure-sum output in one carry pass, an odd stage count peeled as
 // a radix-2 round at stage 0 where a zero-padded row needs no additions.  What the smaller fields change:
 //   * occupancy: 12 / 20 / 28 bytes of LDS per element and 64 / 72 / 96 VGPRs give 8 / 7 / 5 waves per SIMD;
-//   * comm stays in Montgomery form (no canonical-output twiddle set: the column hash's per-element reduction is 2-6
-//     multiply-adds for these fields, not the 72 of Ft255);
+//   * canonical output as in K1s (a.roots29c != null, the commit paths): butterflies in "block 0" -- the elements no
+//     twiddle has touched yet -- take their twiddles from the converting set w^i R' R^-1, everything else is canonical
+//     already, the 4 elements per row that only meet trivial twiddles are reduced at the store; the column hash then
+//     reads comm as it is (its per-element Montgomery reduction was 16-28 % of the leaf kernel for these fields);
 //   * the first pass stores values in [0, p + 64 B) < 2^(32 NL) without the final conditional subtract, the last pass
 //     subtracts under a wave-level __any (Ft63 / Ft127: most waves; Ft191: rarely).
 // Exact modular arithmetic: any stage grouping gives the same fully-reduced bits as the reference's radix-2 loop.
@@ -120,6 +122,8 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
   }
   __syncthreads();
   const u32* cls_pack = pack + (size_t)(FIRST ? tile : 0u) * pi.class_words;
+  const bool canon = a.roots29c != nullptr;
+  const bool blk0_tile = FIRST || tile == 0;                 // tiles that hold elements of "block 0" (never multiplied so far)
   const bool zero_hi = FIRST && a.n_valid <= (1ull << (k - 1));
 
   if constexpr (SH::U0 == 1) {
@@ -129,7 +133,7 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
 #pragma unroll
     for (u32 pp = 0; pp < 2; pp++) {
       const u32 e1 = tid + 256u * pp;                        // slots with the top stage bit clear are [0, half)
-      const E w = planes_get<FT>(blk, SH::period2, e1);
+      const E w = planes_get<FT>(blk, 2 * SH::period2, (canon ? SH::period2 : 0u) + e1);   // stage 0 is all block 0
       const E x = planes_get<FT>(lds, T, e1);
       if (zero_hi) {
         planes_put<FT>(lds, T, e1 + half, ln::mul<FT>(x, w));         // (x, 0) -> (x, x w)
@@ -158,21 +162,24 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
     const u32 jl = q & (period - 1);
     const u32* blk = cls_pack + pi.round_off[SH::U0 + r];
     if (u == 0 && zero_hi) {
-      // zero-padded first round (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x w); inputs < 4p
-      const E w0 = planes_get<FT>(blk, 3 * period, jl), w2 = planes_get<FT>(blk, 3 * period, 2 * period + jl);
+      // zero-padded first round (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x w); inputs < 4p; everything
+      // is block 0, so with canonical output the multiplies leaving it (w0, w1, and w2 for c1) take the converting set
+      const u32 vb = canon ? 3u : 0u;
+      const E w0 = planes_get<FT>(blk, 6 * period, (vb + 0) * period + jl), w2c = planes_get<FT>(blk, 6 * period, (vb + 2) * period + jl);
+      const E w2 = planes_get<FT>(blk, 6 * period, 2 * period + jl);
       if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
         const E x0 = planes_get<FT>(lds, T, e0);
-        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(x0, w2));
+        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(x0, w2c));
         const E b2 = ln::mul<FT>(x0, w0);
         planes_put<FT>(lds, T, e0 + 2 * dq, b2);
         planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(b2, w2));
       } else {
-        const E w1 = planes_get<FT>(blk, 3 * period, period + jl);
+        const E w1 = planes_get<FT>(blk, 6 * period, (vb + 1) * period + jl);
         const E x0 = planes_get<FT>(lds, T, e0), x1 = planes_get<FT>(lds, T, e0 + dq);
         E c0 = ln::add(x0, x1);
         ln::normalize<FT>(c0);
         planes_put<FT>(lds, T, e0, c0);
-        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(x0, x1), w2));
+        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(x0, x1), w2c));
         const E b2 = ln::mul<FT>(x0, w0), b3 = ln::mul<FT>(x1, w1);                          // (-p - eps, eps]
         E c2 = ln::add(b2, b3);
         ln::normalize<FT>(c2);
@@ -202,9 +209,16 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
       planes_put<FT>(lds, T, e0 + 2 * dq, c2);
       planes_put<FT>(lds, T, e0 + 3 * dq, c3);
     } else {
-      const E w0 = planes_get<FT>(blk, 3 * period, jl), w1 = planes_get<FT>(blk, 3 * period, period + jl);
-      const E w2 = planes_get<FT>(blk, 3 * period, 2 * period + jl);
-      planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(b0, b1), w2));                          // in: |value| < 16p
+      // block 0 of stages (u, u + 1) = the quads whose elements all lie below n / 2^(t + 2): exactly q < period in the tiles
+      // that hold block 0.  Their three multiplies that leave block 0 take the converting set; c0 stays a pure sum; c3's
+      // inputs b2, b3 are already canonical
+      const bool blk0c = canon && blk0_tile && q < period;
+      const u32 vb = blk0c ? 3u : 0u;
+      // (c1's twiddle is fetched on its own: the one select instead of two live twiddle sets keeps Ft191 inside 96 VGPRs)
+      const E w2c1 = planes_get<FT>(blk, 6 * period, (blk0c ? 5u : 2u) * period + jl);
+      planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(b0, b1), w2c1));                        // in: |value| < 16p
+      const E w0 = planes_get<FT>(blk, 6 * period, (vb + 0) * period + jl), w1 = planes_get<FT>(blk, 6 * period, (vb + 1) * period + jl);
+      const E w2 = planes_get<FT>(blk, 6 * period, 2 * period + jl);
       const E b2 = ln::mul<FT>(ln::sub(x0, x2), w0);                                              // in: |value| < 8p
       const E b3 = ln::mul<FT>(ln::sub(x1, x3), w1);
       E c2 = ln::add(b2, b3);                                                                     // (-2p - 2 eps, 2 eps]
@@ -231,6 +245,7 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
 #pragma unroll
         for (int i = 0; i < NL; i++) v.v[i] = w[i];
       }
+      if (tile == 0 && g < a.mont_prefix) v = fe_canon<NL>(v);          // canonical output: the never-multiplied prefix
     } else {
 #pragma unroll
       for (int i = 0; i < NL; i++) v.v[i] = w[i];
@@ -256,7 +271,8 @@ __global__ void __launch_bounds__(256) ntt_lns_pack_kernel(NttPassArgs a, NttPac
       const u32 lp = jl & ((1u << LBT) - 1), i = jl >> LBT;
       const u32 g1 = (i << lb) | lo | lp;
       const u32 gm = (1u << (k - t0 - 1)) - 1;
-      planes_put<FT>(blk, SH::period2, jl, tab_entry<FT>(a.roots29, (g1 & gm) << t0));
+      planes_put<FT>(blk, 2 * SH::period2, jl, tab_entry<FT>(a.roots29, (g1 & gm) << t0));
+      planes_put<FT>(blk, 2 * SH::period2, SH::period2 + jl, tab_entry<FT>(a.roots29c, (g1 & gm) << t0));
       continue;
     }
     const u32 r = slot - SH::U0, u = SH::U0 + 2 * r, hb = S - u - 1, period = 1u << (hb - 1 + LBT);
@@ -268,7 +284,7 @@ __global__ void __launch_bounds__(256) ntt_lns_pack_kernel(NttPassArgs a, NttPac
     const u32 g0 = (i0 << lb) | lo | lp;                     // (last pass: the tile's high bits do not reach these twiddles)
     const u32 g1 = g0 + (1u << (hb - 1 + lb));
     const u32 idx[3] = {(g0 & gm0) << t, (g1 & gm0) << t, (g0 & gm1) << (t + 1)};
-    for (u32 v = 0; v < 3; v++) planes_put<FT>(blk, 3 * period, v * period + jl, tab_entry<FT>(a.roots29, idx[v]));
+    for (u32 v = 0; v < 6; v++) planes_put<FT>(blk, 6 * period, v * period + jl, tab_entry<FT>(v < 3 ? a.roots29 : a.roots29c, idx[v % 3]));
   }
 }
 
@@ -276,8 +292,9 @@ template <class FT, int S, int LBT> NttPackInfo pack_info_t() {
   using SH = Shape<S, LBT>;
   NttPackInfo pi{};
   u32 off = 0, slot = 0;
-  if (SH::U0) { pi.round_off[slot++] = off; off += SH::period2 * FT::N; off = (off + 3) & ~3u; }
-  for (int r = 0; r < SH::NR4; r++) { pi.round_off[slot++] = off; off += 3 * SH::period4(r) * FT::N; off = (off + 3) & ~3u; }
+  // radix-2 slot: variants (plain, converting); radix-4 slots: w0, w1, w2 plain, then the same from the converting table
+  if (SH::U0) { pi.round_off[slot++] = off; off += 2 * SH::period2 * FT::N; off = (off + 3) & ~3u; }
+  for (int r = 0; r < SH::NR4; r++) { pi.round_off[slot++] = off; off += 6 * SH::period4(r) * FT::N; off = (off + 3) & ~3u; }
   pi.class_words = off;
   return pi;
 }
