@@ -68,4 +68,50 @@ __device__ __forceinline__ void b3_hash64(uint32_t out[8], const uint32_t l[8], 
   b3_compress(out, m, 0u, 64u, flags);
 }
 
+// ---- one 64-byte compression spread over the four lanes of a quad ---------------------------------------------------------
+// Lane q (= lane id & 3) owns column q of the 4 x 4 state, as the SIMD implementations of BLAKE3 keep one row per vector
+// register: a column step is one G per lane, the diagonal step the same after rotating rows b, c, d by 1, 2, 3 lanes (DPP
+// quad_perm), 42 instructions per round and lane instead of 96.  For the upper levels of a Merkle tree, where a level has
+// fewer nodes than the workgroup has lanes and each level waits for the one below, this cuts the latency of a level from
+// ~700 dependent instructions to ~300.  Every lane passes the same 16 message words.
+template <int K> __device__ __forceinline__ uint32_t b3_qrot(uint32_t x) {      // lane l <- lane (l + K) & 3 of its quad
+  constexpr int ctrl = K == 1 ? 0x39 : (K == 2 ? 0x4E : 0x93);
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, ctrl, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t b3_sel4(uint32_t q, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+  uint32_t r = q == 1 ? x1 : x0;
+  r = q == 2 ? x2 : r;
+  return q == 3 ? x3 : r;
+}
+#define B3_QROUND(m, i0, i1, i2, i3, i4, i5, i6, i7, i8, i9, i10, i11, i12, i13, i14, i15)                   \
+  mx = b3_sel4(q, m[i0], m[i2], m[i4], m[i6]); my = b3_sel4(q, m[i1], m[i3], m[i5], m[i7]);                  \
+  B3_G(a, b, c, d, mx, my)                                                                                   \
+  b = b3_qrot<1>(b); c = b3_qrot<2>(c); d = b3_qrot<3>(d);                                                   \
+  mx = b3_sel4(q, m[i8], m[i10], m[i12], m[i14]); my = b3_sel4(q, m[i9], m[i11], m[i13], m[i15]);            \
+  B3_G(a, b, c, d, mx, my)                                                                                   \
+  b = b3_qrot<3>(b); c = b3_qrot<2>(c); d = b3_qrot<1>(d);
+
+// D(left || right) with the IV as chaining value (Merkle parent, lcpc-2d/src/lib.rs:770-775; BLAKE3 tree parent): all four
+// lanes of the quad call it with the same l, r, flags; lane q receives words q (out_lo) and 4 + q (out_hi) of the digest
+__device__ __forceinline__ void b3_hash64_quad(uint32_t q, uint32_t& out_lo, uint32_t& out_hi, const uint32_t l[8], const uint32_t r[8],
+                                               uint32_t flags) {
+  uint32_t m[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { m[i] = l[i]; m[8 + i] = r[i]; }
+  uint32_t a = b3_sel4(q, B3_IV0, B3_IV1, B3_IV2, B3_IV3);
+  uint32_t b = b3_sel4(q, B3_IV4, B3_IV5, B3_IV6, B3_IV7);
+  uint32_t c = a;
+  uint32_t d = b3_sel4(q, 0u, 0u, 64u, flags);               // counter_lo, counter_hi, block_len, flags
+  uint32_t mx, my;
+  B3_QROUND(m, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  B3_QROUND(m, 2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8)
+  B3_QROUND(m, 3, 4, 10, 12, 13, 2, 7, 14, 6, 5, 9, 0, 11, 15, 8, 1)
+  B3_QROUND(m, 10, 7, 12, 9, 14, 3, 13, 15, 4, 0, 11, 2, 5, 8, 1, 6)
+  B3_QROUND(m, 12, 13, 9, 11, 15, 10, 14, 8, 7, 2, 5, 3, 0, 1, 6, 4)
+  B3_QROUND(m, 9, 14, 11, 5, 8, 12, 15, 1, 13, 3, 0, 10, 2, 6, 4, 7)
+  B3_QROUND(m, 11, 15, 5, 0, 1, 9, 8, 6, 14, 10, 2, 12, 3, 4, 7, 13)
+  out_lo = a ^ c;
+  out_hi = b ^ d;
+}
+
 }  // namespace lcpc

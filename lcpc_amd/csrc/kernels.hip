@@ -662,22 +662,38 @@ hipError_t launch_leaf_finish_nodes(u32* cvs, const u32* node_slot, const u32* n
 // =================================================================================================
 // layers: `width` nodes at `hashes + in_off*8`; each WG reduces SUB = 2^lsub consecutive nodes down
 // `lsub` layers.  Layer j (1-based) of the subtree lands at hashes[layer_off_j + wg * (SUB >> j) + ...].
-__global__ void __launch_bounds__(256) merkle_subtree_kernel(u32* hashes, u64 in_off, u64 width, u32 lsub) {
-  __shared__ u32 buf[256 * 8];
+template <u32 BS>
+__global__ void __launch_bounds__(BS) merkle_subtree_kernel(u32* hashes, u64 in_off, u64 width, u32 lsub) {
+  __shared__ u32 buf[BS * 8];
+  constexpr u32 NQ = BS / 4;                    // quads per workgroup
   const u32 tid = threadIdx.x;
-  const u64 sub = (u64)1 << lsub;               // nodes consumed per WG (<= 512)
+  const u64 sub = (u64)1 << lsub;               // nodes consumed per WG (<= 2 BS)
   const u64 base = (u64)blockIdx.x * sub;
+  constexpr u32 FL = B3_CHUNK_START | B3_CHUNK_END | B3_ROOT;
   u32 l[8], r[8], o[8];
   u64 layer_in = in_off, w = width;
   u64 layer_out = in_off + w;
   u32 n_out = (u32)(sub / 2);
+  // A level with at most BS / 4 parents runs one compression per QUAD of lanes (b3_hash64_quad: ~300 dependent instructions
+  // instead of ~700): from there on a level is shorter than the workgroup and only waits for the one below it.
+  const u32 qd = tid >> 2, q = tid & 3u;
+  u32 o_lo = 0, o_hi = 0;
   // first layer: read from global
-  if (tid < n_out) {
-    ld8(l, hashes + (layer_in + base + 2 * tid) * 8);
-    ld8(r, hashes + (layer_in + base + 2 * tid + 1) * 8);
-    b3_hash64(o, l, r, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
-    st8(hashes + (layer_out + (base >> 1) + tid) * 8, o);
-    st8(buf + tid * 8, o);
+  if (n_out > NQ) {
+    if (tid < n_out) {
+      ld8(l, hashes + (layer_in + base + 2 * tid) * 8);
+      ld8(r, hashes + (layer_in + base + 2 * tid + 1) * 8);
+      b3_hash64(o, l, r, FL);
+      st8(hashes + (layer_out + (base >> 1) + tid) * 8, o);
+      st8(buf + tid * 8, o);
+    }
+  } else if (qd < n_out) {
+    ld8(l, hashes + (layer_in + base + 2 * qd) * 8);
+    ld8(r, hashes + (layer_in + base + 2 * qd + 1) * 8);
+    b3_hash64_quad(q, o_lo, o_hi, l, r, FL);
+    u32* g = hashes + (layer_out + (base >> 1) + qd) * 8;
+    g[q] = o_lo; g[4 + q] = o_hi;
+    buf[qd * 8 + q] = o_lo; buf[qd * 8 + 4 + q] = o_hi;
   }
   for (u32 j = 2; j <= lsub; j++) {
     __syncthreads();
@@ -685,16 +701,31 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(u32* hashes, u64 in
     w >>= 1;
     layer_out = layer_in + w;
     n_out >>= 1;
-    const bool act = tid < n_out;
-    if (act) {
-      ld8(l, buf + (2 * tid) * 8);
-      ld8(r, buf + (2 * tid + 1) * 8);
-      b3_hash64(o, l, r, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
-    }
-    __syncthreads();
-    if (act) {
-      st8(buf + tid * 8, o);
-      st8(hashes + (layer_out + (base >> j) + tid) * 8, o);
+    if (n_out > NQ) {
+      const bool act = tid < n_out;
+      if (act) {
+        ld8(l, buf + (2 * tid) * 8);
+        ld8(r, buf + (2 * tid + 1) * 8);
+        b3_hash64(o, l, r, FL);
+      }
+      __syncthreads();
+      if (act) {
+        st8(buf + tid * 8, o);
+        st8(hashes + (layer_out + (base >> j) + tid) * 8, o);
+      }
+    } else {
+      const bool act = qd < n_out;
+      if (act) {
+        ld8(l, buf + (2 * qd) * 8);
+        ld8(r, buf + (2 * qd + 1) * 8);
+        b3_hash64_quad(q, o_lo, o_hi, l, r, FL);
+      }
+      __syncthreads();
+      if (act) {
+        buf[qd * 8 + q] = o_lo; buf[qd * 8 + 4 + q] = o_hi;
+        u32* g = hashes + (layer_out + (base >> j) + qd) * 8;
+        g[q] = o_lo; g[4 + q] = o_hi;
+      }
     }
   }
 }
@@ -703,9 +734,15 @@ hipError_t launch_merkle_tree(u32* hashes, u64 np2, hipStream_t st) {
   while (width > 1) {
     u32 lw = 0;
     while (((u64)1 << lw) < width) lw++;
-    const u32 lsub = lw < 9 ? lw : 9;
+    if (lw <= 9) {
+      // <= 512 nodes left: the rest of the tree in ONE workgroup of 1024 threads, one compression per quad of lanes from
+      // its first level on (wider levels belong on many CUs: 2048 leaves in one workgroup took 17 us against 9 + 6)
+      hipLaunchKernelGGL(merkle_subtree_kernel<1024>, dim3(1), dim3(1024), 0, st, hashes, in_off, width, lw);
+      return hipGetLastError();
+    }
+    const u32 lsub = 9;
     const u64 nwg = width >> lsub;
-    hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)nwg), dim3(256), 0, st, hashes, in_off, width, lsub);
+    hipLaunchKernelGGL(merkle_subtree_kernel<256>, dim3((unsigned)nwg), dim3(256), 0, st, hashes, in_off, width, lsub);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     for (u32 j = 0; j < lsub; j++) { in_off += width; width >>= 1; }
