@@ -91,6 +91,25 @@ __device__ __forceinline__ uint32_t b3_sel4(uint32_t q, uint32_t x0, uint32_t x1
   B3_G(a, b, c, d, mx, my)                                                                                   \
   b = b3_qrot<3>(b); c = b3_qrot<2>(c); d = b3_qrot<1>(d);
 
+// cv <- compress(cv, m, counter, block_len, flags) over a quad: lane q holds words q (cv_lo) and 4 + q (cv_hi) of the
+// chaining value, all four lanes pass the same message block
+__device__ __forceinline__ void b3_compress_quad(uint32_t q, uint32_t& cv_lo, uint32_t& cv_hi, const uint32_t m[16], uint32_t counter_lo,
+                                                 uint32_t block_len, uint32_t flags) {
+  uint32_t a = cv_lo, b = cv_hi;
+  uint32_t c = b3_sel4(q, B3_IV0, B3_IV1, B3_IV2, B3_IV3);
+  uint32_t d = b3_sel4(q, counter_lo, 0u, block_len, flags);
+  uint32_t mx, my;
+  B3_QROUND(m, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+  B3_QROUND(m, 2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8)
+  B3_QROUND(m, 3, 4, 10, 12, 13, 2, 7, 14, 6, 5, 9, 0, 11, 15, 8, 1)
+  B3_QROUND(m, 10, 7, 12, 9, 14, 3, 13, 15, 4, 0, 11, 2, 5, 8, 1, 6)
+  B3_QROUND(m, 12, 13, 9, 11, 15, 10, 14, 8, 7, 2, 5, 3, 0, 1, 6, 4)
+  B3_QROUND(m, 9, 14, 11, 5, 8, 12, 15, 1, 13, 3, 0, 10, 2, 6, 4, 7)
+  B3_QROUND(m, 11, 15, 5, 0, 1, 9, 8, 6, 14, 10, 2, 12, 3, 4, 7, 13)
+  cv_lo = a ^ c;
+  cv_hi = b ^ d;
+}
+
 // D(left || right) with the IV as chaining value (Merkle parent, lcpc-2d/src/lib.rs:770-775; BLAKE3 tree parent): all four
 // lanes of the quad call it with the same l, r, flags; lane q receives words q (out_lo) and 4 + q (out_hi) of the digest
 __device__ __forceinline__ void b3_hash64_quad(uint32_t q, uint32_t& out_lo, uint32_t& out_hi, const uint32_t l[8], const uint32_t r[8],

@@ -501,9 +501,13 @@ __device__ __forceinline__ void leaf_fill_block(u32 m[16], const LeafArgs& a, u6
   leaf_build_block<NL, PH, CANON>(m, r);
 }
 
-template <int NL, bool CANON = false>
+// QUAD: four lanes per column, one compression per quad (b3_compress_quad): a small commitment has fewer (column, chunk)
+// pairs than the chip has lanes, and a chunk is a chain of up to 16 dependent compressions -- ~300 instead of ~700 dependent
+// instructions each.  The four lanes build the same message block (their loads coalesce to one); 64 columns per workgroup.
+template <int NL, bool CANON = false, bool QUAD = false>
 __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
-  const u64 col = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 col = QUAD ? (u64)blockIdx.x * 64 + (threadIdx.x >> 2) : (u64)blockIdx.x * 256 + threadIdx.x;
+  const u32 q = threadIdx.x & 3u;
   if (col >= a.n_cols) return;
   const u32 chunk = a.chunk_begin + blockIdx.y;
   const u64 total_len = 32 + (u64)NL * 4 * a.n_rows_total;
@@ -512,6 +516,11 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
   const u32 nblocks = (chunk_len + 63) / 64;
   u32 cv[8];
   b3_set_iv(cv);
+  u32 cv_lo = b3_sel4(q, B3_IV0, B3_IV1, B3_IV2, B3_IV3), cv_hi = b3_sel4(q, B3_IV4, B3_IV5, B3_IV6, B3_IV7);   // QUAD: this lane's two words
+  auto compress = [&](const u32* m, u32 blen, u32 flags) {
+    if constexpr (QUAD) b3_compress_quad(q, cv_lo, cv_hi, m, chunk, blen, flags);
+    else b3_compress(cv, m, chunk, blen, flags);
+  };
   // element-word offset of block b's first word is 16*(16*chunk + b) - 8 (the zero prefix is words -8..-1)
   auto block_row0 = [&](u32 b, int& ph) -> int64_t {
     const int64_t s0 = ((int64_t)chunk * 16 + b) * 16 - 8;
@@ -532,7 +541,7 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
       const u32 blen = rem < 64 ? rem : 64;
       u32 flags = (b == 0 ? B3_CHUNK_START : 0u);
       if (b == nblocks - 1) flags |= B3_CHUNK_END | (a.n_chunks_total == 1 ? B3_ROOT : 0u);
-      b3_compress(cv, m, chunk, blen, flags);
+      compress(m, blen, flags);
       cur = nxt;
     }
   } else {
@@ -547,32 +556,38 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
       const u32 blen = rem < 64 ? rem : 64;
       u32 flags = (b == 0 ? B3_CHUNK_START : 0u);
       if (b == nblocks - 1) flags |= B3_CHUNK_END | (a.n_chunks_total == 1 ? B3_ROOT : 0u);
-      b3_compress(cv, m, chunk, blen, flags);
+      compress(m, blen, flags);
     }
   }
   u32* o = a.out + ((u64)blockIdx.y * a.n_cols + col) * 8;
-  *reinterpret_cast<uint4*>(o) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
-  *reinterpret_cast<uint4*>(o + 4) = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+  if constexpr (QUAD) {
+    o[q] = cv_lo;
+    o[4 + q] = cv_hi;
+  } else {
+    *reinterpret_cast<uint4*>(o) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    *reinterpret_cast<uint4*>(o + 4) = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+  }
 }
 // grid.y is limited to 65535: a commitment with millions of short rows (new_from_dims with a small n_per_row) has more
 // leaf-message chunks than that, so the chunk range is launched in slices
-static hipError_t launch_leaf_chunks_slice(int nl, const LeafArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)((a.n_cols + 255) / 256), a.n_chunks_local);
+template <int NL> static void launch_leaf_chunks_nl(const LeafArgs& a, hipStream_t st) {
+  // few (column, chunk) pairs: four lanes per column (latency); else one lane per column (throughput)
+  const bool quad = (u64)a.n_cols * a.n_chunks_local <= 65536;
+  const dim3 grid((unsigned)((a.n_cols + (quad ? 63 : 255)) / (quad ? 64 : 256)), a.n_chunks_local);
   if (a.canon_in) {
-    switch (nl) {
-      case 2: hipLaunchKernelGGL((leaf_chunk_kernel<2, true>), grid, dim3(256), 0, st, a); break;
-      case 4: hipLaunchKernelGGL((leaf_chunk_kernel<4, true>), grid, dim3(256), 0, st, a); break;
-      case 6: hipLaunchKernelGGL((leaf_chunk_kernel<6, true>), grid, dim3(256), 0, st, a); break;
-      case 8: hipLaunchKernelGGL((leaf_chunk_kernel<8, true>), grid, dim3(256), 0, st, a); break;
-      default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
+    if (quad) hipLaunchKernelGGL((leaf_chunk_kernel<NL, true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((leaf_chunk_kernel<NL, true, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (quad) hipLaunchKernelGGL((leaf_chunk_kernel<NL, false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((leaf_chunk_kernel<NL, false, false>), grid, dim3(256), 0, st, a);
   }
+}
+static hipError_t launch_leaf_chunks_slice(int nl, const LeafArgs& a, hipStream_t st) {
   switch (nl) {
-    case 2: hipLaunchKernelGGL(leaf_chunk_kernel<2>, grid, dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(leaf_chunk_kernel<4>, grid, dim3(256), 0, st, a); break;
-    case 6: hipLaunchKernelGGL(leaf_chunk_kernel<6>, grid, dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(leaf_chunk_kernel<8>, grid, dim3(256), 0, st, a); break;
+    case 2: launch_leaf_chunks_nl<2>(a, st); break;
+    case 4: launch_leaf_chunks_nl<4>(a, st); break;
+    case 6: launch_leaf_chunks_nl<6>(a, st); break;
+    case 8: launch_leaf_chunks_nl<8>(a, st); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
