@@ -35,7 +35,7 @@ while kill -0 $BP 2>/dev/null; do
 done | grep -v "([0-9][0-9]Mhz)\|([0-9][0-9][0-9]Mhz)" >> $O/clock_power.txt
 tail -1 $O/clk_bench.log | cut -c1-220 >> $O/clock_power.txt
 # the other configs
-python $R/tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.log
+python $R/tools/bench_configs.py 2> $O/configs.log | grep "^{" > $O/configs.jsonl     # (RCCL prints its version banner on stdout)
 rocprofv3 --kernel-trace --stats -d $O/c3 -o c3 -- python $R/tools/bench_configs.py c3 > $O/c3.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/c3) > $O/c3_kernel_stats.txt
 python $R/tools/rocpd_dispatches.py $(db $O/c3) | tail -24 > $O/c3_dispatches.txt      # the last commit, launch by launch
