@@ -53,9 +53,29 @@ int merkle_top(lcpc_commit_t* m, hipStream_t st) {
   if (c->np2 > c->n_cols)   // hashes[n_cols..np2) stay zero (lib.rs:656-666)
     HIPCHK(m, hipMemsetAsync(m->d_hashes + c->n_cols * 8, 0, (size_t)(c->np2 - c->n_cols) * 32, st));
   if (c->np2 > 1) {
-    HIPCHK(m, launch_merkle_tree(m->d_hashes, c->np2, st));
+    if (!m->h_root) {             // once per object; without the mapping the root is copied out as before
+      void* hp = nullptr;
+      if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) { m->h_root = static_cast<uint32_t*>(hp); m->d_root_alias = static_cast<uint32_t*>(dp); }
+        else (void)hipHostFree(hp);
+      }
+    }
+    HIPCHK(m, launch_merkle_tree(m->d_hashes, c->np2, st, m->d_root_alias));
     m->launches[2]++;
   }
+  return 0;
+}
+// the root of a commit that was just enqueued on `st`, on the host (synchronises the stream)
+int fetch_root(lcpc_commit_t* m, hipStream_t st, uint8_t* root) {
+  const lcpc_ctx* c = m->enc;
+  if (m->d_root_alias && c->np2 > 1) {
+    HIPCHK(m, hipStreamSynchronize(st));
+    memcpy(root, m->h_root, 32);
+    return 0;
+  }
+  HIPCHK(m, hipMemcpyAsync(root, m->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, st));
+  HIPCHK(m, hipStreamSynchronize(st));
   return 0;
 }
 
@@ -133,10 +153,7 @@ static int commit_tail(lcpc_commit_t* m, hipStream_t st, uint8_t* root) {
   if ((rc = merkleize_device(m, st))) return rc;
   if ((rc = finish_timing(m, st))) return rc;
   m->committed = true;
-  if (root) {
-    HIPCHK(m, hipMemcpyAsync(root, m->d_hashes + (2 * m->enc->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(m, hipStreamSynchronize(st));
-  }
+  if (root) return fetch_root(m, st, root);
   return 0;
 }
 
@@ -299,6 +316,7 @@ void lcpc_commit_destroy(lcpc_commit_t* m) {
   for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : m->ev_batch) if (e) (void)hipEventDestroy(e);
   if (m->h_pin) (void)hipHostFree(m->h_pin);
+  if (m->h_root) (void)hipHostFree(m->h_root);
   if (m->s_prove) (void)hipStreamDestroy(m->s_prove);
   if (m->ev_done) (void)hipEventDestroy(m->ev_done);
   if (m->s_copy) (void)hipStreamDestroy(m->s_copy);

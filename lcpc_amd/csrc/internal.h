@@ -136,6 +136,8 @@ struct lcpc_commit_s {
   uint64_t scratch_cap = 0;
   uint32_t* d_t29 = nullptr;       // collapse: tensors in the 29-bit-limb form
   uint64_t t29_cap = 0;
+  uint32_t* h_root = nullptr;      // pinned, device-mapped: the Merkle kernel that produces the root writes it here as well
+  uint32_t* d_root_alias = nullptr;  // ... through this device address (null: no mapping, the root is copied out)
   uint8_t* h_pin = nullptr;        // pinned host arena of prove (tensors, polynomials, their canonical forms)
   uint64_t h_pin_cap = 0;
   // timing
@@ -233,6 +235,7 @@ int ensure_scratch(lcpc_commit_t* m, uint64_t bytes);
 int ensure_cvs(lcpc_commit_t* m, uint64_t n_chunks);
 int ensure_commit_buffers(lcpc_commit_t* m, uint64_t n_rows_local, bool own_coeffs);
 int merkle_top(lcpc_commit_t* m, hipStream_t st);       // zero padding leaves + tree above the leaf digests
+int fetch_root(lcpc_commit_t* m, hipStream_t st, uint8_t* root);   // root of the commit just enqueued on st -> host (synchronises)
 int finish_timing(lcpc_commit_t* m, hipStream_t st);
 int collapse_run(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_polys);
 size_t collapse_scratch_bytes(const lcpc_commit_t* m, uint32_t n_tensors);

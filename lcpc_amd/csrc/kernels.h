@@ -75,7 +75,8 @@ hipError_t launch_leaf_finish(uint32_t* cvs, uint32_t n_chunks, uint64_t n_cols,
 hipError_t launch_leaf_finish_nodes(uint32_t* cvs, const uint32_t* node_slot, const uint32_t* node_log, uint32_t n_nodes,
                                     uint64_t n_cols, uint32_t* out, bool root, hipStream_t st);
 // whole tree above the leaf layer in as few launches as possible (hashes = LcCommit.hashes, np2 leaves)
-hipError_t launch_merkle_tree(uint32_t* hashes, uint64_t np2, hipStream_t st);
+// root_out (may be null): 8 more words the root is written to by the launch that produces it (host-mapped memory)
+hipError_t launch_merkle_tree(uint32_t* hashes, uint64_t np2, hipStream_t st, uint32_t* root_out);
 
 struct CollapseArgs {
   const uint32_t* coeffs;      // local rows x n_per_row

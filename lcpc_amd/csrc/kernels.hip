@@ -678,7 +678,7 @@ hipError_t launch_leaf_finish_nodes(u32* cvs, const u32* node_slot, const u32* n
 // layers: `width` nodes at `hashes + in_off*8`; each WG reduces SUB = 2^lsub consecutive nodes down
 // `lsub` layers.  Layer j (1-based) of the subtree lands at hashes[layer_off_j + wg * (SUB >> j) + ...].
 template <u32 BS>
-__global__ void __launch_bounds__(BS) merkle_subtree_kernel(u32* hashes, u64 in_off, u64 width, u32 lsub) {
+__global__ void __launch_bounds__(BS) merkle_subtree_kernel(u32* hashes, u64 in_off, u64 width, u32 lsub, u32* root_out) {
   __shared__ u32 buf[BS * 8];
   constexpr u32 NQ = BS / 4;                    // quads per workgroup
   const u32 tid = threadIdx.x;
@@ -743,8 +743,14 @@ __global__ void __launch_bounds__(BS) merkle_subtree_kernel(u32* hashes, u64 in_
       }
     }
   }
+  // the launch that produces the root also drops it where the host wants it (pinned, device-mapped memory of the commitment):
+  // the 32-byte device-to-host copy was a blit kernel of its own (4.3 us + its launch) behind every commit that returns a root
+  if (root_out != nullptr) {
+    __syncthreads();
+    if (tid < 8) root_out[tid] = buf[tid];      // node 0 of the last level
+  }
 }
-hipError_t launch_merkle_tree(u32* hashes, u64 np2, hipStream_t st) {
+hipError_t launch_merkle_tree(u32* hashes, u64 np2, hipStream_t st, u32* root_out) {
   u64 in_off = 0, width = np2;
   while (width > 1) {
     u32 lw = 0;
@@ -752,12 +758,12 @@ hipError_t launch_merkle_tree(u32* hashes, u64 np2, hipStream_t st) {
     if (lw <= 9) {
       // <= 512 nodes left: the rest of the tree in ONE workgroup of 1024 threads, one compression per quad of lanes from
       // its first level on (wider levels belong on many CUs: 2048 leaves in one workgroup took 17 us against 9 + 6)
-      hipLaunchKernelGGL(merkle_subtree_kernel<1024>, dim3(1), dim3(1024), 0, st, hashes, in_off, width, lw);
+      hipLaunchKernelGGL(merkle_subtree_kernel<1024>, dim3(1), dim3(1024), 0, st, hashes, in_off, width, lw, root_out);
       return hipGetLastError();
     }
     const u32 lsub = 9;
     const u64 nwg = width >> lsub;
-    hipLaunchKernelGGL(merkle_subtree_kernel<256>, dim3((unsigned)nwg), dim3(256), 0, st, hashes, in_off, width, lsub);
+    hipLaunchKernelGGL(merkle_subtree_kernel<256>, dim3((unsigned)nwg), dim3(256), 0, st, hashes, in_off, width, lsub, (u32*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     for (u32 j = 0; j < lsub; j++) { in_off += width; width >>= 1; }

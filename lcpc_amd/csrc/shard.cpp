@@ -348,10 +348,7 @@ static int commit_finish_phase(lcpc_commit_t* m, uint8_t* gathered, uint64_t n_r
   // a prove on this commitment runs on its own stream: it waits for this point of the commit's stream
   if (!m->ev_done) HIPCHK(m, hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
   HIPCHK(m, hipEventRecord(m->ev_done, st));
-  if (root) {
-    HIPCHK(m, hipMemcpyAsync(root, m->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(m, hipStreamSynchronize(st));
-  }
+  if (root) return fetch_root(m, st, root);
   return 0;
 }
 
