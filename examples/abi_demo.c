@@ -3,14 +3,31 @@
  *   gcc -O2 -Iinclude examples/abi_demo.c -Llcpc_amd/lib -llcpc_hip -Wl,-rpath,$PWD/lcpc_amd/lib -o examples/abi_demo
  *   ./examples/abi_demo            # prints the Merkle root of a fixed ft63 commitment + a verified evaluation
  *
- * Commits c_i = i + 1 (i < 1024) over Ft63 with LigeroEncoding::new(1024), proves and verifies an evaluation,
- * all through include/lcpc_hip.h.  tests/test_gpu_abi_demo.py checks the printed root against the golden
+ * Commits c_i = i + 1 (i < 1024) over Ft63 with LigeroEncoding::new(1024), proves and verifies an evaluation, then
+ * streams the commitment out in the reference's serde layout and back into a second object, all through include/lcpc_hip.h.  tests/test_gpu_abi_demo.py checks the printed root against the golden
  * fixture "ligero_ft63_2e10_iota" (tests/golden/commit_cases.json). */
 #include <inttypes.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "lcpc_hip.h"
+
+/* memory sink / source for the streamed serde of LcCommit (lcpc_commit_bincode_write / lcpc_commit_from_bincode) */
+typedef struct { uint8_t *p; uint64_t len, cap, pos; } membuf;
+static int sink(void *user, const uint8_t *data, uint64_t len) {
+  membuf *b = (membuf *)user;
+  if (b->len + len > b->cap) return 1;
+  memcpy(b->p + b->len, data, len);
+  b->len += len;
+  return 0;
+}
+static int source(void *user, uint8_t *data, uint64_t len) {
+  membuf *b = (membuf *)user;
+  if (b->pos + len > b->len) return 1;
+  memcpy(data, b->p + b->pos, len);
+  b->pos += len;
+  return 0;
+}
 
 #define CHECK(call) do { int rc__ = (call); if (rc__) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc__, lcpc_strerror(rc__)); return 1; } } while (0)
 
@@ -69,6 +86,29 @@ int main(void) {
   const uint64_t eval = (uint64_t)(((unsigned __int128)eval_mont * rinv) % p);
   printf("proof_bytes %" PRIu64 "\neval %016" PRIx64 " expected %016" PRIx64 " %s\n", proof_len, eval, (uint64_t)acc,
          eval == (uint64_t)acc ? "OK" : "MISMATCH");
+  /* the whole commitment through the reference's serde layout (lcpc-2d/src/lib.rs:186-268) and back into a second object:
+   * same root, and the same proof bytes from an identical transcript */
+  membuf mb;
+  mb.cap = lcpc_commit_bincode_size(cm); mb.len = 0; mb.pos = 0;
+  mb.p = malloc(mb.cap);
+  CHECK(lcpc_commit_bincode_write(cm, sink, &mb));
+  lcpc_commit_t *cm2 = NULL;
+  uint8_t root2[32];
+  CHECK(lcpc_commit_create(ctx, &cm2));
+  CHECK(lcpc_commit_from_bincode(cm2, source, &mb, root2));
+  lcpc_transcript *tp2 = lcpc_transcript_new((const uint8_t *)"test transcript", 15);
+  lcpc_transcript_append_message(tp2, (const uint8_t *)"polycommit", 10, root, 32);
+  lcpc_transcript_append_message(tp2, (const uint8_t *)"ncols", 5, ncols_be, 8);
+  uint8_t *proof2 = NULL;
+  uint64_t proof2_len = 0;
+  CHECK(lcpc_prove(cm2, outer, n_rows, tp2, &proof2, &proof2_len, NULL));
+  const int serde_ok = mb.len == mb.cap && mb.pos == mb.len && memcmp(root, root2, 32) == 0 && proof2_len == proof_len &&
+                       memcmp(proof, proof2, proof_len) == 0;
+  printf("commit_bincode_bytes %" PRIu64 " %s\n", mb.len, serde_ok ? "OK" : "MISMATCH");
+  lcpc_free(proof2);
+  lcpc_transcript_free(tp2);
+  lcpc_commit_destroy(cm2);
+  free(mb.p);
   lcpc_free(proof);
   lcpc_transcript_free(tp);
   lcpc_transcript_free(tv);
@@ -76,5 +116,5 @@ int main(void) {
   free(outer);
   lcpc_commit_destroy(cm);
   lcpc_ctx_destroy(ctx);
-  return eval == (uint64_t)acc ? 0 : 2;
+  return eval == (uint64_t)acc && serde_ok ? 0 : 2;
 }

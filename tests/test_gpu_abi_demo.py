@@ -23,3 +23,7 @@ def test_abi_demo_matches_golden():
     assert lines["root"] == case["root"]
     assert int(lines["proof_bytes"]) == case["proof_len"]
     assert lines["eval"].split()[0] == "%016x" % int(case["eval"], 16) and lines["eval"].endswith("OK")
+    # the commitment's own serde (bincode of WrappedLcCommit): 4 rows x 512 + 4 x 256 elements of 8 bytes, dims, 1023 digests
+    n_rows, n_per_row, n_cols = 4, 256, 512
+    size = 8 + n_rows * n_cols * 8 + 8 + n_rows * n_per_row * 8 + 24 + 8 + (2 * n_cols - 1) * 40
+    assert lines["commit_bincode_bytes"] == "%d OK" % size
