@@ -85,3 +85,37 @@ def test_commit_bincode_rejects_bad_streams(oracle):
     cm = LcCommit(enc)
     with pytest.raises(LcpcError):
         cm.get_root()
+
+
+def test_commit_bincode_mutation_sweep(oracle):
+    """random single-bit flips and truncations of a serialised commitment: the reader either refuses the stream (a digest that
+    no longer belongs to comm, a limb vector >= p, a length or dimension that does not fit the encoder, a short read) or -- when
+    the flip landed in `coeffs`, which no digest covers (the reference's Deserialize would take it too) -- accepts it with the
+    same root; it never crashes and never leaves a half-built commitment behind."""
+    import random
+    O, fid, n = oracle, 1, 3000
+    coeffs = O.random_elems(fid, n, 15)
+    enc, oenc = LigeroEncoding.new(fid, n), O.Encoding.ligero(fid, n)
+    oc = O.Commit.commit(coeffs, oenc)
+    good = oracle_bincode(oc)
+    nr, npr, nc = oc.n_rows, oc.n_per_row, oc.n_cols
+    coeffs_lo, coeffs_hi = 8 + nr * nc * 16 + 8, 8 + nr * nc * 16 + 8 + nr * npr * 16
+    rnd = random.Random(7)
+    accepted = refused = 0
+    for i in range(60):
+        bad = bytearray(good)
+        if i % 6 == 5:
+            bad = bad[:rnd.randrange(len(bad))]
+        else:
+            pos = rnd.randrange(len(bad))
+            bad[pos] ^= 1 << rnd.randrange(8)
+        try:
+            d = LcCommit.from_bincode(enc, io.BytesIO(bytes(bad)))
+        except LcpcError as e:
+            assert e.code in (lcpc_amd.ERR_ARG, lcpc_amd.ERR_COMMIT), e.code
+            refused += 1
+            continue
+        assert len(bad) == len(good) and coeffs_lo <= pos < coeffs_hi, "a mutated stream outside coeffs was accepted (byte %d)" % pos
+        assert d.get_root() == oc.get_root()
+        accepted += 1
+    assert refused >= 40
