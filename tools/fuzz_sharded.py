@@ -21,10 +21,10 @@ rnd = random.Random(4242)
 for case in range(n_cases):
     fid = rnd.choice([0, 1, 3, 3])
     L = O.limbs(fid)
-    log_n = rnd.randrange(2, 13)
+    log_n = rnd.randrange(2, 16)          # up to 2^15 columns: the specialised two-pass kernels (K1s / K1n, canonical comm) under sharding
     n_cols = 1 << log_n
     n_per_row = rnd.randrange(1, n_cols)
-    n_rows = rnd.randrange(1, 700)
+    n_rows = rnd.randrange(1, max(2, min(700, (1 << 21) // n_cols)))
     G = rnd.choice([2, 3, 4, 5, 8])
     if case % 5 == 4:
         n_per_row = rnd.randrange(200, 3000)
