@@ -39,6 +39,9 @@ def run_sharded(mk_enc, G, coeffs_rows, n_rows):
     (3, 70, 64, 128, 4),        # 3 chunks over 4 ranks: one rank owns nothing
     (0, 300, 128, 256, 2),      # ft63: 128 rows per chunk
     (1, 200, 64, 128, 4),       # ft127
+    (3, 100, 2048, 4096, 4),    # two-pass rows: K1s, canonical comm on every rank
+    (0, 260, 4096, 8192, 3),    # ft63 on K1n (canonical comm)
+    (1, 130, 2048, 4096, 2),    # ft127 on K1n
     (3, 20, 64, 128, 2),        # single chunk: the "CV" is already the digest
 ])
 def test_sharded_equals_unsharded(oracle, fid, n_rows, n_per_row, n_cols, G):
@@ -142,6 +145,7 @@ class ThreadAllGather:
     ("ligero", 3, 512, 256, 512, 8),     # headline row count
     ("ligero", 3, 70, 64, 128, 4),       # one rank owns no rows
     ("ligero", 0, 300, 128, 256, 2),
+    ("ligero", 1, 130, 2048, 4096, 2),   # ft127 on K1n: opened columns come out of a canonical comm on every rank
     ("ligero", 3, 20, 64, 128, 2),       # single chunk: rank 1 owns nothing
     ("sdig", 3, 70, 300, 0, 4),
 ])
