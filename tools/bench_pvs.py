@@ -27,10 +27,11 @@ N_ITERS = 10
 RHO = {"ligero": (1, 2), "ligero_hlf": (1, 2), "ligero_dfl": (1, 4), "ligero_isz": (38, 39)}
 
 
-def run(kind, lgl):
+def run(kind, lgl, fid=3):
     n = 1 << lgl
-    enc = LigeroEncoding.new(3, n, rho=RHO[kind]) if kind in RHO else SdigEncoding.new(3, n, 0)
-    coeffs = B.rand_coeffs(n, 4, lgl)
+    L = fid + 1
+    enc = LigeroEncoding.new(fid, n, rho=RHO[kind]) if kind in RHO else SdigEncoding.new(fid, n, 0)
+    coeffs = B.rand_coeffs(n, L, lgl)
     st = torch.cuda.current_stream().cuda_stream
     c = LcCommit(enc)
     for _ in range(2):
@@ -41,8 +42,8 @@ def run(kind, lgl):
     t_commit = (time.perf_counter() - t0) / N_ITERS
     root = c.get_root()
     x = 0x1234567 + lgl
-    inner = powers(O, 3, x, c.n_per_row)
-    outer = powers(O, 3, x, c.n_rows, c.n_per_row)
+    inner = powers(O, fid, x, c.n_per_row)
+    outer = powers(O, fid, x, c.n_rows, c.n_per_row)
     nco = enc.get_n_col_opens()
     pf = c.prove(outer, enc, mk_transcript(Transcript, root, nco))
     t0 = time.perf_counter()
@@ -54,7 +55,7 @@ def run(kind, lgl):
     for _ in range(N_ITERS):
         pf.verify(root, outer, inner, enc, mk_transcript(Transcript, root, nco))
     t_verify = (time.perf_counter() - t0) / N_ITERS
-    print(json.dumps({"enc": kind, "lgl": lgl, "dims": [c.n_rows, c.n_per_row, c.n_cols], "commit_ms": round(t_commit * 1e3, 3),
+    print(json.dumps({"enc": kind, "field": ("ft63", "ft127", "ft191", "ft255")[fid], "lgl": lgl, "dims": [c.n_rows, c.n_per_row, c.n_cols], "commit_ms": round(t_commit * 1e3, 3),
                       "prove_ms": round(t_prove * 1e3, 3), "verify_ms": round(t_verify * 1e3, 3), "proof_bytes": len(pf.to_bytes())}),
           flush=True)
     del coeffs, c, enc
