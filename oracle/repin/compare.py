@@ -18,6 +18,8 @@ for line in sys.stdin:
         got = t[2:5]
     elif key == "n_col_opens":
         want, got = [str(c["n_col_opens"]), str(c["n_degree_tests"])], [t[2], t[4]]
+    elif key == "commit_bincode_len":
+        want, got = [str(c["commit_bincode_len"]), c["commit_bincode_sha256"]], [t[2], t[4]]
     elif key == "proof_len":
         want, got = [str(c["proof_len"]), c["proof_sha256"], c["proof_blake3"]], [t[2], t[4], t[6]]
     else:

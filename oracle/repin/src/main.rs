@@ -66,6 +66,8 @@ where
     // LcCommit's fields are private: read comm and hashes out of its serde form (lib.rs:186-197):
     // u64 len, comm elements (raw Montgomery limbs) | u64 len, coeffs | n_rows, n_cols, n_per_row | u64 len, (u64 32, digest)*
     let dump = bincode::serialize(&comm).unwrap();
+    // ... and the serde form itself (the bytes lcpc_commit_bincode_write streams, tests/test_gpu_commit_serde.py)
+    println!("{} commit_bincode_len {} commit_bincode_sha256 {}", name, dump.len(), hex(&Sha256::digest(&dump)));
     let fb = std::mem::size_of::<F>();
     let n_comm = u64::from_le_bytes(dump[0..8].try_into().unwrap()) as usize;
     let comm_bytes = &dump[8..8 + n_comm * fb];

@@ -52,3 +52,17 @@ def mk_transcript(T, root, n_col_opens):
     tr.append_message(b"polycommit", bytes(root))
     tr.append_message(b"ncols", int(n_col_opens).to_bytes(8, "big"))
     return tr
+
+
+def commit_bincode(oc):
+    """bincode 1.3 of WrappedLcCommit (lcpc-2d/src/lib.rs:186-197) built from a commitment's fields (oracle or HIP object with
+    comm() / coeffs() / hashes() / n_rows / n_cols / n_per_row): Vec<F> = u64 len + raw Montgomery limbs; usize = u64;
+    Vec<WrappedOutput> = u64 len + (u64 32 + 32 bytes) each."""
+    import struct
+    comm, coeffs, hashes = oc.comm(), oc.coeffs(), oc.hashes()
+    out = [struct.pack("<Q", comm.shape[0]), comm.tobytes(), struct.pack("<Q", coeffs.shape[0]), coeffs.tobytes(),
+           struct.pack("<QQQ", oc.n_rows, oc.n_cols, oc.n_per_row), struct.pack("<Q", hashes.shape[0])]
+    for h in hashes:
+        out.append(struct.pack("<Q", 32) + bytes(h))
+    return b"".join(out)
+

@@ -35,9 +35,21 @@ def mk_tr(root, n_col_opens):
     return tr
 
 
+def commit_bincode(F, c):
+    """bincode 1.3 of WrappedLcCommit (lcpc-2d/src/lib.rs:186-197): Vec<F> = u64 len + raw Montgomery limbs, usize = u64,
+    Vec<WrappedOutput> = u64 len + (u64 32 + digest) each"""
+    padded = list(c.coeffs) + [0] * (c.n_rows * c.n_per_row - len(c.coeffs))
+    out = [len(c.comm).to_bytes(8, "little"), mont_bytes(F, c.comm), len(padded).to_bytes(8, "little"), mont_bytes(F, padded)]
+    out += [v.to_bytes(8, "little") for v in (c.n_rows, c.n_cols, c.n_per_row)]
+    out.append(len(c.hashes).to_bytes(8, "little"))
+    out += [(32).to_bytes(8, "little") + h for h in c.hashes]
+    return b"".join(out)
+
+
 def commit_case(name, F, enc, enc_desc, n, kind, seed, with_proof=True):
     coeffs = coeffs_for(F, n, kind, seed)
     c = P.commit(F, coeffs, enc)
+    ser_c = commit_bincode(F, c)
     out = dict(name=name, field=F.fid, enc=enc_desc, n_coeffs=n, coeffs=kind, seed=seed,
                n_rows=c.n_rows, n_per_row=c.n_per_row, n_cols=c.n_cols,
                n_col_opens=enc.get_n_col_opens(), n_degree_tests=enc.get_n_degree_tests(),
@@ -46,7 +58,8 @@ def commit_case(name, F, enc, enc_desc, n, kind, seed, with_proof=True):
                hashes_sha256=hashlib.sha256(b"".join(c.hashes)).hexdigest(),
                comm_head=[hex(F.to_mont(v)) for v in c.comm[:4]],
                comm_row0_col1_repr=F.to_repr(c.comm[1]).hex(),
-               leaf0=c.hashes[0].hex())
+               leaf0=c.hashes[0].hex(),
+               commit_bincode_len=len(ser_c), commit_bincode_sha256=hashlib.sha256(ser_c).hexdigest())
     if with_proof:
         x = 0x1234567 % F.p
         inner = [pow(x, i, F.p) for i in range(c.n_per_row)]

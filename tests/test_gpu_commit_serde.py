@@ -9,21 +9,13 @@ import numpy as np
 import pytest
 
 import lcpc_amd
-from common import mk_transcript
+from common import commit_bincode, golden_coeffs, load_golden, mk_transcript
 from lcpc_amd import LcCommit, LcpcError, LigeroEncoding, SdigEncoding, Transcript
 
 pytestmark = pytest.mark.gpu
 
 
-def oracle_bincode(oc):
-    """bincode 1.3 of WrappedLcCommit built from the oracle's fields: Vec<F> = u64 len + raw Montgomery limbs; usize = u64;
-    Vec<WrappedOutput> = u64 len + (u64 32 + 32 bytes) each."""
-    comm, coeffs, hashes = oc.comm(), oc.coeffs(), oc.hashes()
-    out = [struct.pack("<Q", comm.shape[0]), comm.tobytes(), struct.pack("<Q", coeffs.shape[0]), coeffs.tobytes(),
-           struct.pack("<QQQ", oc.n_rows, oc.n_cols, oc.n_per_row), struct.pack("<Q", hashes.shape[0])]
-    for h in hashes:
-        out.append(struct.pack("<Q", 32) + bytes(h))
-    return b"".join(out)
+oracle_bincode = commit_bincode
 
 
 CASES = [("ligero", 3, 1 << 20, None), ("ligero", 3, (1 << 16) - 77, None), ("ligero", 0, 1 << 16, None), ("ligero", 1, 1 << 14, (1, 4)),
@@ -119,3 +111,24 @@ def test_commit_bincode_mutation_sweep(oracle):
         assert d.get_root() == oc.get_root()
         accepted += 1
     assert refused >= 40
+
+
+@pytest.mark.parametrize("case", load_golden("commit_cases.json"), ids=lambda c: c["name"])
+def test_commit_bincode_matches_golden(oracle, case):
+    """the streamed serde bytes of every golden commitment: length and sha256 as committed in tests/golden/commit_cases.json
+    (made by the Python restatement; oracle/repin prints the same keys from the real crates)"""
+    import hashlib
+    O = oracle
+    e = case["enc"]
+    fid = case["field"]
+    if e["kind"] == "ligero":
+        enc = LigeroEncoding.new(fid, e["length"], rho=tuple(e["rho"])) if "length" in e else \
+            LigeroEncoding.new_from_dims(fid, e["n_per_row"], e["n_cols"], rho=tuple(e["rho"]))
+    else:
+        enc = SdigEncoding.new(fid, e["length"], e["seed"], e["code"])
+    c = LcCommit.commit(golden_coeffs(O, case), enc)
+    buf = io.BytesIO()
+    c.to_bincode(buf)
+    assert len(buf.getvalue()) == case["commit_bincode_len"] == c.bincode_size()
+    assert hashlib.sha256(buf.getvalue()).hexdigest() == case["commit_bincode_sha256"]
+

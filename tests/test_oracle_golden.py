@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import pyref as P
-from common import golden_coeffs, hex_to_limbs, load_golden, mk_transcript, powers, sha
+from common import commit_bincode, golden_coeffs, hex_to_limbs, load_golden, mk_transcript, powers, sha
 
 CASES = load_golden("commit_cases.json")
 
@@ -35,6 +35,8 @@ def test_commit_cases(oracle, case):
     assert bytes(c.hashes()[0]).hex() == case["leaf0"]
     for k, h in enumerate(case["comm_head"]):
         assert (c.comm()[k] == hex_to_limbs(h, L)).all()
+    ser = commit_bincode(c)          # serde of LcCommit (lib.rs:186-268): the C oracle's fields in the layout pyref wrote
+    assert len(ser) == case["commit_bincode_len"] and hashlib.sha256(ser).hexdigest() == case["commit_bincode_sha256"]
     if "proof_len" in case:
         x = int(case["eval_point"], 16)
         outer = powers(O, fid, x, c.n_rows, c.n_per_row)
