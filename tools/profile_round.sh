@@ -4,7 +4,8 @@
 #   bench_kernel_stats.txt    rocprofv3 --kernel-trace --stats of the same command (no CPU baseline)
 #   bench_pmc_{fetch,write,sq}.txt + pmc.json     separate --pmc passes (never combined with traces)
 #   clock_power.txt           rocm-smi sclk / socket power sampled while the bench loops
-#   configs.jsonl, c3_kernel_stats.txt, c3_dispatches.txt, c3_pmc.json, c5_kernel_stats.txt, c4_rank.jsonl, fields.jsonl, pvs.jsonl   the other BASELINE.json configs, fields, the reference's loops
+#   configs.jsonl, c3_kernel_stats.txt, c3_dispatches.txt, c3_pmc.json, c5_kernel_stats.txt, c4_rank.jsonl, fields.jsonl, pvs.jsonl,
+#   bench_rs.jsonl, small_trace.txt   the other BASELINE.json configs, fields, the reference's loops and cargo-bench matrix, small commits
 # Run on the MI355X box:  gpurun -- 'bash tools/profile_round.sh r01f'
 TAG=${1:-latest}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -50,5 +51,7 @@ python $R/tools/bench_fields.py 24 > $O/fields.jsonl 2> $O/fields.log           
 python $R/tools/bench_pvs.py > $O/pvs.jsonl 2> $O/pvs.log                              # the reference's rough_bench / prove_verify_size_bench loops
 rocprofv3 --kernel-trace --stats -d $O/c5 -o c5 -- python $R/tools/bench_configs.py c5 > $O/c5.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/c5) > $O/c5_kernel_stats.txt
+python $R/tools/bench_rs.py 2> $O/bench_rs.log | grep "^{" > $O/bench_rs.jsonl            # the reference's cargo-bench matrix (Ft127 / Ft255 x 2^16 / 2^20 / 2^24)
+bash $R/tools/trace_small.sh > $O/small_trace.txt 2>&1                                   # small commitments, launch by launch
 rm -rf $O/kt $O/fetch $O/write $O/sq $O/c3 $O/c5     # raw .db files stay out of the merge-back
 ls -la $O
