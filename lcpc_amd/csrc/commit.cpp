@@ -153,7 +153,16 @@ static int commit_tail(lcpc_commit_t* m, hipStream_t st, uint8_t* root) {
   if ((rc = merkleize_device(m, st))) return rc;
   if ((rc = finish_timing(m, st))) return rc;
   m->committed = true;
+  // whatever reads the commitment next (prove, collapse, open, the getters) runs on another stream -- the null stream, or the
+  // sharded prover's own -- and a caller's NON-BLOCKING stream is not implicitly ordered before those: they wait for this event
+  if (!m->ev_done) HIPCHK(m, hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
+  HIPCHK(m, hipEventRecord(m->ev_done, st));
   if (root) return fetch_root(m, st, root);
+  return 0;
+}
+// order `st` behind the commit that filled this object (no-op when the commit ran on `st` itself or has long finished)
+int order_after_commit(lcpc_commit_t* m, hipStream_t st) {
+  if (m->ev_done) HIPCHK(m, hipStreamWaitEvent(st, m->ev_done, 0));
   return 0;
 }
 
@@ -221,6 +230,7 @@ int collapse_host(lcpc_commit_t* m, const uint64_t* tensors, uint32_t n_tensors,
   uint32_t* d_t = reinterpret_cast<uint32_t*>(base);
   uint32_t* d_p = reinterpret_cast<uint32_t*>(base + tb);
   uint32_t* d_pc = reinterpret_cast<uint32_t*>(base + tb + pb);
+  if ((rc = order_after_commit(m, nullptr))) return rc;
   HIPCHK(m, hipMemcpyAsync(d_t, tensors, (size_t)n_tensors * m->n_rows_local * eb, hipMemcpyHostToDevice, nullptr));
   if ((rc = collapse_run(m, d_t, n_tensors, nullptr, d_p))) return rc;
   if (polys_canon) HIPCHK(m, launch_to_canon(c->NL, d_p, (uint64_t)n_tensors * c->n_per_row, d_pc, nullptr));
@@ -263,6 +273,7 @@ int open_columns_host(lcpc_commit_t* m, const uint64_t* cols, uint32_t n, uint64
   uint64_t* d_cols = reinterpret_cast<uint64_t*>(base);
   uint32_t* d_vals = reinterpret_cast<uint32_t*>(base + cb);
   uint32_t* d_paths = reinterpret_cast<uint32_t*>(base + cb + vb);
+  if ((rc = order_after_commit(m, nullptr))) return rc;
   HIPCHK(m, hipMemcpyAsync(d_cols, cols, (size_t)n * 8, hipMemcpyHostToDevice, nullptr));
   if ((rc = open_columns_device(m, d_cols, n, col_vals ? d_vals : nullptr, paths ? d_paths : nullptr, nullptr))) return rc;
   if (col_vals && m->n_rows_local) {
@@ -573,6 +584,7 @@ int lcpc_get_root(lcpc_commit_t* m, uint8_t root[32]) {
   if (!m || !root) return LCPC_ERR_ARG;
   if (!m->committed) return LCPC_ERR_STATE;
   HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  { int orc = order_after_commit(m, nullptr); if (orc) return orc; }
   HIPCHK(m, hipMemcpy(root, m->d_hashes + (2 * m->enc->np2 - 2) * 8, 32, hipMemcpyDeviceToHost));
   return 0;
 }
@@ -589,6 +601,7 @@ int lcpc_get_hashes(lcpc_commit_t* m, uint8_t* hashes) {
   if (!m || !hashes) return LCPC_ERR_ARG;
   if (!m->committed) return LCPC_ERR_STATE;
   HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  { int orc = order_after_commit(m, nullptr); if (orc) return orc; }
   HIPCHK(m, hipMemcpy(hashes, m->d_hashes, (size_t)(2 * m->enc->np2 - 1) * 32, hipMemcpyDeviceToHost));
   return 0;
 }
@@ -600,6 +613,7 @@ int lcpc_get_comm(lcpc_commit_t* m, uint64_t row0, uint64_t n, uint64_t* out) {
   LCPC_TRY
   std::lock_guard<std::mutex> g(m->mu);
   HIPCHK(m, hipSetDevice(c->prm.device));
+  { int orc = order_after_commit(m, nullptr); if (orc) return orc; }
   const size_t eb = elem_bytes(c);
   if (m->comm_t && !m->comm_rows_valid) {      // Brakedown: the commitment is position-major; make the row-major view once
     if (!m->d_comm || m->cap_comm_rows < m->n_rows_local) {
@@ -639,6 +653,7 @@ int lcpc_get_coeffs(lcpc_commit_t* m, uint64_t row0, uint64_t n, uint64_t* out) 
   if (row0 < m->row_begin || row0 + n > m->row_begin + m->n_rows_local) return LCPC_ERR_ARG;
   const lcpc_ctx* c = m->enc;
   HIPCHK(m, hipSetDevice(c->prm.device));
+  { int orc = order_after_commit(m, nullptr); if (orc) return orc; }
   const size_t eb = elem_bytes(c);
   HIPCHK(m, hipMemcpy(out, reinterpret_cast<const uint8_t*>(m->coeffs_view) + (size_t)(row0 - m->row_begin) * c->n_per_row * eb,
                       (size_t)n * c->n_per_row * eb, hipMemcpyDeviceToHost));
@@ -654,6 +669,7 @@ int lcpc_collapse_device(lcpc_commit_t* m, const uint64_t* tensors_dev, uint32_t
   HIPCHK(m, hipSetDevice(m->enc->prm.device));
   int rc = ensure_scratch(m, collapse_scratch_bytes(m, 2) + 256);
   if (rc) return rc;
+  if ((rc = order_after_commit(m, (hipStream_t)stream))) return rc;
   return collapse_run(m, reinterpret_cast<const uint32_t*>(tensors_dev), n_tensors, (hipStream_t)stream,
                       reinterpret_cast<uint32_t*>(polys_dev));
   LCPC_CATCH(m)

@@ -235,6 +235,7 @@ int ensure_scratch(lcpc_commit_t* m, uint64_t bytes);
 int ensure_cvs(lcpc_commit_t* m, uint64_t n_chunks);
 int ensure_commit_buffers(lcpc_commit_t* m, uint64_t n_rows_local, bool own_coeffs);
 int merkle_top(lcpc_commit_t* m, hipStream_t st);       // zero padding leaves + tree above the leaf digests
+int order_after_commit(lcpc_commit_t* m, hipStream_t st);          // st waits for the commit that filled m (event; cheap)
 int fetch_root(lcpc_commit_t* m, hipStream_t st, uint8_t* root);   // root of the commit just enqueued on st -> host (synchronises)
 int finish_timing(lcpc_commit_t* m, hipStream_t st);
 int collapse_run(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_polys);

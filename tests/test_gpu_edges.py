@@ -372,3 +372,35 @@ def test_many_short_rows_exceed_grid_y(oracle):
     vals, _ = c.open_columns([0, 15, 7])
     ocomm = oc.comm().reshape(n_rows, n_cols, 4)
     assert (vals == ocomm[:, [0, 15, 7]].transpose(1, 0, 2)).all()
+
+
+def test_prove_right_after_async_commit_on_nonblocking_stream(oracle):
+    """lcpc_commit_device with root = NULL only enqueues; prove / collapse / open / the getters run on the null stream, which a
+    caller's NON-BLOCKING stream is not implicitly ordered with: the library orders them behind the commit by an event.  A 2^22
+    commit (~1 ms of kernels) followed at once by the readers, several times over, against the oracle."""
+    import torch
+    from common import mk_transcript
+    from lcpc_amd import Transcript
+    O, fid, n = oracle, 3, 1 << 22
+    enc, oenc = LigeroEncoding.new(fid, n), O.Encoding.ligero(fid, n)
+    st = torch.cuda.Stream()                      # torch streams are created non-blocking
+    for it in range(3):
+        coeffs = O.random_elems(fid, n, 90 + it)
+        dev = torch.from_numpy(coeffs.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        oc = O.Commit.commit(coeffs, oenc, n_threads=8)
+        c = LcCommit(enc)
+        with torch.cuda.stream(st):
+            LcCommit.commit_device(dev.data_ptr(), n, enc, st.cuda_stream, sync=False, into=c)
+        if it == 0:
+            root = c.get_root()                   # getter right behind the enqueue
+            assert root == oc.get_root()
+        elif it == 1:
+            t = O.random_elems(fid, c.n_rows, 5)
+            assert (c.eval_outer(t) == oc.collapse(t)).all()
+        root = oc.get_root()
+        outer = O.random_elems(fid, oc.n_rows, 7)
+        pf = c.prove(outer, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+        opf, _ = oc.prove(outer, oenc, mk_transcript(O.Transcript, root, oenc.get_n_col_opens()))
+        assert pf.to_bytes() == opf
+        st.synchronize()
