@@ -93,6 +93,21 @@ static void plan_passes(lcpc_ctx* c) {
   c->passes.push_back({t0, s_final, 0u, LT});
 }
 
+// first pass of the shape-specialised two-pass kernels: how many neighbouring tiles of a row (log2) run as consecutive
+// workgroups of one XCD.  Its strided runs are run_bytes = F << log_tj long; grouping makes the span that one XCD works on at a
+// time 1 KiB (2 KiB for runs of <= 32 bytes), which is what measured best (build-time A/B in one process, DESIGN.md K1s: n_cols
+// 2^20 -27 % on boxes where the ungrouped order is slow, -4 % elsewhere; 2^19 -3 %; the headline's 128-byte runs -0.5 to -1 %).
+// LCPC_NTT_TILE_GROUP=<log2> overrides (0 = the plain XCD-aware order); read per call so that tests can switch it
+static uint32_t ntt_tile_group(const lcpc_ctx* c, const Pass& first) {
+  const uint32_t tiles_log = c->log_n - 10;
+  if (tiles_log < 3) return 0;
+  uint32_t run_log = first.log_tj;                                        // log2(run bytes)
+  for (uint32_t b = 8u * (uint32_t)c->L; b > 1; b >>= 1) run_log++;
+  uint32_t lg = run_log <= 5 ? 11 - run_log : (run_log < 10 ? 10 - run_log : 0);
+  if (const char* ev = getenv("LCPC_NTT_TILE_GROUP")) lg = (uint32_t)strtoul(ev, nullptr, 10);
+  return std::min(std::min(lg, 6u), tiles_log - 3);
+}
+
 #define ECHK(call)                                                        \
   do {                                                                    \
     hipError_t e__ = (call);                                              \
@@ -135,6 +150,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
         a.n_rows = nr;
         a.log_n = c->log_n; a.t0 = p.t0; a.s = p.s; a.log_tj = p.log_tj;
         a.mid = rb ? ws->d_mid : nullptr;
+        a.tile_group = first ? ntt_tile_group(c, p) : 0u;
         ECHK(launch_ntt_pass_l9s(a, first, c->d_pack[i], c->pack_info[i], st));
         nl++;
       }
@@ -158,6 +174,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.copy_dst = first ? j.copy_dst : nullptr;
       a.n_rows = n_rows;
       a.log_n = c->log_n; a.t0 = p.t0; a.s = p.s; a.log_tj = p.log_tj;
+      a.tile_group = first ? ntt_tile_group(c, p) : 0u;
       ECHK(launch_ntt_pass_lns(c->NL, a, first, c->d_pack[i], c->pack_info[i], st));
       nl++;
     }

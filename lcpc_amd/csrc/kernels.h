@@ -25,6 +25,9 @@ struct NttPassArgs {
   uint32_t* mid = nullptr; // shape-specialised two-pass kernel only, may be null: the 29-bit-limb intermediate between the passes
                            // (n_rows x n_cols x 36 bytes, layout in ntt_l9s.hip); the first pass writes it instead of dst, the
                            // last pass reads it instead of src
+  uint32_t tile_group = 0; // shape-specialised first pass (ntt_l9s.hip, ntt_lns.hip): 2^tile_group neighbouring tiles of a row are
+                           // consecutive workgroups of one XCD (short strided runs then meet in that L2); needs
+                           // tiles_per_row >= 8 << tile_group
 };
 hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream_t st);
 

@@ -68,7 +68,18 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
   const u32 tiles_per_row = 1u << (k - LT);
   u64 row;
   u32 tile;
-  if (tiles_per_row >= 8) {                                  // XCD-aware order, as in ntt_pass_kernel
+  if (FIRST && a.tile_group) {
+    // short runs: 2^tile_group neighbouring tiles touch the same 128-byte lines / DRAM pages.  They go to one XCD (workgroups
+    // are dealt to the XCDs round-robin) as consecutive workgroups, so that a line one of them fetched is in that L2 when the
+    // others ask for it and their partial-line stores meet there before the write-back (host: ntt_tile_group, ctx.cpp)
+    const u32 lg = a.tile_group;
+    const u32 xcd = blockIdx.x & 7u;
+    const u64 qq = blockIdx.x >> 3;
+    const u32 sub = (u32)qq & ((1u << lg) - 1);
+    const u64 q2 = qq >> lg;
+    tile = (((u32)(q2 / a.n_rows) * 8u + xcd) << lg) | sub;
+    row = q2 % a.n_rows;
+  } else if (tiles_per_row >= 8) {                           // XCD-aware order, as in ntt_pass_kernel
     const u32 xcd = blockIdx.x & 7u;
     const u64 qq = blockIdx.x >> 3;
     tile = (u32)(qq / a.n_rows) * 8u + xcd;
@@ -365,6 +376,7 @@ hipError_t launch_ntt_pass_l9s(const NttPassArgs& a, bool first, const uint32_t*
     return launch_t<10, 0, false>(a, pack, pi, st);
   }
   if (a.t0 != 0 || a.s + a.log_tj != 10 || a.s + 10 != a.log_n) return hipErrorInvalidValue;
+  if (a.tile_group && ((1u << (a.log_n - 10)) >> a.tile_group) < 8) return hipErrorInvalidValue;
   switch (a.s) {
 #define X(SV) case SV: return launch_t<SV, 10 - SV, true>(a, pack, pi, st);
     L9S_FIRST_CASES(X)

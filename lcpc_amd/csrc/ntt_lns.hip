@@ -90,7 +90,15 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
   const u32 tiles_per_row = 1u << (k - 10);
   u64 row;
   u32 tile;
-  if (tiles_per_row >= 8) {                                  // XCD-aware order, as in ntt_pass_kernel
+  if (FIRST && a.tile_group) {                               // short runs: neighbouring tiles back to back on one XCD (ntt_l9s.hip)
+    const u32 lg = a.tile_group;
+    const u32 xcd = blockIdx.x & 7u;
+    const u64 qq = blockIdx.x >> 3;
+    const u32 sub = (u32)qq & ((1u << lg) - 1);
+    const u64 q2 = qq >> lg;
+    tile = (((u32)(q2 / a.n_rows) * 8u + xcd) << lg) | sub;
+    row = q2 % a.n_rows;
+  } else if (tiles_per_row >= 8) {                           // XCD-aware order, as in ntt_pass_kernel
     const u32 xcd = blockIdx.x & 7u;
     const u64 qq = blockIdx.x >> 3;
     tile = (u32)(qq / a.n_rows) * 8u + xcd;
@@ -367,14 +375,15 @@ template <class FT> hipError_t launch_pass_f(const NttPassArgs& a, bool first, c
     default: break;                                    \
   }
 
-// n_cols up to 2^19 (Ft63) / 2^20 (Ft127, Ft191): measured against the general kernel's three-pass plans on 2^25-element
-// matrices (round 3): 2^19 columns 0.73 / 1.43 / 2.30 ms against 0.76 / 1.63 / 2.90; 2^20 columns 1.97 / 2.26 ms against
-// 2.02 / 3.26 for Ft127 / Ft191, while Ft63's 8-byte first-pass runs lose there (1.08 against 0.79 ms).
+// n_cols up to 2^20: measured against the general kernel's three-pass plans (round 3, 2^25-element matrices): 2^19 columns
+// 0.73 / 1.43 / 2.30 ms against 0.76 / 1.63 / 2.90; 2^20 columns 1.97 / 2.26 ms against 2.02 / 3.26 for Ft127 / Ft191.  Ft63's
+// 8-byte first-pass runs lost at 2^20 columns until the first pass ran the tiles that share cache lines back to back on one
+// XCD (NttPassArgs.tile_group): 512 rows x 2^20 columns 12.9 ms on the general plan, 23.3 ungrouped, 11.2 grouped.
 // LCPC_NTT_LNS_MAXK lowers the bound (A/B).
 bool ntt_lns_supported(int nl, uint32_t log_n) {
   const char* ev = getenv("LCPC_NTT_LNS_MAXK");
   const uint32_t maxk = ev ? (uint32_t)atoi(ev) : 20;
-  return (nl == 2 || nl == 4 || nl == 6) && log_n >= 11 && log_n <= maxk && log_n <= (nl == 2 ? 19u : 20u);
+  return (nl == 2 || nl == 4 || nl == 6) && log_n >= 11 && log_n <= maxk && log_n <= 20u;
 }
 int ntt_lns_limbs(int nl) { return nl == 2 ? 3 : (nl == 4 ? 5 : (nl == 6 ? 7 : 0)); }
 int ntt_lns_limb_bits(int nl) { return nl == 2 ? 26 : 29; }
@@ -394,6 +403,7 @@ hipError_t launch_ntt_lns_pack(int nl, const NttPassArgs& a, bool first, const N
   return hipErrorInvalidValue;
 }
 hipError_t launch_ntt_pass_lns(int nl, const NttPassArgs& a, bool first, const uint32_t* pack, const NttPackInfo& pi, hipStream_t st) {
+  if (a.tile_group && (!first || ((1u << (a.log_n - 10)) >> a.tile_group) < 8)) return hipErrorInvalidValue;
   LNS_DISPATCH(nl, return launch_pass_f<FT>(a, first, pack, pi, st))
   return hipErrorInvalidValue;
 }

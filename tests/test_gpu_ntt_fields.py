@@ -47,11 +47,12 @@ def test_commit_all_two_pass_shapes_small_fields(oracle, fid, log_n, rate):
     assert (enc.encode(rows) == oc.comm()[n_cols:]).all()
 
 
-@pytest.mark.parametrize("fid,log_n", [(0, 19), (1, 19), (1, 20), (2, 19), (2, 20)])
+@pytest.mark.parametrize("fid,log_n", [(0, 19), (0, 20), (1, 19), (1, 20), (2, 19), (2, 20)])
 @pytest.mark.parametrize("rate", ["1/2", "38/39"])
 def test_commit_long_rows_small_fields(oracle, fid, log_n, rate):
-    """2^19 / 2^20 columns: first passes of 9 / 10 stages whose runs are 2 / 1 elements (still ahead of the general kernel's
-    three-pass plan there, except Ft63 at 2^20, which stays on it)"""
+    """2^19 / 2^20 columns: first passes of 9 / 10 stages whose runs are 2 / 1 elements (8 bytes for Ft63 at 2^20): the tiles
+    that share cache lines run back to back on one XCD (ctx.cpp ntt_tile_group), which keeps these ahead of the general
+    kernel's three-pass plan"""
     O = oracle
     n_cols = 1 << log_n
     n_per_row, rho = {"1/2": (n_cols // 2, (1, 2)), "38/39": (n_cols * 38 // 39, (38, 39))}[rate]
@@ -103,3 +104,35 @@ def test_lazy_limb_range_stress_small_fields(oracle, fid):
         got = enc.encode(rows).reshape(len(pats), n, L)
         for r in range(len(pats)):
             assert (got[r] == oenc.encode(rows[r].copy())).all(), (log_n, n_per_row, r)
+
+
+@pytest.mark.parametrize("fid,log_n", [(0, 13), (0, 14), (0, 17), (0, 20), (1, 13), (1, 16), (1, 19), (2, 14), (2, 18), (2, 20), (3, 13), (3, 14), (3, 15),
+                                       (3, 17), (3, 18), (3, 19), (3, 20)])
+def test_tile_group_orders_agree(oracle, fid, log_n):
+    """the first pass's workgroup -> tile mapping (2^g neighbouring tiles back to back on one XCD, LCPC_NTT_TILE_GROUP=g; the
+    library clamps g to the tiles a row has) is a permutation of the same work: every order gives the same commitment, with 1, 3
+    and 5 rows (the row count enters the mapping), and the default's equals the oracle's"""
+    O = oracle
+    L = fid + 1
+    n_cols, n_per_row = 1 << log_n, 1 << (log_n - 1)
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    for n_rows in (1, 3, 5) if log_n <= 18 else (3,):
+        coeffs = O.random_elems(fid, n_rows * n_per_row - 7, 5 * log_n + fid + n_rows)
+        c = LcCommit.commit(coeffs, enc)
+        if n_rows == 3:
+            oc = O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4)
+            assert c.get_root() == oc.get_root() and (c.comm() == oc.comm()).all()
+        ref_comm, ref_hashes = c.comm(), c.hashes()
+        for g in ("0", "1", "2", "4", "6", "9"):
+            os.environ["LCPC_NTT_TILE_GROUP"] = g
+            try:
+                d = LcCommit.commit(coeffs, enc)
+            finally:
+                del os.environ["LCPC_NTT_TILE_GROUP"]
+            assert (d.comm() == ref_comm).all() and (d.hashes() == ref_hashes).all() and (d.coeffs() == coeffs_padded(coeffs, n_rows, n_per_row, L)).all(), (n_rows, g)
+
+
+def coeffs_padded(coeffs, n_rows, n_per_row, L):
+    out = np.zeros((n_rows * n_per_row, L), np.uint64)
+    out[:len(coeffs)] = coeffs
+    return out
