@@ -210,20 +210,12 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
   const size_t t = c->d_pre.size();
   const DevCsr& pl = c->d_pre[t - 1];
   const size_t eb = elem_bytes(c);
-  {
-    uint64_t cap_b = ws->tmp_cap * eb;
-    int rc = ensure_dev(err, &ws->d_tmp, &cap_b, n_rows * pl.n_out * eb);
-    if (rc) { ws->tmp_cap = 0; return rc; }
-    ws->tmp_cap = cap_b / eb;
-  }
+  // (capacities in BYTES: ensure_dev rounds to 256, and a capacity kept in elements loses the remainder for 24-byte elements --
+  // Ft191 then re-allocated, i.e. hipFree-synchronised, on every call)
+  if (int rc = ensure_dev(err, &ws->d_tmp, &ws->tmp_cap, n_rows * pl.n_out * eb)) return rc;
   if (n_rows >= sdig_t_min_rows()) {
     // fast path: position-major working copy T[pos][row] (lane = row: contiguous gathers, wave-uniform matrix)
-    {
-      uint64_t cap_b = ws->t_cap * eb;
-      int rc = ensure_dev(err, &ws->d_t, &cap_b, n_rows * c->n_cols * eb);
-      if (rc) { ws->t_cap = 0; return rc; }
-      ws->t_cap = cap_b / eb;
-    }
+    if (int rc = ensure_dev(err, &ws->d_t, &ws->t_cap, n_rows * c->n_cols * eb)) return rc;
     ECHK(launch_transpose_to_t(c->NL, j.src, j.src_stride, j.n_valid, n_rows, ws->d_t, st, j.n_src_total, j.copy_dst));
     nl++;
     uint64_t in_start = 0;

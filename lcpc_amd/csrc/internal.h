@@ -39,9 +39,9 @@ struct Pass { uint32_t t0, s, log_tj; int log_tile; };
 // commitment matrix) or, for lcpc_encode_rows, by the encoder context
 struct EncodeWs {
   uint32_t* d_tmp = nullptr;       // last precode output, n_rows x m_last
-  uint64_t tmp_cap = 0;
+  uint64_t tmp_cap = 0;            // bytes
   uint32_t* d_t = nullptr;         // position-major working copy T[pos][row] of the rows being encoded
-  uint64_t t_cap = 0;
+  uint64_t t_cap = 0;              // bytes
   uint32_t* d_mid = nullptr;       // Ligero, Ft255 two-pass plans: the 29-bit-limb intermediate between the passes (ntt_l9s.hip),
   uint64_t mid_cap = 0;            // rows_per_batch x n_cols x 36 bytes (bytes)
   bool mid_failed = false;         // the allocation failed once: stay on the packed intermediate (comm itself)
