@@ -43,7 +43,7 @@ static LeafArgs leaf_args(const lcpc_commit_t* m) {
   const lcpc_ctx* c = m->enc;
   LeafArgs la{};
   la.comm = m->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.col_stride = 1; la.n_cols = c->n_cols;
-  if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = 0; la.row_stride = 1; la.col_stride = m->n_rows_local; }
+  if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = c->t_canon ? 1u : 0u; la.row_stride = 1; la.col_stride = m->n_rows_local; }
   la.n_rows_total = m->n_rows;
   return la;
 }
@@ -133,7 +133,7 @@ static int encode_commit(lcpc_commit_t* m, const uint32_t* src, uint64_t n_src_t
   j.src = src; j.src_stride = c->n_per_row; j.n_valid = c->n_per_row; j.dst = m->d_comm; j.n_rows = m->n_rows_local;
   j.n_src_total = n_src_total;
   j.copy_dst = copy_coeffs ? m->d_coeffs : nullptr;
-  j.canon_out = c->comm_canon;
+  j.canon_out = c->prm.encoding == LCPC_ENC_SDIG ? c->t_canon : c->comm_canon;
   j.keep_t = true;
   bool kept = false;
   j.kept_t = &kept;
@@ -244,7 +244,7 @@ int open_columns_device(lcpc_commit_t* m, const uint64_t* d_cols, uint32_t n, ui
   const lcpc_ctx* c = m->enc;
   if (d_vals && m->n_rows_local) {
     if (m->comm_t)
-      HIPCHK(m, launch_gather_columns(c->NL, m->ws.d_t, m->n_rows_local, 1, m->n_rows_local, d_cols, n, d_vals, nullptr, st));
+      HIPCHK(m, launch_gather_columns(c->NL, m->ws.d_t, m->n_rows_local, 1, m->n_rows_local, d_cols, n, d_vals, c->t_canon ? c->d_r2 : nullptr, st));
     else
       HIPCHK(m, launch_gather_columns(c->NL, m->d_comm, m->n_rows_local, c->n_cols, 1, d_cols, n, d_vals, c->comm_canon ? c->d_r2 : nullptr, st));
   }
@@ -627,7 +627,7 @@ int lcpc_get_comm(lcpc_commit_t* m, uint64_t row0, uint64_t n, uint64_t* out) {
     m->comm_rows_valid = true;
   }
   const uint32_t* src = m->d_comm + (size_t)(row0 - m->row_begin) * c->n_cols * c->NL;
-  if (!c->comm_canon || m->comm_t) {
+  if (!(m->comm_t ? c->t_canon : c->comm_canon)) {
     HIPCHK(m, hipMemcpy(out, src, (size_t)n * c->n_cols * eb, hipMemcpyDeviceToHost));
     return 0;
   }

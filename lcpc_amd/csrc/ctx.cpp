@@ -216,7 +216,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
   if (n_rows >= sdig_t_min_rows()) {
     // fast path: position-major working copy T[pos][row] (lane = row: contiguous gathers, wave-uniform matrix)
     if (int rc = ensure_dev(err, &ws->d_t, &ws->t_cap, n_rows * c->n_cols * eb)) return rc;
-    ECHK(launch_transpose_to_t(c->NL, j.src, j.src_stride, j.n_valid, n_rows, ws->d_t, st, j.n_src_total, j.copy_dst));
+    ECHK(launch_transpose_to_t(c->NL, j.src, j.src_stride, j.n_valid, n_rows, ws->d_t, st, j.n_src_total, j.copy_dst, j.canon_out && j.keep_t));
     nl++;
     uint64_t in_start = 0;
     SpmmTArgs a{};
@@ -573,6 +573,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
   if (!rc) rc = dev_alloc(err, &c->d_r2, 8 * f->L);
   if (rc) return rc;
   HIPCHK(c, hipMemcpy(c->d_r2, f->r2, 8 * f->L, hipMemcpyHostToDevice));
+  c->t_canon = !getenv("LCPC_COMM_MONT");                  // commits keep the position-major commitment canonical (kernels.hip transpose_to_t_kernel)
   if (dbg) fprintf(stderr, "[SdigEncoding::new] matgen %.1f ms, convert + upload %.1f ms\n", t_gen1 - t_gen0, now() - t_gen1);
   return 0;
 }

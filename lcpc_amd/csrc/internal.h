@@ -76,6 +76,8 @@ struct lcpc_ctx {
   uint32_t* d_roots29 = nullptr;   // Ft255: twiddles in radix-2^29 / R'=2^261 Montgomery form (field_dev.h fe_mul_r29)
   uint32_t* d_qp29 = nullptr;      // Ft255: q*p as 29-bit limbs (l9::clamp); null = packed-form NTT kernel
   uint32_t* d_roots29c = nullptr;  // Ft255 lazy-limb kernel: w^i * 2^5, the table that converts to canonical on the fly
+  bool t_canon = false;            // Brakedown: the position-major commitment of a commit (ws.d_t, >= sdig_t_min_rows() rows) holds
+                                   // canonical values: converted once in the input transpose, kept by every (linear) level
   bool comm_canon = false;         // d_comm of a commit holds canonical values (x * R^-1), not Montgomery form: the column
                                    // hash reads them as they are; every read-out (get_comm, open_columns) converts back
   std::vector<lcpc::Pass> passes;

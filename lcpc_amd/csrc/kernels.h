@@ -126,7 +126,8 @@ hipError_t launch_spmv(int nl, const SpmvArgs& a, hipStream_t st);
 // ---- position-major ("transposed") Brakedown path: T[pos][row], row fastest -----------------------
 // rows x n_valid block of a row-major matrix -> T (leading dimension n_rows); and back
 hipError_t launch_transpose_to_t(int nl, const uint32_t* src, uint64_t src_stride, uint64_t n_valid, uint64_t n_rows,
-                                 uint32_t* t, hipStream_t st, uint64_t n_src_total = ~(uint64_t)0, uint32_t* copy_dst = nullptr);
+                                 uint32_t* t, hipStream_t st, uint64_t n_src_total = ~(uint64_t)0, uint32_t* copy_dst = nullptr,
+                                 bool canon = false);   // canon: T receives canonical values (x R^-1); copy_dst the values as read
 hipError_t launch_transpose_from_t(int nl, const uint32_t* t, uint64_t n_pos, uint64_t n_rows, uint32_t* dst,
                                    uint64_t dst_stride, hipStream_t st);
 struct SpmmTArgs {

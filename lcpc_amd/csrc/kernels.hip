@@ -1129,7 +1129,7 @@ hipError_t launch_sdig_rs(int nl, const u32* in, u64 in_stride, u32 n_in, u32* m
 // =================================================================================================
 template <int NL>
 __global__ void __launch_bounds__(256) transpose_to_t_kernel(const u32* src, u64 src_stride, u64 n_valid, u64 n_rows, u32* t,
-                                                            u64 n_src_total, u32* copy_dst) {
+                                                            u64 n_src_total, u32* copy_dst, u32 canon) {
   // tile: 32 positions x 32 rows; LDS holds it row-major with a one-element pad
   __shared__ u32 tile[32 * 33 * NL];
   const u64 p0 = (u64)blockIdx.x * 32, r0 = (u64)blockIdx.y * 32;
@@ -1141,8 +1141,17 @@ __global__ void __launch_bounds__(256) transpose_to_t_kernel(const u32* src, u64
       // (lcpc-2d lib.rs:636-645) is written here, where every message element is loaded exactly once
       const Fe<NL> v = (r * src_stride + p < n_src_total) ? fe_load<NL>(src + (r * src_stride + p) * NL) : fe_zero<NL>();
       if (copy_dst != nullptr) fe_store<NL>(copy_dst + (r * src_stride + p) * NL, v);
+      // canon: the working copy starts from canonical values x R^-1.  Every later step is linear with Montgomery-form
+      // constants (dot products with the matrix values, Horner in the R-S base case), i.e. keeps the form of its input, so the
+      // whole codeword comes out canonical and the column hash reads it as it is -- the one reduction per element happens
+      // here, in a kernel that waits for memory, instead of in the hash kernel, which is bound by VALU issue
+      Fe<NL> u = v;
+      if (canon) {
+        if constexpr (NL == 8) u = fe_canon_r29(v);            // 72 carry-free mads instead of the packed-limb reduction
+        else u = fe_canon<NL>(v);
+      }
 #pragma unroll
-      for (int w = 0; w < NL; w++) tile[(rr * 33 + tx) * NL + w] = v.v[w];
+      for (int w = 0; w < NL; w++) tile[(rr * 33 + tx) * NL + w] = u.v[w];
     }
   }
   __syncthreads();
@@ -1181,11 +1190,11 @@ __global__ void __launch_bounds__(256) transpose_from_t_kernel(const u32* t, u64
   }
 }
 hipError_t launch_transpose_to_t(int nl, const u32* src, u64 src_stride, u64 n_valid, u64 n_rows, u32* t, hipStream_t st,
-                                 u64 n_src_total, u32* copy_dst) {
+                                 u64 n_src_total, u32* copy_dst, bool canon) {
   if (!n_valid || !n_rows) return hipSuccess;
   dim3 grid((unsigned)((n_valid + 31) / 32), (unsigned)((n_rows + 31) / 32));
   LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL(transpose_to_t_kernel<NLV>, grid, dim3(256), 0, st, src, src_stride, n_valid, n_rows, t,
-                                          n_src_total, copy_dst));
+                                          n_src_total, copy_dst, canon ? 1u : 0u));
   return hipGetLastError();
 }
 hipError_t launch_transpose_from_t(int nl, const u32* t, u64 n_pos, u64 n_rows, u32* dst, u64 dst_stride, hipStream_t st) {

@@ -241,7 +241,7 @@ static int commit_shard_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, ui
     const uint32_t* src = reinterpret_cast<const uint32_t*>(coeffs_local);
     EncodeJob j;
     j.src_stride = c->n_per_row; j.n_valid = c->n_per_row; j.dst = m->d_comm; j.n_rows = m->n_rows_local;
-    j.canon_out = c->comm_canon; j.keep_t = true;
+    j.canon_out = c->prm.encoding == LCPC_ENC_SDIG ? c->t_canon : c->comm_canon; j.keep_t = true;
     bool kept = false;
     j.kept_t = &kept;
     if (borrow) {
@@ -269,7 +269,7 @@ static int commit_shard_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, ui
     for (int k = 0; k < n_nodes; k++) all_single = all_single && lg[k] == 0;
     LeafArgs la{};
     la.comm = m->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.col_stride = 1; la.n_cols = c->n_cols; la.row_base = (int64_t)rb;
-    if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = 0; la.row_stride = 1; la.col_stride = m->n_rows_local; }
+    if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = c->t_canon ? 1u : 0u; la.row_stride = 1; la.col_stride = m->n_rows_local; }
     la.n_rows_total = n_rows_total; la.chunk_begin = (uint32_t)cb; la.n_chunks_local = (uint32_t)(ce - cb);
     la.n_chunks_total = (uint32_t)nch;
     if (all_single) {                       // nothing to pre-merge: chunk CVs are the nodes

@@ -355,6 +355,45 @@ def test_ab_switch_paths_stay_correct(oracle, switch):
     assert pf.to_bytes() == opf
 
 
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+@pytest.mark.parametrize("mont", [False, True])
+def test_brakedown_position_major_commitment_forms(oracle, fid, mont):
+    """Brakedown commits with >= 24 rows keep the commitment position-major on the device, by default as canonical values
+    (converted once in the input transpose; every level is linear and keeps the form; the column hash reads them as they are)
+    and with LCPC_COMM_MONT=1 in Montgomery form (the hash kernel reduces each element).  Everything that leaves the
+    library -- comm, coeffs, hashes, opened columns, proof bytes, the bincode of the commitment -- is the oracle's in both."""
+    import os
+    O = oracle
+    n_per_row, n_rows = 900, 37
+    oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 5)
+    _, _, n_cols = oenc.get_dims(n_per_row)
+    if mont:
+        os.environ["LCPC_COMM_MONT"] = "1"
+    try:
+        enc = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 5)
+    finally:
+        os.environ.pop("LCPC_COMM_MONT", None)
+    coeffs = O.random_elems(fid, n_rows * n_per_row - 11, 40 + fid)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+    assert c.get_root() == oc.get_root() and (c.hashes() == oc.hashes()).all()
+    cols = [0, 1, n_per_row - 1, n_per_row, n_cols - 1, n_cols // 2 + 3]
+    vals, paths = c.open_columns(cols)
+    ocomm = oc.comm().reshape(n_rows, n_cols, fid + 1)
+    assert (vals == ocomm[:, cols].transpose(1, 0, 2)).all()
+    assert (c.comm() == oc.comm()).all() and (c.coeffs() == oc.coeffs()).all()
+    root = c.get_root()
+    t = O.random_elems(fid, c.n_rows, 79)
+    pf = c.prove(t, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+    opf, _ = oc.prove(t, oenc, mk_transcript(O.Transcript, root, enc.get_n_col_opens()))
+    assert pf.to_bytes() == opf
+    from common import commit_bincode
+    import io
+    buf = io.BytesIO()
+    c.to_bincode(buf)
+    assert buf.getvalue() == commit_bincode(oc)
+
+
 def test_many_short_rows_exceed_grid_y(oracle):
     """A commitment made with new_from_dims and a small n_per_row has more BLAKE3 chunks per leaf message than a grid
     dimension may hold (65535): 2.2 M rows of 8 Ft255 coefficients -> 68 751 chunks.  The column hash launches the chunk

@@ -32,14 +32,21 @@ def time_commit(name, enc, n, L, iters=5):
     coeffs = rand_coeffs(n, L, 1)
     st = torch.cuda.current_stream().cuda_stream
     c = LcCommit(enc)                       # one LcCommit object, refilled (no allocation inside the loop)
-    for _ in range(2):
-        LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False, borrow=BORROW, into=c)
-    torch.cuda.synchronize()
+    # >= 0.1 s of warm-up, then >= 0.2 s (and >= iters) back-to-back commits: after the idle set-up the device needs tens of
+    # milliseconds to come back to working clocks (bench.py's setup steps; tools/bench_fields.py)
     t0 = time.perf_counter()
-    for _ in range(iters):
-        LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False, borrow=BORROW, into=c)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    while time.perf_counter() - t0 < 0.1:
+        for _ in range(2):
+            LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False, borrow=BORROW, into=c)
+        torch.cuda.synchronize()
+    reps = 0
+    t0 = time.perf_counter()
+    while reps < iters or time.perf_counter() - t0 < 0.2:
+        for _ in range(iters):
+            LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False, borrow=BORROW, into=c)
+        torch.cuda.synchronize()
+        reps += iters
+    dt = (time.perf_counter() - t0) / reps
     c.set_timing(True)
     LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=True, borrow=BORROW, into=c)
     tm = c.timings()
