@@ -1296,11 +1296,12 @@ __device__ __forceinline__ Fe<NL> spmm_t_terms(const SpmmTArgs& a, const u32* xi
 }
 
 // OPW = outputs per workgroup (4: the wide levels; narrower ones go to spmm_t_sliced_kernel)
+// n_main: the rows this launch covers, [0, n_main) (all of them, or the whole 64-row groups when spmm_t_tail_kernel takes the rest)
 template <int NL, int SPMM_OPW>
-__global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a) {
+__global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a, u32 n_main) {
   const u64 row = (u64)blockIdx.y * 128 + threadIdx.x;
-  if ((row & ~(u64)63) >= a.n_rows) return;          // a wave with no row at all (<= 64 rows: the workgroup's second wave)
-  const bool live = row < a.n_rows;
+  if ((row & ~(u64)63) >= n_main) return;            // a wave with no row at all (<= 64 rows: the workgroup's second wave)
+  const bool live = row < n_main;
   const u64 rr = live ? row : 0;                     // dead lanes recompute row 0 and do not store
   const u32* xin = a.t + (a.in_off * a.n_rows + rr) * NL;
   const size_t pstride = (size_t)a.n_rows * NL;      // words between consecutive positions
@@ -1314,6 +1315,63 @@ __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a) {
       u32* dst = a.out_alt ? a.out_alt + (o * a.n_rows + row) * NL : a.t + ((a.out_off + o) * a.n_rows + row) * NL;
       fe_store<NL>(dst, res);
     }
+  }
+}
+
+// Rows [n_main, n_rows) of every output, n_rows - n_main < 64: under the lane = row mapping they fill a fraction of a wave
+// (C3's 101 rows: 37 of the second wave's 64 lanes, 21 % of all issued lanes idle in a kernel that VALU issue binds).  Here the
+// lanes run over (output, tail row) pairs back to back, so that a wave holds the tails of two or three outputs and is full.
+// The price: matrix entries are per lane (vector loads; 64 lanes share two or three distinct entries, L1 hits) instead of
+// scalar, and a wave runs as long as its longest output.  Same dot products, same reduction points (every <= 60 terms).
+__global__ void __launch_bounds__(256) spmm_t_tail_kernel(SpmmTArgs a, u32 n_main) {
+  constexpr int NL = 8;
+  const u32 tail = (u32)a.n_rows - n_main;
+  const u64 total = a.m * tail;
+  const u64 flat = (u64)blockIdx.x * 256 + threadIdx.x;
+  if ((flat & ~(u64)63) >= total) return;
+  const bool live = flat < total;
+  const u64 f = live ? flat : total - 1;             // dead lanes shadow the last pair and do not store
+  const u64 o = f / tail;
+  const u32 row = n_main + (u32)(f - o * tail);
+  const u32 k0 = a.rowptr[o], len = a.rowptr[o + 1] - k0;
+  u32 maxlen = len;                                   // the wave's trip count
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const u32 other = (u32)__shfl_xor((int)maxlen, d, 64); maxlen = other > maxlen ? other : maxlen; }
+  maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+  const u32* xin = a.t + (a.in_off * a.n_rows + row) * NL;
+  const size_t pstride = (size_t)a.n_rows * NL;
+  auto load_v = [&](u32 k) {
+    Fe29 v;
+    const uint4* p = reinterpret_cast<const uint4*>(a.vals29 + (size_t)k * 12);
+    const uint4 lo = p[0], hi = p[1];
+    v.v[0] = lo.x; v.v[1] = lo.y; v.v[2] = lo.z; v.v[3] = lo.w; v.v[4] = hi.x; v.v[5] = hi.y; v.v[6] = hi.z; v.v[7] = hi.w;
+    v.v[8] = a.vals29[(size_t)k * 12 + 8];
+    return v;
+  };
+  Fe<NL> res = fe_zero<NL>();
+  Fe<NL> x = fe_zero<NL>();
+  Fe29 v;
+#pragma unroll
+  for (int i = 0; i < 9; i++) v.v[i] = 0;
+  if (len) { x = fe_load<NL>(xin + (size_t)a.colidx[k0] * pstride); v = load_v(k0); }
+  for (u32 ib = 0; ib < maxlen; ib += 60) {
+    const u32 ie = ib + 60 < maxlen ? ib + 60 : maxlen;
+    Lazy29 acc;
+    lazy29_zero(acc);
+    u32 since = 0;
+    for (u32 i = ib; i < ie; i++) {
+      Fe<NL> xn = x;
+      Fe29 vn = v;
+      if (i + 1 < len) { xn = fe_load<NL>(xin + (size_t)a.colidx[k0 + i + 1] * pstride); vn = load_v(k0 + i + 1); }
+      if (i < len) lazy29_mac(acc, fe_to29(x), v);
+      if (++since == 6) { lazy29_normalize(acc); since = 0; }
+      x = xn; v = vn;
+    }
+    res = fe_add<NL>(res, lazy29_reduce(acc));
+  }
+  if (live) {
+    u32* dst = a.out_alt ? a.out_alt + (o * a.n_rows + row) * NL : a.t + ((a.out_off + o) * a.n_rows + row) * NL;
+    fe_store<NL>(dst, res);
   }
 }
 
@@ -1359,8 +1417,19 @@ __global__ void __launch_bounds__(128 * SL) spmm_t_sliced_kernel(SpmmTArgs a) {
 hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st) {
   if (a.m == 0 || a.n_rows == 0) return hipSuccess;
   if (a.m >= 8192) {
-    dim3 grid((unsigned)((a.m + 3) / 4), (unsigned)((a.n_rows + 127) / 128));
-    LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_kernel<NLV, 4>), grid, dim3(128), 0, st, a));
+    // a last group of <= 48 rows goes to the packed-tail kernel (Ft255 limb path), the whole 64-row groups stay lane = row
+    u32 n_main = (u32)a.n_rows;
+    const u32 tail = (u32)(a.n_rows & 63);
+    const bool tail_on = !getenv("LCPC_SDIG_NO_TAIL");           // (read per call: tests switch it)
+    if (nl == 8 && a.vals29 != nullptr && tail != 0 && tail <= 48 && tail_on) n_main -= tail;
+    if (n_main) {
+      dim3 grid((unsigned)((a.m + 3) / 4), (unsigned)((n_main + 127) / 128));
+      LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_kernel<NLV, 4>), grid, dim3(128), 0, st, a, n_main));
+    }
+    if (n_main != (u32)a.n_rows) {
+      const u64 total = a.m * (a.n_rows - n_main);
+      hipLaunchKernelGGL(spmm_t_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, n_main);
+    }
   } else if (a.m > 2048) {
     dim3 grid((unsigned)a.m, (unsigned)((a.n_rows + 127) / 128));
     LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_sliced_kernel<NLV, 2>), grid, dim3(256), 0, st, a));

@@ -394,6 +394,30 @@ def test_brakedown_position_major_commitment_forms(oracle, fid, mont):
     assert buf.getvalue() == commit_bincode(oc)
 
 
+@pytest.mark.parametrize("n_rows", [37, 40, 48, 49, 101, 130, 167])
+def test_brakedown_packed_tail_rows(oracle, n_rows):
+    """Ft255 Brakedown, wide levels: a last group of <= 48 rows is computed by spmm_t_tail_kernel (lanes over (output, row) pairs,
+    per-lane matrix entries) instead of a mostly idle wave of the lane = row kernel; LCPC_SDIG_NO_TAIL=1 keeps the old mapping.
+    Both equal the oracle -- tail only (37, 40, 48 rows), just above the limit (49: no tail kernel), one and two whole groups
+    before the tail (101, 130, 167).  n_per_row is large enough for the first levels to have >= 8192 outputs."""
+    import os
+    O, fid, n_per_row = oracle, 3, 70000
+    oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 9)
+    _, _, n_cols = oenc.get_dims(n_per_row)
+    enc = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 9)
+    coeffs = O.random_elems(fid, n_rows * n_per_row - 3, 50 + n_rows)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=8)
+    c = LcCommit.commit(coeffs, enc)
+    os.environ["LCPC_SDIG_NO_TAIL"] = "1"
+    try:
+        d = LcCommit.commit(coeffs, enc)
+    finally:
+        del os.environ["LCPC_SDIG_NO_TAIL"]
+    assert c.get_root() == oc.get_root() == d.get_root()
+    assert (c.hashes() == oc.hashes()).all()
+    assert (c.comm() == oc.comm()).all() and (d.comm() == oc.comm()).all()
+
+
 def test_many_short_rows_exceed_grid_y(oracle):
     """A commitment made with new_from_dims and a small n_per_row has more BLAKE3 chunks per leaf message than a grid
     dimension may hold (65535): 2.2 M rows of 8 Ft255 coefficients -> 68 751 chunks.  The column hash launches the chunk
