@@ -74,7 +74,8 @@ static void plan_passes(lcpc_ctx* c) {
   auto n_pass = [&](int lt) { unsigned per = lt - ltj_min, rest = k - lt; return 1 + (rest + per - 1) / per; };
   if (c->d_qp29 && (k == 19 || k == 20) && !getenv("LCPC_NTT_GENERAL") && !getenv("LCPC_NTT_TILE2048")) {
     // Ft255, 2^19 / 2^20 columns (C4's shape): still two passes on 1024-element tiles for the shape-specialised kernel,
-    // whose first pass then moves 64- / 32-byte runs -- it is VALU-bound with HBM to spare (measured: DESIGN.md section 4)
+    // whose first pass then moves 64- / 32-byte runs -- affordable because the tiles that share those cache lines run back
+    // to back on one XCD (ntt_tile_group below; measured: DESIGN.md section 4 K1s)
     c->passes.push_back({0, k - 10, 20 - k, 10});
     c->passes.push_back({k - 10, 10, 0u, 10});
     return;
