@@ -25,7 +25,7 @@ void ctx_ref(lcpc_ctx* c) { c->refs.fetch_add(1); }
 static void ctx_free(lcpc_ctx* c) {
   (void)hipSetDevice(c->prm.device);
   comm_release(c);
-  dev_free(c->d_pack[0]); dev_free(c->d_pack[1]);
+  dev_free(c->d_pack[0]); dev_free(c->d_pack[1]); dev_free(c->d_pack[2]); dev_free(c->d_roots29s); dev_free(c->d_roots29cs);
   dev_free(c->d_rootsl); dev_free(c->d_rootslc); dev_free(c->d_qpl); dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
   dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->ws.d_mid); dev_free(c->d_scratch);
   if (c->h_varena) (void)hipHostFree(c->h_varena);
@@ -99,15 +99,16 @@ static void plan_passes(lcpc_ctx* c) {
 // time 1 KiB (2 KiB for runs of <= 32 bytes), which is what measured best (build-time A/B in one process, DESIGN.md K1s: n_cols
 // 2^20 -27 % on boxes where the ungrouped order is slow, -4 % elsewhere; 2^19 -3 %; the headline's 128-byte runs -0.5 to -1 %).
 // LCPC_NTT_TILE_GROUP=<log2> overrides (0 = the plain XCD-aware order); read per call so that tests can switch it
-static uint32_t ntt_tile_group(const lcpc_ctx* c, const Pass& first) {
-  const uint32_t tiles_log = c->log_n - 10;
+static uint32_t ntt_tile_group_of(uint32_t log_n, int L, uint32_t log_tj) {
+  const uint32_t tiles_log = log_n - 10;
   if (tiles_log < 3) return 0;
-  uint32_t run_log = first.log_tj;                                        // log2(run bytes)
-  for (uint32_t b = 8u * (uint32_t)c->L; b > 1; b >>= 1) run_log++;
+  uint32_t run_log = log_tj;                                              // log2(run bytes)
+  for (uint32_t b = 8u * (uint32_t)L; b > 1; b >>= 1) run_log++;
   uint32_t lg = run_log <= 5 ? 11 - run_log : (run_log < 10 ? 10 - run_log : 0);
   if (const char* ev = getenv("LCPC_NTT_TILE_GROUP")) lg = (uint32_t)strtoul(ev, nullptr, 10);
   return std::min(std::min(lg, 6u), tiles_log - 3);
 }
+static uint32_t ntt_tile_group(const lcpc_ctx* c, const Pass& first) { return ntt_tile_group_of(c->log_n, c->L, first.log_tj); }
 
 #define ECHK(call)                                                        \
   do {                                                                    \
@@ -155,6 +156,37 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
         ECHK(launch_ntt_pass_l9s(a, first, c->d_pack[i], c->pack_info[i], st));
         nl++;
       }
+    }
+    return 0;
+  }
+  if (c->prm.encoding == LCPC_ENC_LIGERO && c->l9s3) {
+    // 2^21 .. 2^26 columns: s0 stages with the first-pass kernel over the whole rows (zero padding, ragged tail and the coeffs
+    // copy live there), then every row is 2^s0 independent 2^20-point transforms: the two-pass plan on n_rows << s0 sub-rows, in
+    // place, with the sub-sampled tables.  Canonical output: after the first pass only sub-row 0 of each row still holds
+    // never-multiplied elements ("block 0"), so only those sub-rows take the converting twiddles / the prefix reduction
+    const uint32_t s0 = c->log_n - 20;
+    for (int i = 0; i < 3; i++) {
+      const Pass& p = c->passes[i];
+      const bool first = i == 0, sub = i > 0;
+      NttPassArgs a{};
+      a.dst = j.dst;
+      a.src = first ? j.src : j.dst;
+      a.roots = c->d_roots; a.qp29 = c->d_qp29;
+      a.roots29 = sub ? c->d_roots29s : c->d_roots29;
+      a.roots29c = j.canon_out ? (sub ? c->d_roots29cs : c->d_roots29c) : nullptr;
+      a.canon_row_mask = sub ? (1u << s0) - 1 : 0u;
+      a.mont_prefix = (j.canon_out && i == 2) ? 4u : 0u;
+      a.src_stride = first ? j.src_stride : ((uint64_t)1 << 20);
+      a.dst_stride = first ? c->n_cols : ((uint64_t)1 << 20);
+      a.n_valid = first ? j.n_valid : ((uint64_t)1 << 20);
+      a.n_src_total = first ? j.n_src_total : ~(uint64_t)0;
+      a.copy_dst = first ? j.copy_dst : nullptr;
+      a.n_rows = first ? n_rows : n_rows << s0;
+      a.log_n = first ? c->log_n : 20u;
+      a.t0 = i == 2 ? 10u : 0u; a.s = p.s; a.log_tj = p.log_tj;
+      a.tile_group = i == 0 ? ntt_tile_group_of(c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(20, c->L, 0) : 0u);
+      ECHK(launch_ntt_pass_l9s(a, i < 2, c->d_pack[i], c->pack_info[i], st));
+      nl++;
     }
     return 0;
   }
@@ -461,6 +493,32 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       }
       HIPCHK(c, hipDeviceSynchronize());
       c->l9s = true;
+    } else if (c->d_qp29 && !getenv("LCPC_NTT_GENERAL") && !getenv("LCPC_NTT_NO_3PASS") && ntt_l9s3_supported(c->log_n)) {
+      // three passes of the shape-specialised kernel (kernels.h ntt_l9s3_supported): tables for the 2^20-point sub-transforms,
+      // pack 0 for the first pass over the whole rows (one class per tile position: 2^(log_n - 10)), packs 1 / 2 = those of a
+      // 2^20-column context
+      const unsigned k = c->log_n, s0 = k - 20;
+      const size_t n_sub = (size_t)1 << 19;
+      if ((rc = dev_alloc(err, &c->d_roots29s, n_sub * 48)) || (rc = dev_alloc(err, &c->d_roots29cs, n_sub * 48))) return rc;
+      HIPCHK(c, launch_ntt_l9s_subtable(c->d_roots29, s0, n_sub, c->d_roots29s, nullptr));
+      HIPCHK(c, launch_ntt_l9s_subtable(c->d_roots29c, s0, n_sub, c->d_roots29cs, nullptr));
+      c->passes.clear();
+      c->passes.push_back({0, s0, 10 - s0, 10});
+      c->passes.push_back({s0, 10, 0u, 10});
+      c->passes.push_back({s0 + 10, 10, 0u, 10});
+      for (int i = 0; i < 3; i++) {
+        const Pass& ps = c->passes[i];
+        const bool first = i < 2;                              // passes 0 and 1 run the first-pass kernel
+        NttPassArgs a{};
+        a.roots29 = i == 0 ? c->d_roots29 : c->d_roots29s; a.roots29c = i == 0 ? c->d_roots29c : c->d_roots29cs;
+        a.log_n = i == 0 ? k : 20u; a.t0 = i == 2 ? 10u : 0u; a.s = ps.s; a.log_tj = ps.log_tj;
+        c->pack_info[i] = ntt_l9s_pack_info(ps.s, first);
+        const uint32_t n_classes = i == 0 ? 1u << (k - 10) : (i == 1 ? 1024u : 1u);
+        if ((rc = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return rc;
+        HIPCHK(c, launch_ntt_l9s_pack(a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
+      }
+      HIPCHK(c, hipDeviceSynchronize());
+      c->l9s3 = true;
     }
     if (!c->d_qp29 && c->passes.size() >= 2 && !getenv("LCPC_NTT_GENERAL") && ntt_lns_supported(c->NL, c->log_n)) {
       // Ft63 / Ft127 / Ft191 rows that need more than one pass: two passes on 1024-element tiles with the lazy-limb

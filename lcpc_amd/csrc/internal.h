@@ -81,9 +81,12 @@ struct lcpc_ctx {
   bool comm_canon = false;         // d_comm of a commit holds canonical values (x * R^-1), not Montgomery form: the column
                                    // hash reads them as they are; every read-out (get_comm, open_columns) converts back
   std::vector<lcpc::Pass> passes;
-  uint32_t* d_pack[2] = {nullptr, nullptr};   // Ft255 two-pass plans: lane-order twiddle packs of the specialised kernel (ntt_l9s.hip)
-  lcpc::NttPackInfo pack_info[2]{};
+  uint32_t* d_pack[3] = {nullptr, nullptr, nullptr};   // Ft255 two- / three-pass plans: lane-order twiddle packs of the specialised kernel (ntt_l9s.hip)
+  lcpc::NttPackInfo pack_info[3]{};
   bool l9s = false;
+  bool l9s3 = false;               // 2^21 .. 2^26 columns: first-pass kernel over the whole rows, then the 2^20-point two-pass plan per block
+  uint32_t* d_roots29s = nullptr;  // l9s3: the 2^20-point twiddle tables (every 2^(log_n - 20)-th entry of d_roots29 / d_roots29c)
+  uint32_t* d_roots29cs = nullptr;
   // Ft63 / Ft127 / Ft191 two-pass plans: the lazy-limb kernel of ntt_lns.hip (packs in d_pack / pack_info as well)
   bool lns = false;
   uint32_t* d_rootsl = nullptr;    // w^i * R' mod p as N limbs of W bits (field_ln.h), ntt_lns_stride words per entry

@@ -25,6 +25,9 @@ struct NttPassArgs {
   uint32_t* mid = nullptr; // shape-specialised two-pass kernel only, may be null: the 29-bit-limb intermediate between the passes
                            // (n_rows x n_cols x 36 bytes, layout in ntt_l9s.hip); the first pass writes it instead of dst, the
                            // last pass reads it instead of src
+  uint32_t canon_row_mask = 0; // canonical output (roots29c != null) applies to the rows r with (r & canon_row_mask) == 0 only: the
+                           // three-pass plan runs its last two passes on n_rows << s0 sub-rows of 2^20 elements, of which only every
+                           // 2^s0-th still holds never-multiplied elements (ntt_l9s.hip)
   uint32_t tile_group = 0; // shape-specialised first pass (ntt_l9s.hip, ntt_lns.hip): 2^tile_group neighbouring tiles of a row are
                            // consecutive workgroups of one XCD (short strided runs then meet in that L2); needs
                            // tiles_per_row >= 8 << tile_group
@@ -38,6 +41,12 @@ struct NttPackInfo {
   uint32_t class_words;     // words per tile class
 };
 bool ntt_l9s_supported(uint32_t log_n, uint32_t n_passes, int log_tile);
+// three passes for 2^21 .. 2^26 columns: s0 = log_n - 20 stages with the first-pass kernel on the whole rows (element stride 2^20),
+// then the two-pass plan of a 2^20-point transform on each of the 2^s0 contiguous blocks of every row (DIF: after s0 stages the
+// blocks are independent transforms with the root w^(2^s0)), from a sub-sampled twiddle table
+bool ntt_l9s3_supported(uint32_t log_n);
+// sub[i] = tab[i << shift], 12-word entries, i < n
+hipError_t launch_ntt_l9s_subtable(const uint32_t* tab, uint32_t shift, uint64_t n, uint32_t* sub, hipStream_t st);
 NttPackInfo ntt_l9s_pack_info(uint32_t s, bool first);
 // a: the pass (log_n, t0, s, log_tj, roots29, roots29c); first pass: n_classes = tiles per row, last pass: 1
 hipError_t launch_ntt_l9s_pack(const NttPassArgs& a, bool first, const NttPackInfo& pi, uint32_t n_classes, uint32_t* pack, hipStream_t st);

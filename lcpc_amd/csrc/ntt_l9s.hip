@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     if constexpr (FIRST) return ((e >> LBT) << lb) | (tile << LTJ) | (e & ((1u << LBT) - 1));
     else return (tile << S) | e;
   };
-  const bool canon = a.roots29c != nullptr;
+  const bool canon = a.roots29c != nullptr && ((u32)row & a.canon_row_mask) == 0;     // (wave-uniform)
   for (u32 i = tid; i < 64 * 12; i += 256) nqp[i] = 0u - a.qp29[i];
   const u32* src = a.src + row * a.src_stride * NL;
   if constexpr (LAST && MID) {
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       // -> [0, p): after the clamp, value >= p needs the top limb to reach floor(p / 2^232) -- about one element in 2^17;
       // the conditional subtract runs only in the waves that hold such an element
       if (__any((int)(x.v[8] >= (u32)P29::limb(8)))) v = fe_reduce_once8(w);
-      if (tile == 0 && g < a.mont_prefix) v = fe_canon_r29(v);          // canonical output: the never-multiplied prefix
+      if (canon && tile == 0 && g < a.mont_prefix) v = fe_canon_r29(v); // canonical output: the never-multiplied prefix
     }
     fe_store<NL>(dst + (size_t)g * NL, v);
   }
@@ -341,6 +341,19 @@ hipError_t launch_t(const NttPassArgs& a, const u32* pack, const NttPackInfo& pi
 
 }  // namespace
 
+bool ntt_l9s3_supported(uint32_t log_n) { return log_n >= 21 && log_n <= 26; }
+
+__global__ void __launch_bounds__(256) subtable_kernel(const u32* tab, u32 shift, u64 n, u32* sub) {
+  for (u64 id = (u64)blockIdx.x * 256 + threadIdx.x; id < n * 3; id += (u64)gridDim.x * 256) {
+    const u64 i = id / 3, c = id % 3;
+    reinterpret_cast<uint4*>(sub)[i * 3 + c] = reinterpret_cast<const uint4*>(tab)[(i << shift) * 3 + c];
+  }
+}
+hipError_t launch_ntt_l9s_subtable(const uint32_t* tab, uint32_t shift, uint64_t n, uint32_t* sub, hipStream_t st) {
+  hipLaunchKernelGGL(subtable_kernel, dim3(2048), dim3(256), 0, st, tab, shift, n, sub);
+  return hipGetLastError();
+}
+
 bool ntt_l9s_supported(uint32_t log_n, uint32_t n_passes, int log_tile) { return n_passes == 2 && log_tile == 10 && log_n >= 11 && log_n <= 20; }
 
 #define L9S_FIRST_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
@@ -375,7 +388,8 @@ hipError_t launch_ntt_pass_l9s(const NttPassArgs& a, bool first, const uint32_t*
     if (a.s != 10 || a.log_tj != 0 || a.t0 + a.s != a.log_n) return hipErrorInvalidValue;
     return launch_t<10, 0, false>(a, pack, pi, st);
   }
-  if (a.t0 != 0 || a.s + a.log_tj != 10 || a.s + 10 != a.log_n) return hipErrorInvalidValue;
+  // two-pass plans: s + 10 stages in all; three-pass plans: s + 20 (the first pass works at element stride 2^20)
+  if (a.t0 != 0 || a.s + a.log_tj != 10 || (a.s + 10 != a.log_n && a.s + 20 != a.log_n)) return hipErrorInvalidValue;
   if (a.tile_group && ((1u << (a.log_n - 10)) >> a.tile_group) < 8) return hipErrorInvalidValue;
   switch (a.s) {
 #define X(SV) case SV: return launch_t<SV, 10 - SV, true>(a, pack, pi, st);

@@ -79,3 +79,36 @@ def test_limb_intermediate_modes_agree(oracle, log_n, mid_mb):
     assert (g.comm() == c.comm()).all() and (g.hashes() == c.hashes()).all() and (g.coeffs() == c.coeffs()).all()
     assert g.get_root() == oc.get_root() and (c.comm() == oc.comm()).all()
     assert (e == oc.comm()).all()
+
+
+@pytest.mark.parametrize("log_n,rate", [(21, "1/2"), (21, "38/39"), (21, "1/4"), (21, "1/2-"), (22, "1/2"), (22, "38/39"), (23, "1/2"), (23, "3/4"), (24, "1/2")])
+def test_commit_three_pass_shapes(oracle, log_n, rate):
+    """2^21 .. 2^26 columns (reachable on a 288 GB device: the reference's 38/39-rate dims at 2^30 .. 2^32 coefficients): s0 =
+    log_n - 20 stages with the first-pass kernel over the whole rows, then the 2^20-point two-pass plan on each of the 2^s0 blocks
+    of a row, canonical output only in block 0.  Commit (2 rows, the second ragged) and encode_rows against the oracle; the
+    general kernel's three-pass plan (LCPC_NTT_NO_3PASS=1) must give the same bytes."""
+    O, fid = oracle, 3
+    n_cols = 1 << log_n
+    n_per_row, rho = {"1/2": (n_cols // 2, (1, 2)), "1/4": (n_cols // 4, (1, 4)), "38/39": (n_cols * 38 // 39, (38, 39)),
+                      "3/4": (n_cols * 3 // 4, (3, 4)), "1/2-": (n_cols // 2 - 3, (1, 2))}[rate]
+    n = n_per_row + max(1, n_per_row // 3)
+    coeffs = O.random_elems(fid, n, log_n * 5 + len(rate))
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, rho=rho)
+    oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols, rho=rho)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=8)
+    assert c.get_root() == oc.get_root()
+    assert (c.hashes() == oc.hashes()).all()
+    assert (c.comm() == oc.comm()).all()
+    assert (c.coeffs() == oc.coeffs()).all()
+    rows = np.zeros((n_cols, 4), np.uint64)
+    rows[:n - n_per_row] = coeffs[n_per_row:]
+    assert (enc.encode(rows) == oc.comm()[n_cols:]).all()
+    if log_n <= 22:
+        os.environ["LCPC_NTT_NO_3PASS"] = "1"
+        try:
+            enc_g = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, rho=rho)
+        finally:
+            del os.environ["LCPC_NTT_NO_3PASS"]
+        g = LcCommit.commit(coeffs, enc_g)
+        assert (g.comm() == c.comm()).all() and (g.hashes() == c.hashes()).all()
