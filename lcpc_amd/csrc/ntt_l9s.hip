@@ -1,6 +1,7 @@
 // lcpc_amd/csrc/ntt_l9s.hip -- K1s: the shape-specialised Ft255 row NTT (LcEncoding::encode for Ligero,
 // lcpc-ligero-pc/src/lib.rs:162-164 = fffft fft_io_pc [3P]) for the two-pass plans on 1024-element tiles
-// (2^11 <= n_cols <= 2^18, which covers BASELINE.json's Ligero configs).
+// (2^11 <= n_cols <= 2^20, which covers BASELINE.json's Ligero configs) and, built from the same two kernels, three-pass plans
+// for 2^21 .. 2^26 columns (kernels.h ntt_l9s3_supported).
 //
 // Same tiling, same lazy signed 9 x 29-bit arithmetic and the same canonical-output trick as ntt_pass_l9_kernel
 // (kernels.hip, which stays the general kernel: one pass, three passes, 2048-element tiles); what differs is where the

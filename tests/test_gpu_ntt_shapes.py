@@ -2,7 +2,7 @@
 1 .. 10 stages (odd counts peel a radix-2 round at stage 0) on 1 .. 512-element runs, last pass of 10 stages.  For each:
 commit (canonical-output path, coeffs copy fused into pass 1, ragged last row) and encode_rows (Montgomery path) against
 the oracle, at the rates the reference uses (1/2 default, 1/4 timing test, 38/39 and 3/4: no zero half / partly zero).
-The general kernel (LCPC_NTT_GENERAL=1) must give the same bytes."""
+The general kernel (LCPC_NTT_GENERAL=1) must give the same bytes.  Three-pass plans (2^21 .. 2^24 columns) at the end."""
 import os
 
 import numpy as np
