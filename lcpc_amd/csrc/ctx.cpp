@@ -25,7 +25,7 @@ void ctx_ref(lcpc_ctx* c) { c->refs.fetch_add(1); }
 static void ctx_free(lcpc_ctx* c) {
   (void)hipSetDevice(c->prm.device);
   comm_release(c);
-  dev_free(c->d_pack[0]); dev_free(c->d_pack[1]); dev_free(c->d_pack[2]); dev_free(c->d_roots29s); dev_free(c->d_roots29cs);
+  dev_free(c->d_pack[0]); dev_free(c->d_pack[1]); dev_free(c->d_pack[2]); dev_free(c->d_roots29s); dev_free(c->d_roots29cs); dev_free(c->d_rootsls); dev_free(c->d_rootslcs);
   dev_free(c->d_rootsl); dev_free(c->d_rootslc); dev_free(c->d_qpl); dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
   dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->ws.d_mid); dev_free(c->d_scratch);
   if (c->h_varena) (void)hipHostFree(c->h_varena);
@@ -186,6 +186,33 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.t0 = i == 2 ? 10u : 0u; a.s = p.s; a.log_tj = p.log_tj;
       a.tile_group = i == 0 ? ntt_tile_group_of(c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(20, c->L, 0) : 0u);
       ECHK(launch_ntt_pass_l9s(a, i < 2, c->d_pack[i], c->pack_info[i], st));
+      nl++;
+    }
+    return 0;
+  }
+  if (c->prm.encoding == LCPC_ENC_LIGERO && c->lns3) {        // the three-pass plan of the l9s3 branch above, on K1n
+    const uint32_t s0 = c->log_n - 20;
+    for (int i = 0; i < 3; i++) {
+      const Pass& p = c->passes[i];
+      const bool first = i == 0, sub = i > 0;
+      NttPassArgs a{};
+      a.dst = j.dst;
+      a.src = first ? j.src : j.dst;
+      a.roots = c->d_roots; a.qp29 = c->d_qpl;
+      a.roots29 = sub ? c->d_rootsls : c->d_rootsl;
+      a.roots29c = j.canon_out ? (sub ? c->d_rootslcs : c->d_rootslc) : nullptr;
+      a.canon_row_mask = sub ? (1u << s0) - 1 : 0u;
+      a.mont_prefix = (j.canon_out && i == 2) ? 4u : 0u;
+      a.src_stride = first ? j.src_stride : ((uint64_t)1 << 20);
+      a.dst_stride = first ? c->n_cols : ((uint64_t)1 << 20);
+      a.n_valid = first ? j.n_valid : ((uint64_t)1 << 20);
+      a.n_src_total = first ? j.n_src_total : ~(uint64_t)0;
+      a.copy_dst = first ? j.copy_dst : nullptr;
+      a.n_rows = first ? n_rows : n_rows << s0;
+      a.log_n = first ? c->log_n : 20u;
+      a.t0 = i == 2 ? 10u : 0u; a.s = p.s; a.log_tj = p.log_tj;
+      a.tile_group = i == 0 ? ntt_tile_group_of(c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(20, c->L, 0) : 0u);
+      ECHK(launch_ntt_pass_lns(c->NL, a, i < 2, c->d_pack[i], c->pack_info[i], st));
       nl++;
     }
     return 0;
@@ -520,13 +547,20 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       HIPCHK(c, hipDeviceSynchronize());
       c->l9s3 = true;
     }
-    if (!c->d_qp29 && c->passes.size() >= 2 && !getenv("LCPC_NTT_GENERAL") && ntt_lns_supported(c->NL, c->log_n)) {
+    const bool lns3 = !c->d_qp29 && !getenv("LCPC_NTT_GENERAL") && !getenv("LCPC_NTT_NO_3PASS") && ntt_lns3_supported(c->NL, c->log_n);
+    if (!c->d_qp29 && c->passes.size() >= 2 && !getenv("LCPC_NTT_GENERAL") && (ntt_lns_supported(c->NL, c->log_n) || lns3)) {
       // Ft63 / Ft127 / Ft191 rows that need more than one pass: two passes on 1024-element tiles with the lazy-limb
       // kernel (ntt_lns.hip), its twiddle table in limb form (w^i R' mod p), the clamp table and the lane-order packs
       const unsigned k = c->log_n;
       c->passes.clear();
-      c->passes.push_back({0, k - 10, 20 - k, 10});
-      c->passes.push_back({k - 10, 10, 0u, 10});
+      if (lns3) {                                              // three passes: s0 stages over the whole rows, then 10 + 10 per 2^20-element block
+        c->passes.push_back({0, k - 20, 30 - k, 10});
+        c->passes.push_back({k - 20, 10, 0u, 10});
+        c->passes.push_back({k - 10, 10, 0u, 10});
+      } else {
+        c->passes.push_back({0, k - 10, 20 - k, 10});
+        c->passes.push_back({k - 10, 10, 0u, 10});
+      }
       const int N = ntt_lns_limbs(c->NL), W = ntt_lns_limb_bits(c->NL), stride = ntt_lns_stride(c->NL);
       uint64_t rp[MAXL] = {1, 0, 0, 0};                        // R' = 2^(N W) mod p, a plain integer
       for (int i = 0; i < N * W; i++) h_add(*f, rp, rp, rp);
@@ -563,18 +597,27 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       if (he == hipSuccess) he = hipDeviceSynchronize();
       dev_free(d_rp); dev_free(d_rpc);
       if (he != hipSuccess) return fail_hip(err, he, "ntt_lns tables");
-      for (int i = 0; i < 2; i++) {
+      if (lns3) {
+        const size_t n_sub = (size_t)1 << 19;
+        if ((rc = dev_alloc(err, &c->d_rootsls, n_sub * stride * 4)) || (rc = dev_alloc(err, &c->d_rootslcs, n_sub * stride * 4))) return rc;
+        HIPCHK(c, launch_ntt_lns_subtable(c->NL, c->d_rootsl, k - 20, n_sub, c->d_rootsls, nullptr));
+        HIPCHK(c, launch_ntt_lns_subtable(c->NL, c->d_rootslc, k - 20, n_sub, c->d_rootslcs, nullptr));
+      }
+      for (int i = 0; i < (lns3 ? 3 : 2); i++) {
         const Pass& ps = c->passes[i];
-        const bool first = i == 0;
+        const bool first = lns3 ? i < 2 : i == 0;              // three-pass plans: passes 0 and 1 run the first-pass kernel
+        const bool sub = lns3 && i > 0;
         NttPassArgs a{};
-        a.roots29 = c->d_rootsl; a.roots29c = c->d_rootslc; a.log_n = k; a.t0 = ps.t0; a.s = ps.s; a.log_tj = ps.log_tj;
+        a.roots29 = sub ? c->d_rootsls : c->d_rootsl; a.roots29c = sub ? c->d_rootslcs : c->d_rootslc;
+        a.log_n = sub ? 20u : k; a.t0 = sub ? (i == 2 ? 10u : 0u) : ps.t0; a.s = ps.s; a.log_tj = ps.log_tj;
         c->pack_info[i] = ntt_lns_pack_info(c->NL, ps.s, first);
-        const uint32_t n_classes = first ? 1u << (k - 10) : 1u;
+        const uint32_t n_classes = !first ? 1u : (sub ? 1024u : 1u << (k - 10));
         if ((rc = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return rc;
         HIPCHK(c, launch_ntt_lns_pack(c->NL, a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
       }
       HIPCHK(c, hipDeviceSynchronize());
-      c->lns = true;
+      c->lns = !lns3;
+      c->lns3 = lns3;
       c->comm_canon = !getenv("LCPC_COMM_MONT");               // commits keep comm canonical on the device, as for Ft255
     }
     return 0;

@@ -89,6 +89,9 @@ struct lcpc_ctx {
   uint32_t* d_roots29cs = nullptr;
   // Ft63 / Ft127 / Ft191 two-pass plans: the lazy-limb kernel of ntt_lns.hip (packs in d_pack / pack_info as well)
   bool lns = false;
+  bool lns3 = false;               // the same fields at 2^21 .. 2^26 columns: three passes (sub-sampled tables in d_rootsls / d_rootslcs)
+  uint32_t* d_rootsls = nullptr;
+  uint32_t* d_rootslcs = nullptr;
   uint32_t* d_rootsl = nullptr;    // w^i * R' mod p as N limbs of W bits (field_ln.h), ntt_lns_stride words per entry
   uint32_t* d_rootslc = nullptr;   // w^i * R' R^-1 mod p: the table that converts to canonical on the fly (canonical-output commits)
   uint32_t* d_qpl = nullptr;       // (i - 24) * p, i < 64, same form (ln::clamp_*)

@@ -56,6 +56,10 @@ hipError_t launch_ntt_pass_l9s(const NttPassArgs& a, bool first, const uint32_t*
 // nl = 2 / 4 / 6.  a.roots29 = the limb-form twiddle table (w^i R' mod p, ntt_lns_stride words per entry), a.qp29 = the
 // (i - 24) p table (64 rows, same stride)
 bool ntt_lns_supported(int nl, uint32_t log_n);
+// three passes for 2^21 .. 2^26 columns, built like ntt_l9s3_supported's plan (first-pass kernel over the whole rows, then the
+// 2^20-point two-pass plan per block from sub-sampled tables)
+bool ntt_lns3_supported(int nl, uint32_t log_n);
+hipError_t launch_ntt_lns_subtable(int nl, const uint32_t* tab, uint32_t shift, uint64_t n, uint32_t* sub, hipStream_t st);
 int ntt_lns_limbs(int nl);
 int ntt_lns_limb_bits(int nl);
 int ntt_lns_stride(int nl);

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
   }
   __syncthreads();
   const u32* cls_pack = pack + (size_t)(FIRST ? tile : 0u) * pi.class_words;
-  const bool canon = a.roots29c != nullptr;
+  const bool canon = a.roots29c != nullptr && ((u32)row & a.canon_row_mask) == 0;     // (wave-uniform; three-pass plans: kernels.h)
   const bool blk0_tile = FIRST || tile == 0;                 // tiles that hold elements of "block 0" (never multiplied so far)
   const bool zero_hi = FIRST && a.n_valid <= (1ull << (k - 1));
 
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
 #pragma unroll
         for (int i = 0; i < NL; i++) v.v[i] = w[i];
       }
-      if (tile == 0 && g < a.mont_prefix) v = fe_canon<NL>(v);          // canonical output: the never-multiplied prefix
+      if (canon && tile == 0 && g < a.mont_prefix) v = fe_canon<NL>(v); // canonical output: the never-multiplied prefix
     } else {
 #pragma unroll
       for (int i = 0; i < NL; i++) v.v[i] = w[i];
@@ -356,7 +356,7 @@ template <class FT> hipError_t launch_pass_f(const NttPassArgs& a, bool first, c
     if (a.s != 10 || a.log_tj != 0 || a.t0 + a.s != a.log_n) return hipErrorInvalidValue;
     return launch_t<FT, 10, 0, false>(a, pack, pi, st);
   }
-  if (a.t0 != 0 || a.s + a.log_tj != 10 || a.s + 10 != a.log_n) return hipErrorInvalidValue;
+  if (a.t0 != 0 || a.s + a.log_tj != 10 || (a.s + 10 != a.log_n && a.s + 20 != a.log_n)) return hipErrorInvalidValue;   // (+ 20: three-pass plans)
   switch (a.s) {
 #define X(SV) case SV: return launch_t<FT, SV, 10 - SV, true>(a, pack, pi, st);
     LNS_FIRST_CASES(X)
@@ -384,6 +384,17 @@ bool ntt_lns_supported(int nl, uint32_t log_n) {
   const char* ev = getenv("LCPC_NTT_LNS_MAXK");
   const uint32_t maxk = ev ? (uint32_t)atoi(ev) : 20;
   return (nl == 2 || nl == 4 || nl == 6) && log_n >= 11 && log_n <= maxk && log_n <= 20u;
+}
+bool ntt_lns3_supported(int nl, uint32_t log_n) { return (nl == 2 || nl == 4 || nl == 6) && log_n >= 21 && log_n <= 26; }
+__global__ void __launch_bounds__(256) lns_subtable_kernel(const u32* tab, u32 shift, u64 n, u32 words, u32* sub) {
+  for (u64 id = (u64)blockIdx.x * 256 + threadIdx.x; id < n * words; id += (u64)gridDim.x * 256) {
+    const u64 i = id / words, w = id % words;
+    sub[i * words + w] = tab[(i << shift) * words + w];
+  }
+}
+hipError_t launch_ntt_lns_subtable(int nl, const uint32_t* tab, uint32_t shift, uint64_t n, uint32_t* sub, hipStream_t st) {
+  hipLaunchKernelGGL(lns_subtable_kernel, dim3(2048), dim3(256), 0, st, tab, shift, n, (u32)ntt_lns_stride(nl), sub);
+  return hipGetLastError();
 }
 int ntt_lns_limbs(int nl) { return nl == 2 ? 3 : (nl == 4 ? 5 : (nl == 6 ? 7 : 0)); }
 int ntt_lns_limb_bits(int nl) { return nl == 2 ? 26 : 29; }

@@ -136,3 +136,34 @@ def coeffs_padded(coeffs, n_rows, n_per_row, L):
     out = np.zeros((n_rows * n_per_row, L), np.uint64)
     out[:len(coeffs)] = coeffs
     return out
+
+
+@pytest.mark.parametrize("fid,log_n,rate", [(0, 21, "1/2"), (0, 22, "38/39"), (0, 23, "1/2"), (1, 21, "1/2"), (1, 21, "38/39"), (1, 22, "1/4"), (2, 21, "1/2-"),
+                                            (2, 22, "1/2"), (2, 21, "3/4")])
+def test_commit_three_pass_shapes_small_fields(oracle, fid, log_n, rate):
+    """2^21 .. 2^26 columns on K1n: the three-pass plan of tests/test_gpu_ntt_shapes.py::test_commit_three_pass_shapes (first-pass
+    kernel over the whole rows, then the 2^20-point two-pass plan per block, canonical output in block 0 only) for Ft63 / Ft127 /
+    Ft191: commit (2 rows, the second ragged) and encode_rows against the oracle, and the general kernel's bytes."""
+    O = oracle
+    L = fid + 1
+    n_cols = 1 << log_n
+    n_per_row, rho = {"1/2": (n_cols // 2, (1, 2)), "1/4": (n_cols // 4, (1, 4)), "38/39": (n_cols * 38 // 39, (38, 39)),
+                      "3/4": (n_cols * 3 // 4, (3, 4)), "1/2-": (n_cols // 2 - 3, (1, 2))}[rate]
+    n = n_per_row + max(1, n_per_row // 3)
+    coeffs = O.random_elems(fid, n, log_n * 3 + len(rate) + fid)
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, rho=rho)
+    oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols, rho=rho)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=8)
+    assert c.get_root() == oc.get_root() and (c.hashes() == oc.hashes()).all()
+    assert (c.comm() == oc.comm()).all() and (c.coeffs() == oc.coeffs()).all()
+    rows = np.zeros((n_cols, L), np.uint64)
+    rows[:n - n_per_row] = coeffs[n_per_row:]
+    assert (enc.encode(rows) == oc.comm()[n_cols:]).all()
+    os.environ["LCPC_NTT_NO_3PASS"] = "1"
+    try:
+        enc_g = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, rho=rho)
+    finally:
+        del os.environ["LCPC_NTT_NO_3PASS"]
+    g = LcCommit.commit(coeffs, enc_g)
+    assert (g.comm() == c.comm()).all() and (g.hashes() == c.hashes()).all()
