@@ -526,96 +526,133 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       // 2^20-column context
       const unsigned k = c->log_n, s0 = k - 20;
       const size_t n_sub = (size_t)1 << 19;
-      if ((rc = dev_alloc(err, &c->d_roots29s, n_sub * 48)) || (rc = dev_alloc(err, &c->d_roots29cs, n_sub * 48))) return rc;
-      HIPCHK(c, launch_ntt_l9s_subtable(c->d_roots29, s0, n_sub, c->d_roots29s, nullptr));
-      HIPCHK(c, launch_ntt_l9s_subtable(c->d_roots29c, s0, n_sub, c->d_roots29cs, nullptr));
-      c->passes.clear();
-      c->passes.push_back({0, s0, 10 - s0, 10});
-      c->passes.push_back({s0, 10, 0u, 10});
-      c->passes.push_back({s0 + 10, 10, 0u, 10});
-      for (int i = 0; i < 3; i++) {
-        const Pass& ps = c->passes[i];
-        const bool first = i < 2;                              // passes 0 and 1 run the first-pass kernel
-        NttPassArgs a{};
-        a.roots29 = i == 0 ? c->d_roots29 : c->d_roots29s; a.roots29c = i == 0 ? c->d_roots29c : c->d_roots29cs;
-        a.log_n = i == 0 ? k : 20u; a.t0 = i == 2 ? 10u : 0u; a.s = ps.s; a.log_tj = ps.log_tj;
-        c->pack_info[i] = ntt_l9s_pack_info(ps.s, first);
-        const uint32_t n_classes = i == 0 ? 1u << (k - 10) : (i == 1 ? 1024u : 1u);
-        if ((rc = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return rc;
-        HIPCHK(c, launch_ntt_l9s_pack(a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
+      // the first pack is ~2.3 x one row (4.9 GB at 2^26 columns): if the device cannot hold the plan's tables, the general kernel's
+      // three passes (tables already built above) take the rows instead -- slower, not an error
+      const std::vector<Pass> general_plan = c->passes;
+      auto build = [&]() -> int {
+        int r;
+        if ((r = dev_alloc(err, &c->d_roots29s, n_sub * 48)) || (r = dev_alloc(err, &c->d_roots29cs, n_sub * 48))) return r;
+        HIPCHK(c, launch_ntt_l9s_subtable(c->d_roots29, s0, n_sub, c->d_roots29s, nullptr));
+        HIPCHK(c, launch_ntt_l9s_subtable(c->d_roots29c, s0, n_sub, c->d_roots29cs, nullptr));
+        c->passes.clear();
+        c->passes.push_back({0, s0, 10 - s0, 10});
+        c->passes.push_back({s0, 10, 0u, 10});
+        c->passes.push_back({s0 + 10, 10, 0u, 10});
+        for (int i = 0; i < 3; i++) {
+          const Pass& ps = c->passes[i];
+          const bool first = i < 2;                            // passes 0 and 1 run the first-pass kernel
+          NttPassArgs a{};
+          a.roots29 = i == 0 ? c->d_roots29 : c->d_roots29s; a.roots29c = i == 0 ? c->d_roots29c : c->d_roots29cs;
+          a.log_n = i == 0 ? k : 20u; a.t0 = i == 2 ? 10u : 0u; a.s = ps.s; a.log_tj = ps.log_tj;
+          c->pack_info[i] = ntt_l9s_pack_info(ps.s, first);
+          const uint32_t n_classes = i == 0 ? 1u << (k - 10) : (i == 1 ? 1024u : 1u);
+          if (i == 0 && getenv("LCPC_DEBUG_FAIL_3PASS")) return LCPC_ERR_NOMEM;       // (test hook: the fallback below)
+          if ((r = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return r;
+          HIPCHK(c, launch_ntt_l9s_pack(a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
+        }
+        HIPCHK(c, hipDeviceSynchronize());
+        return 0;
+      };
+      const int brc = build();
+      if (brc == 0) {
+        c->l9s3 = true;
+      } else if (brc == LCPC_ERR_NOMEM) {
+        for (auto& pk : c->d_pack) { dev_free(pk); pk = nullptr; }
+        dev_free(c->d_roots29s); dev_free(c->d_roots29cs);
+        c->d_roots29s = c->d_roots29cs = nullptr;
+        c->passes = general_plan;
+        (void)hipGetLastError();                               // the failed hipMalloc must not surface at the next launch check
+        err->clear();
+      } else {
+        return brc;
       }
-      HIPCHK(c, hipDeviceSynchronize());
-      c->l9s3 = true;
     }
     const bool lns3 = !c->d_qp29 && !getenv("LCPC_NTT_GENERAL") && !getenv("LCPC_NTT_NO_3PASS") && ntt_lns3_supported(c->NL, c->log_n);
     if (!c->d_qp29 && c->passes.size() >= 2 && !getenv("LCPC_NTT_GENERAL") && (ntt_lns_supported(c->NL, c->log_n) || lns3)) {
       // Ft63 / Ft127 / Ft191 rows that need more than one pass: two passes on 1024-element tiles with the lazy-limb
       // kernel (ntt_lns.hip), its twiddle table in limb form (w^i R' mod p), the clamp table and the lane-order packs
-      const unsigned k = c->log_n;
-      c->passes.clear();
-      if (lns3) {                                              // three passes: s0 stages over the whole rows, then 10 + 10 per 2^20-element block
-        c->passes.push_back({0, k - 20, 30 - k, 10});
-        c->passes.push_back({k - 20, 10, 0u, 10});
-        c->passes.push_back({k - 10, 10, 0u, 10});
-      } else {
-        c->passes.push_back({0, k - 10, 20 - k, 10});
-        c->passes.push_back({k - 10, 10, 0u, 10});
-      }
-      const int N = ntt_lns_limbs(c->NL), W = ntt_lns_limb_bits(c->NL), stride = ntt_lns_stride(c->NL);
-      uint64_t rp[MAXL] = {1, 0, 0, 0};                        // R' = 2^(N W) mod p, a plain integer
-      for (int i = 0; i < N * W; i++) h_add(*f, rp, rp, rp);
-      std::vector<uint32_t> tab((size_t)64 * stride, 0);
-      for (int i = 0; i < 64; i++) {                           // (i - 24) * p as normalised signed limbs (two's complement top limb)
-        const int q = i - 24;
-        uint64_t mag[5] = {0, 0, 0, 0, 0};
-        unsigned __int128 cy = 0;
-        for (int w = 0; w < 5; w++) { cy += (unsigned __int128)(w < f->L ? f->p[w] : 0) * (uint64_t)(q < 0 ? -q : q); mag[w] = (uint64_t)cy; cy >>= 64; }
-        if (q < 0) {                                           // two's complement over 320 bits
-          unsigned __int128 c2 = 1;
-          for (int w = 0; w < 5; w++) { c2 += (unsigned __int128)(~mag[w]); mag[w] = (uint64_t)c2; c2 >>= 64; }
+      const std::vector<Pass> general_plan = c->passes;      // (if the tables do not fit the device: the general kernel, as for l9s3)
+      auto build = [&]() -> int {
+        int rc_ = 0;
+        const unsigned k = c->log_n;
+        c->passes.clear();
+        if (lns3) {                                              // three passes: s0 stages over the whole rows, then 10 + 10 per 2^20-element block
+          c->passes.push_back({0, k - 20, 30 - k, 10});
+          c->passes.push_back({k - 20, 10, 0u, 10});
+          c->passes.push_back({k - 10, 10, 0u, 10});
+        } else {
+          c->passes.push_back({0, k - 10, 20 - k, 10});
+          c->passes.push_back({k - 10, 10, 0u, 10});
         }
-        for (int l = 0; l < N; l++) {
-          const int b = W * l, w = b / 64, sh = b % 64;
-          uint64_t x = mag[w] >> sh;
-          if (sh) x |= mag[w + 1] << (64 - sh);
-          tab[(size_t)i * stride + l] = l + 1 < N ? (uint32_t)(x & (((uint64_t)1 << W) - 1)) : (uint32_t)x;   // top limb: sign-extended
+        const int N = ntt_lns_limbs(c->NL), W = ntt_lns_limb_bits(c->NL), stride = ntt_lns_stride(c->NL);
+        uint64_t rp[MAXL] = {1, 0, 0, 0};                        // R' = 2^(N W) mod p, a plain integer
+        for (int i = 0; i < N * W; i++) h_add(*f, rp, rp, rp);
+        std::vector<uint32_t> tab((size_t)64 * stride, 0);
+        for (int i = 0; i < 64; i++) {                           // (i - 24) * p as normalised signed limbs (two's complement top limb)
+          const int q = i - 24;
+          uint64_t mag[5] = {0, 0, 0, 0, 0};
+          unsigned __int128 cy = 0;
+          for (int w = 0; w < 5; w++) { cy += (unsigned __int128)(w < f->L ? f->p[w] : 0) * (uint64_t)(q < 0 ? -q : q); mag[w] = (uint64_t)cy; cy >>= 64; }
+          if (q < 0) {                                           // two's complement over 320 bits
+            unsigned __int128 c2 = 1;
+            for (int w = 0; w < 5; w++) { c2 += (unsigned __int128)(~mag[w]); mag[w] = (uint64_t)c2; c2 >>= 64; }
+          }
+          for (int l = 0; l < N; l++) {
+            const int b = W * l, w = b / 64, sh = b % 64;
+            uint64_t x = mag[w] >> sh;
+            if (sh) x |= mag[w + 1] << (64 - sh);
+            tab[(size_t)i * stride + l] = l + 1 < N ? (uint32_t)(x & (((uint64_t)1 << W) - 1)) : (uint32_t)x;   // top limb: sign-extended
+          }
         }
+        const size_t n_roots = (size_t)1 << (k - 1);
+        uint64_t rpc[MAXL];
+        h_canon(*f, rpc, rp);                                    // R' R^-1 mod p: the converting table is w^i R' R^-1 = mont_mul(w^i R, R' R^-1)
+        uint32_t *d_rp = nullptr, *d_rpc = nullptr;
+        if ((rc_ = dev_alloc(err, &d_rp, 8 * f->L))) return rc_;
+        if ((rc_ = dev_alloc(err, &d_rpc, 8 * f->L))) { dev_free(d_rp); return rc_; }
+        if ((rc_ = dev_alloc(err, &c->d_rootsl, n_roots * stride * 4)) || (rc_ = dev_alloc(err, &c->d_rootslc, n_roots * stride * 4)) ||
+            (rc_ = dev_alloc(err, &c->d_qpl, tab.size() * 4))) { dev_free(d_rp); dev_free(d_rpc); return rc_; }
+        hipError_t he = hipMemcpy(d_rp, rp, 8 * f->L, hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipMemcpy(d_rpc, rpc, 8 * f->L, hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipMemcpy(c->d_qpl, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = launch_ntt_lns_roots(c->NL, c->d_roots, n_roots, d_rp, c->d_rootsl, nullptr);
+        if (he == hipSuccess) he = launch_ntt_lns_roots(c->NL, c->d_roots, n_roots, d_rpc, c->d_rootslc, nullptr);
+        if (he == hipSuccess) he = hipDeviceSynchronize();
+        dev_free(d_rp); dev_free(d_rpc);
+        if (he != hipSuccess) return fail_hip(err, he, "ntt_lns tables");
+        if (lns3) {
+          const size_t n_sub = (size_t)1 << 19;
+          if ((rc_ = dev_alloc(err, &c->d_rootsls, n_sub * stride * 4)) || (rc_ = dev_alloc(err, &c->d_rootslcs, n_sub * stride * 4))) return rc_;
+          HIPCHK(c, launch_ntt_lns_subtable(c->NL, c->d_rootsl, k - 20, n_sub, c->d_rootsls, nullptr));
+          HIPCHK(c, launch_ntt_lns_subtable(c->NL, c->d_rootslc, k - 20, n_sub, c->d_rootslcs, nullptr));
+        }
+        for (int i = 0; i < (lns3 ? 3 : 2); i++) {
+          const Pass& ps = c->passes[i];
+          const bool first = lns3 ? i < 2 : i == 0;              // three-pass plans: passes 0 and 1 run the first-pass kernel
+          const bool sub = lns3 && i > 0;
+          NttPassArgs a{};
+          a.roots29 = sub ? c->d_rootsls : c->d_rootsl; a.roots29c = sub ? c->d_rootslcs : c->d_rootslc;
+          a.log_n = sub ? 20u : k; a.t0 = sub ? (i == 2 ? 10u : 0u) : ps.t0; a.s = ps.s; a.log_tj = ps.log_tj;
+          c->pack_info[i] = ntt_lns_pack_info(c->NL, ps.s, first);
+          const uint32_t n_classes = !first ? 1u : (sub ? 1024u : 1u << (k - 10));
+          if (lns3 && i == 0 && getenv("LCPC_DEBUG_FAIL_3PASS")) return LCPC_ERR_NOMEM;   // (test hook: the fallback below)
+          if ((rc_ = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return rc_;
+          HIPCHK(c, launch_ntt_lns_pack(c->NL, a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
+        }
+        HIPCHK(c, hipDeviceSynchronize());
+        return 0;
+      };
+      const int brc = build();
+      if (brc == LCPC_ERR_NOMEM) {
+        for (auto& pk : c->d_pack) { dev_free(pk); pk = nullptr; }
+        dev_free(c->d_rootsl); dev_free(c->d_rootslc); dev_free(c->d_qpl); dev_free(c->d_rootsls); dev_free(c->d_rootslcs);
+        c->d_rootsl = c->d_rootslc = c->d_qpl = c->d_rootsls = c->d_rootslcs = nullptr;
+        c->passes = general_plan;
+        (void)hipGetLastError();
+        err->clear();
+        return 0;
       }
-      const size_t n_roots = (size_t)1 << (k - 1);
-      uint64_t rpc[MAXL];
-      h_canon(*f, rpc, rp);                                    // R' R^-1 mod p: the converting table is w^i R' R^-1 = mont_mul(w^i R, R' R^-1)
-      uint32_t *d_rp = nullptr, *d_rpc = nullptr;
-      if ((rc = dev_alloc(err, &d_rp, 8 * f->L))) return rc;
-      if ((rc = dev_alloc(err, &d_rpc, 8 * f->L))) { dev_free(d_rp); return rc; }
-      if ((rc = dev_alloc(err, &c->d_rootsl, n_roots * stride * 4)) || (rc = dev_alloc(err, &c->d_rootslc, n_roots * stride * 4)) ||
-          (rc = dev_alloc(err, &c->d_qpl, tab.size() * 4))) { dev_free(d_rp); dev_free(d_rpc); return rc; }
-      hipError_t he = hipMemcpy(d_rp, rp, 8 * f->L, hipMemcpyHostToDevice);
-      if (he == hipSuccess) he = hipMemcpy(d_rpc, rpc, 8 * f->L, hipMemcpyHostToDevice);
-      if (he == hipSuccess) he = hipMemcpy(c->d_qpl, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
-      if (he == hipSuccess) he = launch_ntt_lns_roots(c->NL, c->d_roots, n_roots, d_rp, c->d_rootsl, nullptr);
-      if (he == hipSuccess) he = launch_ntt_lns_roots(c->NL, c->d_roots, n_roots, d_rpc, c->d_rootslc, nullptr);
-      if (he == hipSuccess) he = hipDeviceSynchronize();
-      dev_free(d_rp); dev_free(d_rpc);
-      if (he != hipSuccess) return fail_hip(err, he, "ntt_lns tables");
-      if (lns3) {
-        const size_t n_sub = (size_t)1 << 19;
-        if ((rc = dev_alloc(err, &c->d_rootsls, n_sub * stride * 4)) || (rc = dev_alloc(err, &c->d_rootslcs, n_sub * stride * 4))) return rc;
-        HIPCHK(c, launch_ntt_lns_subtable(c->NL, c->d_rootsl, k - 20, n_sub, c->d_rootsls, nullptr));
-        HIPCHK(c, launch_ntt_lns_subtable(c->NL, c->d_rootslc, k - 20, n_sub, c->d_rootslcs, nullptr));
-      }
-      for (int i = 0; i < (lns3 ? 3 : 2); i++) {
-        const Pass& ps = c->passes[i];
-        const bool first = lns3 ? i < 2 : i == 0;              // three-pass plans: passes 0 and 1 run the first-pass kernel
-        const bool sub = lns3 && i > 0;
-        NttPassArgs a{};
-        a.roots29 = sub ? c->d_rootsls : c->d_rootsl; a.roots29c = sub ? c->d_rootslcs : c->d_rootslc;
-        a.log_n = sub ? 20u : k; a.t0 = sub ? (i == 2 ? 10u : 0u) : ps.t0; a.s = ps.s; a.log_tj = ps.log_tj;
-        c->pack_info[i] = ntt_lns_pack_info(c->NL, ps.s, first);
-        const uint32_t n_classes = !first ? 1u : (sub ? 1024u : 1u << (k - 10));
-        if ((rc = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return rc;
-        HIPCHK(c, launch_ntt_lns_pack(c->NL, a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
-      }
-      HIPCHK(c, hipDeviceSynchronize());
+      if (brc) return brc;
       c->lns = !lns3;
       c->lns3 = lns3;
       c->comm_canon = !getenv("LCPC_COMM_MONT");               // commits keep comm canonical on the device, as for Ft255

@@ -112,3 +112,23 @@ def test_commit_three_pass_shapes(oracle, log_n, rate):
             del os.environ["LCPC_NTT_NO_3PASS"]
         g = LcCommit.commit(coeffs, enc_g)
         assert (g.comm() == c.comm()).all() and (g.hashes() == c.hashes()).all()
+
+
+@pytest.mark.parametrize("fid", [3, 1])
+def test_three_pass_tables_do_not_fit(oracle, fid):
+    """the three-pass plan's first pack is ~2.3 x one row; when the device cannot hold it the context falls back to the general
+    kernel's plan instead of failing (LCPC_DEBUG_FAIL_3PASS simulates the failed allocation after the sub-sampled tables were
+    made, so the clean-up runs): same commitment, and the context made afterwards without the hook is unaffected."""
+    O = oracle
+    log_n = 21
+    n_cols, n_per_row = 1 << log_n, 1 << (log_n - 1)
+    coeffs = O.random_elems(fid, n_per_row + 1000, 9 + fid)
+    os.environ["LCPC_DEBUG_FAIL_3PASS"] = "1"
+    try:
+        enc_f = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    finally:
+        del os.environ["LCPC_DEBUG_FAIL_3PASS"]
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    a, b = LcCommit.commit(coeffs, enc_f), LcCommit.commit(coeffs, enc)
+    assert a.get_root() == b.get_root() and (a.comm() == b.comm()).all()
+    assert a.get_root() == O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=8).get_root()
