@@ -28,13 +28,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-KERNEL_SOURCES = ("kernels.hip", "ntt_l9s.hip", "ntt_l9_dev.h", "field_dev.h", "field_r29_gen.h", "blake3_dev.h", "kernels.h")
+
+
+def kernel_sources():
+    """everything that decides WHAT a commit launches and HOW: every device source and header of the library, plus the host
+    units that plan the passes, order the tiles and sequence the launches (ctx.cpp, commit.cpp, shard.cpp)"""
+    d = os.path.join(ROOT, "lcpc_amd", "csrc")
+    return sorted(n for n in os.listdir(d) if n.endswith((".hip", ".h")) or n in ("ctx.cpp", "commit.cpp", "shard.cpp"))
 
 
 def kernel_stamp():
-    """sha256 over the device sources: a committed PMC file is only quoted while it describes these kernels."""
+    """sha256 over kernel_sources(): a committed PMC file is only quoted while it describes this build."""
     h = hashlib.sha256()
-    for n in KERNEL_SOURCES:
+    for n in kernel_sources():
+        h.update(n.encode())
         with open(os.path.join(ROOT, "lcpc_amd", "csrc", n), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -462,10 +469,14 @@ def main():
                     "finish": round(float(ph[2]) * 1e3, 3), "gathered_MB": round(gathered.numel() / 1e6, 1)}
     elif distributed:
         # native exchange: the library's own event brackets (encode | hash | exchange + finish), MAX over ranks
-        ph = torch.tensor([tm.encode_ms, tm.hash_ms, tm.merkle_ms], dtype=torch.float64, device=dev)
+        # exchange_exposed_ms: how long the commit's stream waited, after its last hash launch, for the last column slice to
+        # come back from the exchange stream -- the part of the wire time that the slice pipeline does NOT hide
+        ph = torch.tensor([tm.encode_ms, tm.hash_ms, tm.merkle_ms, tm.exchange_exposed_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(ph, op=dist.ReduceOp.MAX)
         shard_ms = {"local_encode": round(float(ph[0]), 3), "local_hash": round(float(ph[1]), 3),
-                    "exchange_plus_finish": round(float(ph[2]), 3)}
+                    "exchange_tail_plus_merkle": round(float(ph[2]), 3), "exchange_exposed_ms": round(float(ph[3]), 3),
+                    "column_slices": int(os.environ.get("LCPC_SHARD_SLICES", "4")),
+                    "note": "per slice of columns the all-gather runs on a second stream while the next slice is hashed; MAX over ranks"}
 
     out = {"metric": "field-elements committed/sec (whole node), Ligero 2^%d coeffs" % args.log_len,
            "value": value, "unit": "field-elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define LCPC_ABI_VERSION 2
+/* 3: the column-range phases of the sharded commit (lcpc_commit_shard_encode_device, lcpc_commit_shard_hash_device,
+ * lcpc_commit_finish_cols_device, lcpc_commit_finish_merkle_device), lcpc_timings.exchange_exposed_ms; the LcCommit bincode
+ * entry points of round 3 are part of 3 as well.  A caller checks lcpc_abi_version() == LCPC_ABI_VERSION before anything else. */
+#define LCPC_ABI_VERSION 3
 
 /* fields of lcpc-test-fields/src/lib.rs:13-59 */
 enum { LCPC_FT63 = 0, LCPC_FT127 = 1, LCPC_FT191 = 2, LCPC_FT255 = 3 };
@@ -224,15 +227,37 @@ int  lcpc_shard_nodes(uint64_t n_chunks_total, uint32_t shard_count, uint32_t sh
 int  lcpc_comm_unique_id(uint8_t id[128]);
 int  lcpc_comm_init(lcpc_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_t world);
 int  lcpc_comm_destroy(lcpc_ctx *ctx);
-/* whole sharded commit on `stream`: encode + hash the local rows (coeffs_local_dev = this rank's rows, row-major),
- * ncclAllGather of the node chaining values, leaf digests + Merkle tree (replicated).  No host synchronisation unless
- * `root` is non-NULL.  flags as lcpc_commit_device. */
+/* whole sharded commit: encode the local rows (coeffs_local_dev = this rank's rows, row-major) on `stream`, then per SLICE
+ * of columns (4 by default; LCPC_SHARD_SLICES=<1..16> when the encoder is created) the local column hash on `stream` and --
+ * on a second stream owned by the commitment, behind an event -- ncclAllGather (+ grouped ncclBroadcasts) of that slice's
+ * node chaining values and its leaf digests, so that the wire time of slice s hides behind the hashing of slice s + 1 and
+ * only the last slice's exchange is exposed; `stream` then waits for the last slice and builds the Merkle tree (replicated).
+ * No host synchronisation unless `root` is non-NULL.  flags as lcpc_commit_device.
+ * Collectives on one communicator must be issued in the same order on every rank: drive the sharded commits / proves of
+ * one encoder from ONE host thread per rank, in the same program order everywhere (the library only keeps two commitments
+ * of one process from interleaving their slices). */
 int  lcpc_commit_sharded_device(lcpc_commit_t *cm, const uint64_t *coeffs_local_dev, uint64_t n_rows_total, void *stream,
                                 uint32_t flags, uint8_t *root);
 /* LcCommit::prove on a sharded commitment with the three all-gathers on RCCL (see lcpc_prove_sharded). */
 int  lcpc_prove_sharded_rccl(lcpc_commit_t *cm, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
                              uint8_t **proof, uint64_t *proof_len, uint64_t *cols_opened);
-/* (b) phase 1: encode the local rows (coeffs_dev = local rows only, row-major, padded) and reduce them to one
+/* (b) split phases.  The two calls lcpc_commit_shard_device / lcpc_commit_finish_device below are the unsliced form; a
+ * caller that wants to overlap ITS collective with the hashing drives the four steps itself, slicing the middle two by
+ * column ranges [col_begin, col_end) that together cover [0, n_cols) (any order, any streams the caller orders correctly;
+ * all four refer to the commit started by the encode step):
+ *   lcpc_commit_shard_encode_device    encode the local rows (lib.rs:648-653)
+ *   lcpc_commit_shard_hash_device      columns [col_begin, col_end) of the local rows -> nodes_dev[k][col_end - col_begin][32 B],
+ *                                      k < n_nodes of this rank (this rank's part of hash_columns, lib.rs:706-745)
+ *   lcpc_commit_finish_cols_device     gathered_dev[slot][col_end - col_begin][32 B] (slots as for lcpc_commit_finish_device;
+ *                                      clobbered) -> the leaf digests of those columns
+ *   lcpc_commit_finish_merkle_device   the tree above the leaf digests (lib.rs:747-785), root; the commitment is complete */
+int  lcpc_commit_shard_encode_device(lcpc_commit_t *cm, const uint64_t *coeffs_local_dev, uint64_t n_rows_total, void *stream,
+                                     uint32_t flags);
+int  lcpc_commit_shard_hash_device(lcpc_commit_t *cm, uint64_t col_begin, uint64_t col_end, void *stream, uint8_t *nodes_dev);
+int  lcpc_commit_finish_cols_device(lcpc_commit_t *cm, uint8_t *gathered_dev, uint32_t slots_per_rank, uint64_t col_begin,
+                                    uint64_t col_end, void *stream);
+int  lcpc_commit_finish_merkle_device(lcpc_commit_t *cm, void *stream, uint8_t *root);
+/* phase 1, unsliced: encode the local rows (coeffs_dev = local rows only, row-major, padded) and reduce them to one
  * BLAKE3 chaining value per (local node, column): nodes_dev[k * n_cols + col][32 B], k < n_nodes. */
 int  lcpc_commit_shard_device(lcpc_commit_t *cm, const uint64_t *coeffs_local_dev, uint64_t n_rows_total,
                               void *stream, uint32_t flags, uint8_t *nodes_dev);
@@ -269,6 +294,10 @@ int  lcpc_prove_sharded(lcpc_commit_t *cm, const uint64_t *outer_tensor, uint64_
 typedef struct {
   float encode_ms, hash_ms, merkle_ms, total_ms;
   uint32_t encode_launches, hash_launches, merkle_launches;
+  /* lcpc_commit_sharded_device only: how long the commit's stream stood still between the end of its last hash launch and
+   * the arrival of the last slice's leaf digests from the exchange stream (the part of the exchange that is NOT hidden;
+   * contained in merkle_ms).  0 elsewhere. */
+  float exchange_exposed_ms;
 } lcpc_timings;
 int  lcpc_set_timing(lcpc_commit_t *cm, int enable);
 int  lcpc_get_timings(lcpc_commit_t *cm, lcpc_timings *out);

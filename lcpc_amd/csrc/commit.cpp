@@ -329,6 +329,8 @@ void lcpc_commit_destroy(lcpc_commit_t* m) {
   if (m->h_pin) (void)hipHostFree(m->h_pin);
   if (m->h_root) (void)hipHostFree(m->h_root);
   if (m->s_prove) (void)hipStreamDestroy(m->s_prove);
+  if (m->s_xchg) (void)hipStreamDestroy(m->s_xchg);
+  for (auto& e : m->ev_slice) if (e) (void)hipEventDestroy(e);
   if (m->ev_done) (void)hipEventDestroy(m->ev_done);
   if (m->s_copy) (void)hipStreamDestroy(m->s_copy);
   if (m->s_comp) (void)hipStreamDestroy(m->s_comp);

@@ -44,10 +44,10 @@ void ctx_unref(lcpc_ctx* c) {
 // (64 + 64 + 16 bytes per run at 2^18 columns) and it LOSES 1-2 %.  Hence: on by default only for n_cols <= 2^15;
 // LCPC_NTT_MID_MAX_MB=<MiB> forces it for every shape within that budget (A/B, tests), =0 turns it off.
 uint64_t ntt_mid_rows(const lcpc_ctx* c, uint64_t n_rows) {
-  const char* ev = getenv("LCPC_NTT_MID_MAX_MB");               // read per call: the tests switch it between commits
+  const bool ev = c->sw_ntt_mid_max_mb >= 0;                    // (read when the context was created)
   if (!c->l9s || n_rows == 0) return 0;
   if (!ev && c->log_n > 15) return 0;
-  const uint64_t max_mb = ev ? strtoull(ev, nullptr, 10) : 6144;
+  const uint64_t max_mb = ev ? (uint64_t)c->sw_ntt_mid_max_mb : 6144;
   if (max_mb == 0) return 0;
   const uint64_t per_row = c->n_cols * 36;
   uint64_t fit = (max_mb << 20) / per_row;
@@ -98,17 +98,17 @@ static void plan_passes(lcpc_ctx* c) {
 // workgroups of one XCD.  Its strided runs are run_bytes = F << log_tj long; grouping makes the span that one XCD works on at a
 // time 1 KiB (2 KiB for runs of <= 32 bytes), which is what measured best (build-time A/B in one process, DESIGN.md K1s: n_cols
 // 2^20 -27 % on boxes where the ungrouped order is slow, -4 % elsewhere; 2^19 -3 %; the headline's 128-byte runs -0.5 to -1 %).
-// LCPC_NTT_TILE_GROUP=<log2> overrides (0 = the plain XCD-aware order); read per call so that tests can switch it
-static uint32_t ntt_tile_group_of(uint32_t log_n, int L, uint32_t log_tj) {
+// LCPC_NTT_TILE_GROUP=<log2> at context creation overrides (0 = the plain XCD-aware order)
+static uint32_t ntt_tile_group_of(const lcpc_ctx* c, uint32_t log_n, int L, uint32_t log_tj) {
   const uint32_t tiles_log = log_n - 10;
   if (tiles_log < 3) return 0;
   uint32_t run_log = log_tj;                                              // log2(run bytes)
   for (uint32_t b = 8u * (uint32_t)L; b > 1; b >>= 1) run_log++;
   uint32_t lg = run_log <= 5 ? 11 - run_log : (run_log < 10 ? 10 - run_log : 0);
-  if (const char* ev = getenv("LCPC_NTT_TILE_GROUP")) lg = (uint32_t)strtoul(ev, nullptr, 10);
+  if (c->sw_ntt_tile_group >= 0) lg = (uint32_t)c->sw_ntt_tile_group;
   return std::min(std::min(lg, 6u), tiles_log - 3);
 }
-static uint32_t ntt_tile_group(const lcpc_ctx* c, const Pass& first) { return ntt_tile_group_of(c->log_n, c->L, first.log_tj); }
+static uint32_t ntt_tile_group(const lcpc_ctx* c, const Pass& first) { return ntt_tile_group_of(c, c->log_n, c->L, first.log_tj); }
 
 #define ECHK(call)                                                        \
   do {                                                                    \
@@ -184,7 +184,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.n_rows = first ? n_rows : n_rows << s0;
       a.log_n = first ? c->log_n : 20u;
       a.t0 = i == 2 ? 10u : 0u; a.s = p.s; a.log_tj = p.log_tj;
-      a.tile_group = i == 0 ? ntt_tile_group_of(c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(20, c->L, 0) : 0u);
+      a.tile_group = i == 0 ? ntt_tile_group_of(c, c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(c, 20, c->L, 0) : 0u);
       ECHK(launch_ntt_pass_l9s(a, i < 2, c->d_pack[i], c->pack_info[i], st));
       nl++;
     }
@@ -211,7 +211,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.n_rows = first ? n_rows : n_rows << s0;
       a.log_n = first ? c->log_n : 20u;
       a.t0 = i == 2 ? 10u : 0u; a.s = p.s; a.log_tj = p.log_tj;
-      a.tile_group = i == 0 ? ntt_tile_group_of(c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(20, c->L, 0) : 0u);
+      a.tile_group = i == 0 ? ntt_tile_group_of(c, c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(c, 20, c->L, 0) : 0u);
       ECHK(launch_ntt_pass_lns(c->NL, a, i < 2, c->d_pack[i], c->pack_info[i], st));
       nl++;
     }
@@ -280,7 +280,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
     nl++;
     uint64_t in_start = 0;
     SpmmTArgs a{};
-    a.t = ws->d_t; a.n_rows = n_rows;
+    a.t = ws->d_t; a.n_rows = n_rows; a.tail_on = c->sw_sdig_tail;
     auto set_mat = [&](const DevCsr& m) { a.rowptr = m.rowptr; a.colidx = m.colidx; a.vals = m.vals; a.vals29 = m.vals29; a.m = m.n_out; };
     for (size_t i = 0; i + 1 < t; i++) {
       const uint64_t in_end = in_start + c->d_pre[i].n_in;
@@ -731,6 +731,10 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
   c->prm = *p;
   c->f = f; c->L = f->L; c->NL = 2 * f->L;
   if (c->prm.sdig_code == 0) c->prm.sdig_code = 3;
+  if (const char* ev = getenv("LCPC_NTT_MID_MAX_MB")) c->sw_ntt_mid_max_mb = (int64_t)strtoull(ev, nullptr, 10);
+  if (const char* ev = getenv("LCPC_NTT_TILE_GROUP")) c->sw_ntt_tile_group = (int32_t)strtoul(ev, nullptr, 10);
+  c->sw_sdig_tail = !getenv("LCPC_SDIG_NO_TAIL");
+  if (const char* ev = getenv("LCPC_SHARD_SLICES")) c->shard_slices = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)strtoul(ev, nullptr, 10), LCPC_MAX_SHARD_SLICES));
   int rc = 0;
   // row sharding needs rows that do not straddle BLAKE3 chunks (F | 1024)
   if (c->prm.shard_count > 1 && (c->prm.shard_rank >= c->prm.shard_count || 1024 % (8 * f->L) != 0)) rc = LCPC_ERR_ARG;

@@ -64,8 +64,17 @@ struct lcpc_transcript {
   lcpc_transcript(const uint8_t* l, size_t n) : t(l, n) {}
 };
 
+constexpr uint32_t LCPC_MAX_SHARD_SLICES = 16;
+
 struct lcpc_ctx {
   lcpc_params prm{};
+  // A/B switches, read from the environment ONCE, when the context is created (never on a launch path: getenv next to a
+  // setenv of another thread is undefined behaviour, and a context must not change plans under a running commit)
+  int64_t sw_ntt_mid_max_mb = -1;  // LCPC_NTT_MID_MAX_MB: -1 = the default rule of ntt_mid_rows
+  int32_t sw_ntt_tile_group = -1;  // LCPC_NTT_TILE_GROUP: -1 = the default rule of ntt_tile_group_of
+  bool sw_sdig_tail = true;        // LCPC_SDIG_NO_TAIL unset
+  uint32_t shard_slices = 4;       // native sharded commit: column slices whose exchange overlaps the next slice's hashing
+                                   // (LCPC_SHARD_SLICES at context creation; 1 = everything in sequence on one stream)
   const lcpc::FieldDesc* f = nullptr;
   int L = 0, NL = 0;
   uint64_t n_per_row = 0, n_cols = 0, np2 = 0;
@@ -150,9 +159,14 @@ struct lcpc_commit_s {
   uint64_t h_pin_cap = 0;
   // timing
   bool timing = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // start | encoded | hashed | done; [4] (ev_xw): the commit's stream has
+                                   // the leaf digests (sharded commit: behind the exchange)
   hipStream_t s_prove = nullptr;   // sharded prove: its device steps and the native exchange, ordered behind the commit by ev_done
   hipEvent_t ev_done = nullptr;    // recorded on the commit's stream when a sharded commit has been enqueued completely
+  // native sharded commit, sliced (shard.cpp): the exchange stream and the per-slice hand-over events ([S] = the way back)
+  hipStream_t s_xchg = nullptr;
+  hipEvent_t ev_slice[LCPC_MAX_SHARD_SLICES + 1] = {nullptr};
+  bool shard_encoded = false;      // split phases: the encode step of a sharded commit has been enqueued, hash / finish / merkle may follow
   hipStream_t s_copy = nullptr, s_comp = nullptr;   // lcpc_commit (host pointer): H2D of row batch b+1 overlaps the NTTs of batch b
   hipEvent_t ev_batch[16] = {nullptr};
   lcpc_timings last{};

@@ -1420,8 +1420,7 @@ hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st) {
     // a last group of <= 48 rows goes to the packed-tail kernel (Ft255 limb path), the whole 64-row groups stay lane = row
     u32 n_main = (u32)a.n_rows;
     const u32 tail = (u32)(a.n_rows & 63);
-    const bool tail_on = !getenv("LCPC_SDIG_NO_TAIL");           // (read per call: tests switch it)
-    if (nl == 8 && a.vals29 != nullptr && tail != 0 && tail <= 48 && tail_on) n_main -= tail;
+    if (nl == 8 && a.vals29 != nullptr && tail != 0 && tail <= 48 && a.tail_on) n_main -= tail;
     if (n_main) {
       dim3 grid((unsigned)((a.m + 3) / 4), (unsigned)((n_main + 127) / 128));
       LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_kernel<NLV, 4>), grid, dim3(128), 0, st, a, n_main));

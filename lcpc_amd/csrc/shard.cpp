@@ -220,20 +220,28 @@ int open_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* cols, uin
 }
 
 // ---- sharded commit phases ----------------------------------------------------------------------------------
-// phase 1: local rows -> comm -> node chaining values at nodes_dev[k][col]
-static int commit_shard_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, hipStream_t st, uint32_t flags,
-                              uint8_t* nodes_dev) {
+// The commit of a rank is four steps (the column range makes the middle two sliceable, so that the exchange of one slice of
+// columns overlaps the hashing of the next -- lcpc_commit_sharded_device below, or a caller with its own collective):
+//   encode        local rows -> comm                                                     (lib.rs:648-653)
+//   hash_cols     columns [c0, c1) of the local rows -> node chaining values [k][c1 - c0] (lib.rs:706-745, this rank's part)
+//   finish_cols   gathered node CVs of columns [c0, c1) -> leaf digests hashes[c0, c1)   (lib.rs:706-745, the rest)
+//   merkle        the tree above the leaf digests                                        (lib.rs:747-785)
+static int shard_encode_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, hipStream_t st, uint32_t flags) {
   const lcpc_ctx* c = m->enc;
   uint64_t rb, re, cb, ce, nch;
   shard_layout_of(c, c->prm.shard_rank, n_rows_total, &rb, &re, &cb, &ce, &nch);
+  int rc = order_after_commit(m, st);      // a refill on another stream than the previous fill's: behind that fill
+  if (rc) return rc;
   m->committed = false;
   m->comm_t = false; m->comm_rows_valid = false; m->coeffs_view = nullptr;
   m->n_rows = n_rows_total; m->row_begin = rb; m->n_rows_local = re - rb;
   m->chunk_begin = cb; m->chunk_end = ce; m->n_chunks = nch;
   m->launches[0] = m->launches[1] = m->launches[2] = 0;
+  m->last.exchange_exposed_ms = 0.f;
+  m->shard_encoded = false;
   const bool fused = c->prm.encoding == LCPC_ENC_LIGERO || m->n_rows_local >= sdig_t_min_rows();
   const bool borrow = (flags & LCPC_COMMIT_BORROW_COEFFS) != 0 && m->n_rows_local > 0;   // local rows are always whole rows
-  int rc = ensure_commit_buffers(m, m->n_rows_local, !borrow);
+  rc = ensure_commit_buffers(m, m->n_rows_local, !borrow);
   if (rc) return rc;
   if (m->timing) HIPCHK(m, hipEventRecord(m->ev[0], st));
   if (m->n_rows_local) {
@@ -261,78 +269,99 @@ static int commit_shard_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, ui
     m->coeffs_view = m->d_coeffs;
   }
   if (m->timing) HIPCHK(m, hipEventRecord(m->ev[1], st));
-  if (ce > cb) {
-    uint64_t first[64];
-    uint32_t lg[64];
-    const int n_nodes = shard_nodes(cb, ce, first, lg);
-    bool all_single = true;
-    for (int k = 0; k < n_nodes; k++) all_single = all_single && lg[k] == 0;
-    LeafArgs la{};
-    la.comm = m->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.col_stride = 1; la.n_cols = c->n_cols; la.row_base = (int64_t)rb;
-    if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = c->t_canon ? 1u : 0u; la.row_stride = 1; la.col_stride = m->n_rows_local; }
-    la.n_rows_total = n_rows_total; la.chunk_begin = (uint32_t)cb; la.n_chunks_local = (uint32_t)(ce - cb);
-    la.n_chunks_total = (uint32_t)nch;
-    if (all_single) {                       // nothing to pre-merge: chunk CVs are the nodes
-      la.out = reinterpret_cast<uint32_t*>(nodes_dev);
-      HIPCHK(m, launch_leaf_chunks(c->NL, la, st));
-      m->launches[1]++;
-    } else {
-      if ((rc = ensure_cvs(m, ce - cb))) return rc;
-      la.out = m->d_cvs;
-      HIPCHK(m, launch_leaf_chunks(c->NL, la, st));
-      m->launches[1]++;
-      for (int k = 0; k < n_nodes; k++) {   // one subtree CV per aligned block of chunks
-        uint32_t* blk = m->d_cvs + (first[k] - cb) * c->n_cols * 8;
-        uint32_t* out = reinterpret_cast<uint32_t*>(nodes_dev) + (size_t)k * c->n_cols * 8;
-        HIPCHK(m, launch_leaf_finish_nodes(blk, nullptr, nullptr, 1u << lg[k], c->n_cols, out, false, st));
-        m->launches[1]++;
-      }
-    }
-  }
-  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], st));
+  if (ce > cb && (rc = ensure_cvs(m, ce - cb))) return rc;      // (all slices share it; sized once so that no slice reallocates)
+  m->shard_encoded = true;
   return 0;
 }
 
-// phase 2: gathered node CVs -> leaf digests -> Merkle tree.  Slot of rank g's node k in `gathered`: padded layout
-// (slots_per_rank > 0) g * slots_per_rank + k; compact layout (slots_per_rank == 0, the native exchange) g for k = 0 and
-// G + (running index over ranks of their nodes k >= 1) otherwise
-static int commit_finish_phase(lcpc_commit_t* m, uint8_t* gathered, uint64_t n_rows_total, uint32_t slots_per_rank, hipStream_t st, uint8_t* root) {
+// columns [c0, c1) of the local rows -> one chaining value per (local node, column): nodes_dev[k][c1 - c0][32 B]
+static int shard_hash_cols(lcpc_commit_t* m, uint64_t c0, uint64_t c1, hipStream_t st, uint8_t* nodes_dev) {
   const lcpc_ctx* c = m->enc;
-  const uint64_t nch = leaf_chunks(c, n_rows_total);
-  const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
-  // node table over all ranks, in chunk order: slot in the gathered buffer + log2(size); cached per shape
-  const uint64_t key = (nch << 24) ^ ((uint64_t)slots_per_rank << 8) ^ G;
-  if (!m->d_node_tab || m->node_tab_key != key) {
-    m->node_slot_h.clear(); m->node_log_h.clear();
-    uint32_t extra = G;
-    for (uint32_t r = 0; r < G; r++) {
-      uint64_t first[64];
-      uint32_t lg[64];
-      const int n = shard_nodes(nch * r / G, nch * (r + 1) / G, first, lg);
-      if (slots_per_rank && (uint32_t)n > slots_per_rank) return LCPC_ERR_ARG;
-      for (int k = 0; k < n; k++) {
-        m->node_slot_h.push_back(slots_per_rank ? r * slots_per_rank + (uint32_t)k : (k == 0 ? r : extra++));
-        m->node_log_h.push_back(lg[k]);
-      }
-    }
-    const uint32_t nn = (uint32_t)m->node_slot_h.size();
-    dev_free(m->d_node_tab);
-    m->d_node_tab = nullptr;
-    int rc = dev_alloc(&m->err, &m->d_node_tab, (size_t)nn * 8);
-    if (rc) return rc;
-    HIPCHK(m, hipMemcpyAsync(m->d_node_tab, m->node_slot_h.data(), nn * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(m, hipMemcpyAsync(m->d_node_tab + nn, m->node_log_h.data(), nn * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(m, hipStreamSynchronize(st));      // one-off per shape (pageable sources)
-    m->node_tab_key = key;
+  const uint64_t cb = m->chunk_begin, ce = m->chunk_end, w = c1 - c0;
+  if (ce <= cb || w == 0) return 0;
+  uint64_t first[64];
+  uint32_t lg[64];
+  const int n_nodes = shard_nodes(cb, ce, first, lg);
+  bool all_single = true;
+  for (int k = 0; k < n_nodes; k++) all_single = all_single && lg[k] == 0;
+  LeafArgs la{};
+  la.comm = m->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.col_stride = 1;
+  if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = c->t_canon ? 1u : 0u; la.row_stride = 1; la.col_stride = m->n_rows_local; }
+  la.comm += c0 * la.col_stride * c->NL;          // the kernel's column 0 is column c0 of the matrix
+  la.n_cols = w; la.row_base = (int64_t)m->row_begin;
+  la.n_rows_total = m->n_rows; la.chunk_begin = (uint32_t)cb; la.n_chunks_local = (uint32_t)(ce - cb);
+  la.n_chunks_total = (uint32_t)m->n_chunks;
+  if (all_single) {                       // nothing to pre-merge: chunk CVs are the nodes
+    la.out = reinterpret_cast<uint32_t*>(nodes_dev);
+    HIPCHK(m, launch_leaf_chunks(c->NL, la, st));
+    m->launches[1]++;
+    return 0;
   }
-  const uint32_t n_nodes = (uint32_t)m->node_slot_h.size();
-  if (nch == 1) {   // single-chunk message: the one "node" already carries ROOT (leaf_chunk_kernel)
-    HIPCHK(m, hipMemcpyAsync(m->d_hashes, gathered + (size_t)m->node_slot_h[0] * c->n_cols * 32, (size_t)c->n_cols * 32, hipMemcpyDeviceToDevice, st));
-  } else {
-    HIPCHK(m, launch_leaf_finish_nodes(reinterpret_cast<uint32_t*>(gathered), m->d_node_tab, m->d_node_tab + n_nodes, n_nodes, c->n_cols,
-                                       m->d_hashes, true, st));
+  uint32_t* cvs = m->d_cvs + (ce - cb) * c0 * 8;      // this slice's [chunk][w] block of the CV buffer
+  la.out = cvs;
+  HIPCHK(m, launch_leaf_chunks(c->NL, la, st));
+  m->launches[1]++;
+  for (int k = 0; k < n_nodes; k++) {   // one subtree CV per aligned block of chunks
+    uint32_t* blk = cvs + (first[k] - cb) * w * 8;
+    uint32_t* out = reinterpret_cast<uint32_t*>(nodes_dev) + (size_t)k * w * 8;
+    HIPCHK(m, launch_leaf_finish_nodes(blk, nullptr, nullptr, 1u << lg[k], w, out, false, st));
     m->launches[1]++;
   }
+  return 0;
+}
+
+// node table over all ranks, in chunk order: slot in the gathered buffer + log2(size); cached per shape.  Slot of rank g's
+// node k: padded layout (slots_per_rank > 0) g * slots_per_rank + k; compact layout (slots_per_rank == 0, the native
+// exchange) g for k = 0 and G + (running index over ranks of their nodes k >= 1) otherwise
+static int shard_node_table(lcpc_commit_t* m, uint32_t slots_per_rank, hipStream_t st) {
+  const lcpc_ctx* c = m->enc;
+  const uint64_t nch = m->n_chunks;
+  const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
+  const uint64_t key = (nch << 24) ^ ((uint64_t)slots_per_rank << 8) ^ G;
+  if (m->d_node_tab && m->node_tab_key == key) return 0;
+  m->node_slot_h.clear(); m->node_log_h.clear();
+  uint32_t extra = G;
+  for (uint32_t r = 0; r < G; r++) {
+    uint64_t first[64];
+    uint32_t lg[64];
+    const int n = shard_nodes(nch * r / G, nch * (r + 1) / G, first, lg);
+    if (slots_per_rank && (uint32_t)n > slots_per_rank) return LCPC_ERR_ARG;
+    for (int k = 0; k < n; k++) {
+      m->node_slot_h.push_back(slots_per_rank ? r * slots_per_rank + (uint32_t)k : (k == 0 ? r : extra++));
+      m->node_log_h.push_back(lg[k]);
+    }
+  }
+  const uint32_t nn = (uint32_t)m->node_slot_h.size();
+  HIPCHK(m, hipStreamSynchronize(st));        // one-off per shape: the old table may still be read by a finish in flight
+  dev_free(m->d_node_tab);
+  m->d_node_tab = nullptr;
+  int rc = dev_alloc(&m->err, &m->d_node_tab, (size_t)nn * 8);
+  if (rc) return rc;
+  HIPCHK(m, hipMemcpy(m->d_node_tab, m->node_slot_h.data(), nn * 4, hipMemcpyHostToDevice));
+  HIPCHK(m, hipMemcpy(m->d_node_tab + nn, m->node_log_h.data(), nn * 4, hipMemcpyHostToDevice));
+  m->node_tab_key = key;
+  return 0;
+}
+
+// gathered node CVs of columns [c0, c1) (gathered[slot][c1 - c0][32 B], clobbered) -> leaf digests hashes[c0, c1)
+static int shard_finish_cols(lcpc_commit_t* m, uint8_t* gathered, uint32_t slots_per_rank, uint64_t c0, uint64_t c1, hipStream_t st) {
+  const uint64_t w = c1 - c0;
+  if (w == 0) return 0;
+  int rc = shard_node_table(m, slots_per_rank, st);
+  if (rc) return rc;
+  const uint32_t n_nodes = (uint32_t)m->node_slot_h.size();
+  uint32_t* out = m->d_hashes + c0 * 8;
+  if (m->n_chunks == 1) {   // single-chunk message: the one "node" already carries ROOT (leaf_chunk_kernel)
+    HIPCHK(m, hipMemcpyAsync(out, gathered + (size_t)m->node_slot_h[0] * w * 32, (size_t)w * 32, hipMemcpyDeviceToDevice, st));
+  } else {
+    HIPCHK(m, launch_leaf_finish_nodes(reinterpret_cast<uint32_t*>(gathered), m->d_node_tab, m->d_node_tab + n_nodes, n_nodes, w, out, true, st));
+    m->launches[1]++;
+  }
+  return 0;
+}
+
+// the Merkle tree over the finished leaf digests; the commitment is complete behind this
+static int shard_merkle_phase(lcpc_commit_t* m, hipStream_t st, uint8_t* root) {
   int rc = merkle_top(m, st);
   if (rc) return rc;
   if (m->timing) {
@@ -340,11 +369,12 @@ static int commit_finish_phase(lcpc_commit_t* m, uint8_t* gathered, uint64_t n_r
     HIPCHK(m, hipEventSynchronize(m->ev[3]));
     (void)hipEventElapsedTime(&m->last.encode_ms, m->ev[0], m->ev[1]);
     (void)hipEventElapsedTime(&m->last.hash_ms, m->ev[1], m->ev[2]);
-    (void)hipEventElapsedTime(&m->last.merkle_ms, m->ev[2], m->ev[3]);   // includes the exchange
+    (void)hipEventElapsedTime(&m->last.merkle_ms, m->ev[2], m->ev[3]);   // includes whatever of the exchange is exposed
     (void)hipEventElapsedTime(&m->last.total_ms, m->ev[0], m->ev[3]);
     m->last.encode_launches = m->launches[0]; m->last.hash_launches = m->launches[1]; m->last.merkle_launches = m->launches[2];
   }
   m->committed = true;
+  m->shard_encoded = false;
   // a prove on this commitment runs on its own stream: it waits for this point of the commit's stream
   if (!m->ev_done) HIPCHK(m, hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
   HIPCHK(m, hipEventRecord(m->ev_done, st));
@@ -376,22 +406,75 @@ int lcpc_shard_nodes(uint64_t n_chunks, uint32_t G, uint32_t g, uint32_t* n_node
   return 0;
 }
 
+// ---- split phases (a caller-side collective) ----------------------------------------------------------------
+int lcpc_commit_shard_encode_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint32_t flags) {
+  if (!m || n_rows_total == 0) return LCPC_ERR_ARG;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  return shard_encode_phase(m, coeffs_local, n_rows_total, (hipStream_t)stream, flags);
+  LCPC_CATCH(m)
+}
+
+int lcpc_commit_shard_hash_device(lcpc_commit_t* m, uint64_t col_begin, uint64_t col_end, void* stream, uint8_t* nodes_dev) {
+  if (!m || !nodes_dev || col_begin > col_end || col_end > m->enc->n_cols) return LCPC_ERR_ARG;
+  if (!m->shard_encoded) return LCPC_ERR_STATE;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  int rc = shard_hash_cols(m, col_begin, col_end, (hipStream_t)stream, nodes_dev);
+  if (rc) return rc;
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], (hipStream_t)stream));
+  return 0;
+  LCPC_CATCH(m)
+}
+
+int lcpc_commit_finish_cols_device(lcpc_commit_t* m, uint8_t* gathered, uint32_t slots_per_rank, uint64_t col_begin, uint64_t col_end,
+                                   void* stream) {
+  if (!m || !gathered || col_begin > col_end || col_end > m->enc->n_cols) return LCPC_ERR_ARG;
+  if (!m->shard_encoded) return LCPC_ERR_STATE;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  return shard_finish_cols(m, gathered, slots_per_rank, col_begin, col_end, (hipStream_t)stream);
+  LCPC_CATCH(m)
+}
+
+int lcpc_commit_finish_merkle_device(lcpc_commit_t* m, void* stream, uint8_t* root) {
+  if (!m) return LCPC_ERR_ARG;
+  if (!m->shard_encoded) return LCPC_ERR_STATE;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(m->enc->prm.device));
+  return shard_merkle_phase(m, (hipStream_t)stream, root);
+  LCPC_CATCH(m)
+}
+
+// the unsliced pair: encode + hash of every column; finish of every column + Merkle
 int lcpc_commit_shard_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint32_t flags,
                              uint8_t* nodes_dev) {
   if (!m || n_rows_total == 0 || !nodes_dev) return LCPC_ERR_ARG;
   LCPC_TRY
   std::lock_guard<std::mutex> g(m->mu);
   HIPCHK(m, hipSetDevice(m->enc->prm.device));
-  return commit_shard_phase(m, coeffs_local, n_rows_total, (hipStream_t)stream, flags, nodes_dev);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = shard_encode_phase(m, coeffs_local, n_rows_total, st, flags);
+  if (!rc) rc = shard_hash_cols(m, 0, m->enc->n_cols, st, nodes_dev);
+  if (rc) return rc;
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], st));
+  return 0;
   LCPC_CATCH(m)
 }
 
 int lcpc_commit_finish_device(lcpc_commit_t* m, uint8_t* gathered, uint64_t n_rows_total, uint32_t slots_per_rank, void* stream, uint8_t* root) {
   if (!m || !gathered || n_rows_total != m->n_rows) return LCPC_ERR_ARG;
+  if (!m->shard_encoded) return LCPC_ERR_STATE;
   LCPC_TRY
   std::lock_guard<std::mutex> g(m->mu);
   HIPCHK(m, hipSetDevice(m->enc->prm.device));
-  return commit_finish_phase(m, gathered, n_rows_total, slots_per_rank, (hipStream_t)stream, root);
+  int rc = shard_finish_cols(m, gathered, slots_per_rank, 0, m->enc->n_cols, (hipStream_t)stream);
+  if (rc) return rc;
+  return shard_merkle_phase(m, (hipStream_t)stream, root);
   LCPC_CATCH(m)
 }
 
@@ -430,6 +513,26 @@ int lcpc_comm_destroy(lcpc_ctx* c) {
   return 0;
 }
 
+// column slices of the native exchange: boundaries at multiples of 256 columns (the hash kernels' workgroup width), no slice
+// narrower than 1024 columns.  Returns the number of slices; bounds[s] .. bounds[s + 1] is slice s
+static uint32_t shard_slices(const lcpc_ctx* c, uint64_t* bounds) {
+  uint32_t S = std::max<uint32_t>(1, std::min<uint32_t>(c->shard_slices, LCPC_MAX_SHARD_SLICES));
+  while (S > 1 && c->n_cols / S < 1024) S--;
+  uint32_t n = 0;
+  bounds[0] = 0;
+  for (uint32_t s = 1; s <= S; s++) {
+    uint64_t b = s == S ? c->n_cols : std::min<uint64_t>(c->n_cols, ((c->n_cols * s / S) + 255) & ~(uint64_t)255);
+    if (b > bounds[n]) bounds[++n] = b;
+  }
+  return n;
+}
+
+// One commit on a row shard with the exchange inside: encode on `stream`; then per slice of columns (shard_slices) the local
+// hash on `stream`, and on the commitment's exchange stream -- behind an event -- the collectives of that slice (node 0 of
+// every rank by ncclAllGather, the few second / third nodes by one ncclBroadcast each, grouped) and the leaf digests of that
+// slice.  The wire time of slice s overlaps the hashing of slice s + 1: only the last slice's exchange is exposed.  `stream`
+// then waits for the exchange stream and builds the Merkle tree.  One slice (LCPC_SHARD_SLICES=1) = everything in sequence on
+// `stream`.
 int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint32_t flags, uint8_t* root) {
   if (!m || n_rows_total == 0) return LCPC_ERR_ARG;
   lcpc_ctx* c = m->enc;
@@ -441,9 +544,9 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
   const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
   const uint32_t me = G > 1 ? c->prm.shard_rank : 0;
   const uint64_t nch = leaf_chunks(c, n_rows_total);
-  // one slot = n_cols chaining values.  What crosses the wire: node 0 of every rank (one all-gather of one slot each)
-  // plus the few second / third nodes some ranks own (one broadcast each: at the headline only the last rank has one),
-  // instead of padding every rank to the largest node count.
+  // one slot = one chaining value per column of a slice.  What crosses the wire: node 0 of every rank (one all-gather of one
+  // slot each) plus the few second / third nodes some ranks own (one broadcast each: at the headline only the last rank has
+  // one), instead of padding every rank to the largest node count.  Per slice, contiguous:
   // [ this rank's nodes ][ gathered: G slots of node 0, then the extra nodes in rank order ]
   uint32_t n_nodes_of[256], extras = 0, my_slots = 1;
   if (G > 256) return LCPC_ERR_ARG;
@@ -454,27 +557,60 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
     if (n_nodes_of[r] > 1) extras += n_nodes_of[r] - 1;
     if (r == me && n_nodes_of[r] > 1) my_slots = n_nodes_of[r];
   }
-  const uint64_t slot_bytes = c->n_cols * 32;
-  int rc = ensure_dev(&m->err, &m->d_gather, &m->gather_cap, slot_bytes * ((uint64_t)my_slots + G + extras));
+  const uint64_t tot_slots = (uint64_t)my_slots + G + extras;
+  int rc = ensure_dev(&m->err, &m->d_gather, &m->gather_cap, tot_slots * c->n_cols * 32);
   if (rc) return rc;
-  uint8_t* send = m->d_gather;
-  uint8_t* recv = m->d_gather + slot_bytes * my_slots;
-  if ((rc = commit_shard_phase(m, coeffs_local, n_rows_total, st, flags, send))) return rc;
-  // collectives of one communicator must be submitted in the same order on every rank: two commitments under this encoder
-  // driven from different host threads take turns here (from GroupStart to GroupEnd)
-  std::lock_guard<std::mutex> xg(c->xchg_mu);
-  int nrc = rccl().GroupStart();
-  if (nrc == 0) nrc = rccl().AllGather(send, recv, (size_t)slot_bytes, NCCL_UINT8, c->comm, st);
-  uint32_t x = G;
-  for (uint32_t r = 0; r < G && nrc == 0; r++)
-    for (uint32_t k = 1; k < n_nodes_of[r] && nrc == 0; k++, x++) {
-      uint8_t* dst = recv + slot_bytes * x;
-      nrc = rccl().Broadcast(r == me ? send + slot_bytes * k : dst, dst, (size_t)slot_bytes, NCCL_UINT8, (int)r, c->comm, st);
+  uint64_t bounds[LCPC_MAX_SHARD_SLICES + 1];
+  const uint32_t S = shard_slices(c, bounds);
+  if ((rc = shard_encode_phase(m, coeffs_local, n_rows_total, st, flags))) return rc;
+  if ((rc = shard_node_table(m, 0, st))) return rc;           // (one-off per shape; no synchronisation inside the slice loop)
+  hipStream_t sx = st;
+  if (S > 1) {
+    if (!m->s_xchg) HIPCHK(m, hipStreamCreateWithFlags(&m->s_xchg, hipStreamNonBlocking));
+    for (uint32_t s = 0; s <= S; s++)
+      if (!m->ev_slice[s]) HIPCHK(m, hipEventCreateWithFlags(&m->ev_slice[s], hipEventDisableTiming));
+    sx = m->s_xchg;
+  }
+  {
+    // Collectives of one communicator must be submitted in the same order on every rank.  This lock only keeps the slices of
+    // two commitments of ONE process from interleaving; it cannot order submissions ACROSS ranks -- one encoder's sharded
+    // commits / proves must be issued in the same program order on every rank (one driving thread per communicator).
+    std::lock_guard<std::mutex> xg(c->xchg_mu);
+    for (uint32_t s = 0; s < S; s++) {
+      const uint64_t c0 = bounds[s], c1 = bounds[s + 1], w = c1 - c0;
+      const uint64_t slot_bytes = w * 32;
+      uint8_t* send = m->d_gather + tot_slots * c0 * 32;
+      uint8_t* recv = send + slot_bytes * my_slots;
+      if ((rc = shard_hash_cols(m, c0, c1, st, send))) return rc;
+      if (S > 1) {
+        HIPCHK(m, hipEventRecord(m->ev_slice[s], st));
+        HIPCHK(m, hipStreamWaitEvent(sx, m->ev_slice[s], 0));
+      } else if (m->timing) {
+        HIPCHK(m, hipEventRecord(m->ev[2], st));
+      }
+      int nrc = rccl().GroupStart();
+      if (nrc == 0) nrc = rccl().AllGather(send, recv, (size_t)slot_bytes, NCCL_UINT8, c->comm, sx);
+      uint32_t x = G;
+      for (uint32_t r = 0; r < G && nrc == 0; r++)
+        for (uint32_t k = 1; k < n_nodes_of[r] && nrc == 0; k++, x++) {
+          uint8_t* dst = recv + slot_bytes * x;
+          nrc = rccl().Broadcast(r == me ? send + slot_bytes * k : dst, dst, (size_t)slot_bytes, NCCL_UINT8, (int)r, c->comm, sx);
+        }
+      const int erc = rccl().GroupEnd();
+      if (nrc == 0) nrc = erc;
+      if (nrc != 0) return fail_nccl(&m->err, nrc, "ncclAllGather / ncclBroadcast");
+      if ((rc = shard_finish_cols(m, recv, 0, c0, c1, sx))) return rc;
     }
-  const int erc = rccl().GroupEnd();
-  if (nrc == 0) nrc = erc;
-  if (nrc != 0) return fail_nccl(&m->err, nrc, "ncclAllGather / ncclBroadcast");
-  return commit_finish_phase(m, recv, n_rows_total, 0, st, root);
+  }
+  if (S > 1) {
+    if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], st));          // the last slice's hash is done here ...
+    HIPCHK(m, hipEventRecord(m->ev_slice[S], sx));
+    HIPCHK(m, hipStreamWaitEvent(st, m->ev_slice[S], 0));            // ... and here its exchange + leaf digests
+  }
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[4], st));
+  if ((rc = shard_merkle_phase(m, st, root))) return rc;
+  if (m->timing) (void)hipEventElapsedTime(&m->last.exchange_exposed_ms, m->ev[2], m->ev[4]);
+  return 0;
   LCPC_CATCH(m)
 }
 

@@ -15,7 +15,7 @@ import oracle_lib as O
 import struct
 
 import pyref as P
-from lcpc_amd.distributed import aligned_nodes, chunk_split, sharded_commit, slots_per_rank
+from lcpc_amd.distributed import aligned_nodes, chunk_split, sharded_commit, slice_bounds, slots_per_rank
 
 
 class OracleShardEngine:
@@ -41,44 +41,57 @@ class OracleShardEngine:
         return rb, re, cb, ce, n_chunks
 
     def commit_shard(self, local_coeffs, n_rows):
+        self.commit_encode(local_coeffs, n_rows)
+        return self.commit_hash_cols(0, self.n_cols)
+
+    def commit_finish(self, gathered, n_rows, slots, want_root=True):
+        self.commit_finish_cols(gathered, slots, 0, self.n_cols)
+        return self.commit_merkle(want_root)
+
+    # ---- the four-step form (encode | hash a column range | leaf digests of a column range | tree) ----
+    def commit_encode(self, local_coeffs, n_rows, borrow=False):
         rb, re, cb, ce, _ = self.layout(n_rows)
         rows = local_coeffs.numpy().view(np.uint64).reshape(re - rb, self.n_per_row, self.L)
         comm = np.zeros((re - rb, self.n_cols, self.L), np.uint64)
         for r in range(re - rb):
             comm[r, :self.n_per_row] = rows[r]
             comm[r] = self.enc.encode(comm[r].copy()).reshape(self.n_cols, self.L)
-        cvs = O.leaf_chunk_cvs(self.fid, comm, self.n_cols, rb, re - rb, n_rows, cb, ce)
+        self._n_rows = n_rows
+        self._cvs = O.leaf_chunk_cvs(self.fid, comm, self.n_cols, rb, re - rb, n_rows, cb, ce)
+        np2 = 1 << max(0, (self.n_cols - 1).bit_length())
+        self.hashes = np.zeros((2 * np2 - 1, 32), np.uint8)
+
+    def commit_hash_cols(self, c0, c1):
+        _, _, cb, ce, _ = self.layout(self._n_rows)
+        cvs = self._cvs
         # pre-merge the chunk CVs into aligned subtree nodes (BLAKE3 parent rule, no ROOT), as the HIP engine does
         nodes = []
         for first, lg in aligned_nodes(cb, ce):
-            level = [[struct.unpack("<8I", cvs[first - cb + i, col].tobytes()) for i in range(1 << lg)] for col in range(self.n_cols)]
-            out = np.zeros((self.n_cols, 32), np.uint8)
-            for col in range(self.n_cols):
-                cur = level[col]
+            out = np.zeros((c1 - c0, 32), np.uint8)
+            for col in range(c0, c1):
+                cur = [struct.unpack("<8I", cvs[first - cb + i, col].tobytes()) for i in range(1 << lg)]
                 while len(cur) > 1:
                     cur = [P.b3_parent(cur[2 * i], cur[2 * i + 1], False) for i in range(len(cur) // 2)]
-                out[col] = np.frombuffer(struct.pack("<8I", *cur[0]), np.uint8)
+                out[col - c0] = np.frombuffer(struct.pack("<8I", *cur[0]), np.uint8)
             nodes.append(out)
-        arr = np.stack(nodes) if nodes else np.zeros((0, self.n_cols, 32), np.uint8)
+        arr = np.stack(nodes) if nodes else np.zeros((0, c1 - c0, 32), np.uint8)
         return torch.from_numpy(arr)
 
-    def commit_finish(self, gathered, n_rows, slots, want_root=True):
-        """fold the gathered nodes of every rank (in chunk order) with the BLAKE3 stack rule, then the Merkle tree"""
-        _, _, _, _, n_chunks = self.layout(n_rows)
+    def commit_finish_cols(self, gathered, slots, c0, c1):
+        """fold the gathered nodes of every rank (in chunk order) with the BLAKE3 stack rule into the leaf digests of [c0, c1)"""
+        _, _, _, _, n_chunks = self.layout(self._n_rows)
         g = gathered.numpy()
         order = []
         for r, (b, e) in enumerate(chunk_split(n_chunks, self.world)):
             for k, (first, lg) in enumerate(aligned_nodes(b, e)):
                 order.append((r * slots + k, lg))
-        np2 = 1 << max(0, (self.n_cols - 1).bit_length())
-        hashes = np.zeros((2 * np2 - 1, 32), np.uint8)
-        for col in range(self.n_cols):
+        for col in range(c0, c1):
             if n_chunks == 1:
-                hashes[col] = g[order[0][0], col]
+                self.hashes[col] = g[order[0][0], col - c0]
                 continue
             stack, total = [], 0
             for j, (slot, lg) in enumerate(order):
-                cv = struct.unpack("<8I", g[slot, col].tobytes())
+                cv = struct.unpack("<8I", g[slot, col - c0].tobytes())
                 if j == len(order) - 1:
                     break
                 total += 1 << lg
@@ -90,13 +103,16 @@ class OracleShardEngine:
             while stack:
                 left = stack.pop()
                 cv = P.b3_parent(left, cv, len(stack) == 0)
-            hashes[col] = np.frombuffer(struct.pack("<8I", *cv), np.uint8)
+            self.hashes[col] = np.frombuffer(struct.pack("<8I", *cv), np.uint8)
+
+    def commit_merkle(self, want_root=True):
+        hashes = self.hashes
+        np2 = (len(hashes) + 1) // 2
         width, ins, outs = np2, 0, np2
         while width > 1:
             for i in range(width // 2):
                 hashes[outs + i] = np.frombuffer(O.blake3(hashes[ins + 2 * i].tobytes() + hashes[ins + 2 * i + 1].tobytes()), np.uint8)
             ins, outs, width = outs, outs + width // 2, width // 2
-        self.hashes = hashes
         return hashes[-1].tobytes()
 
 
@@ -108,7 +124,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q):
+def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q, slices=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -117,7 +133,7 @@ def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q):
         rb, re, _, _, _ = eng.layout(n_rows)
         coeffs = O.random_elems(fid, n_rows * n_per_row, 17).reshape(n_rows, n_per_row, -1)
         local = torch.from_numpy(coeffs[rb:re].copy().view(np.int64))
-        root = sharded_commit(eng, local, n_rows)
+        root = sharded_commit(eng, local, n_rows, slices=slices)
         q.put((rank, root, eng.hashes.tobytes()))
     finally:
         dist.destroy_process_group()
@@ -128,11 +144,16 @@ def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q):
     (2, 0, 300, 16, 32),     # ft63: 128 rows per chunk
     (3, 3, 40, 16, 32),      # 2 chunks over 3 ranks: one rank owns nothing
 ])
-def test_sharded_commit_gloo(world, fid, n_rows, n_per_row, n_cols):
+@pytest.mark.parametrize("slices", [1, [0, 24, 40, 64]])
+def test_sharded_commit_gloo(world, fid, n_rows, n_per_row, n_cols, slices):
+    """slices: the four-step form of the same commit (encode | per column slice: hash, all-gather, leaf digests | tree) with
+    explicit slice boundaries (clipped to n_cols) -- one all-gather per slice, same root and same tree"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fid, n_rows, n_per_row, n_cols, q)) for r in range(world)]
+    if slices != 1:
+        slices = sorted(set(min(b, n_cols) for b in slices))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fid, n_rows, n_per_row, n_cols, q, slices)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -146,6 +167,19 @@ def test_sharded_commit_gloo(world, fid, n_rows, n_per_row, n_cols):
     for rank, root, hashes in res:
         assert root == oc.get_root(), "rank %d" % rank
         assert hashes == oc.hashes().tobytes()
+
+
+def test_slice_bounds_cover_and_align():
+    """the column slices of a sliced sharded commit partition [0, n_cols) at multiples of 256, none narrower than 1024 columns
+    (the rule of shard_slices() in csrc/shard.cpp; the GPU tests check that the library's slices give the unsliced tree)"""
+    for n_cols in (64, 1000, 1024, 2048, 4096, 5000, 252931, 262144, 1 << 20):
+        for S in (1, 2, 3, 4, 7, 16, 40):
+            b = slice_bounds(n_cols, S)
+            assert b[0] == 0 and b[-1] == n_cols and all(x < y for x, y in zip(b, b[1:]))
+            assert all(x % 256 == 0 for x in b[1:-1])
+            assert len(b) - 1 <= max(1, min(S, 16, n_cols // 1024))
+            if len(b) > 2:
+                assert min(y - x for x, y in zip(b, b[1:])) >= 512
 
 
 def test_aligned_nodes_cover_and_align():

@@ -37,6 +37,37 @@ def test_bench_gpus2_self_launches_two_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_n1_json_contract():
+    """the N = 1 line the driver records: one JSON object carrying the metric, `roofline` (bound / achieved / peak / frac with
+    frac == achieved / peak, per-launch algorithmic bytes and launch time) and `cpu_baseline` (value, cores, kind, sample, and
+    the same coefficients' root through the HIP path == the CPU port's root)"""
+    r = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--log-len", "22", "--no-power-sample"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True and out["vs_baseline"] is None
+    assert out["unit"] == "field-elements/s" and out["data"] == "synthetic"
+    assert abs(out["value"] - (1 << 22) / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    cfg = out["config"]
+    assert "lcpc-ligero-pc commit" in cfg["workload"] and "Ft255" in cfg["workload"] and "2^22" in cfg["workload"] and "model" not in cfg
+    assert cfg["n_rows"] * cfg["n_per_row"] == 1 << 22 and cfg["n_cols"] == 2 * cfg["n_per_row"]
+    rf = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_GB_per_launch", "avg_launch_ms"):
+        assert k in rf, k
+    assert rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and rf["achieved"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-3 * rf["frac"] + 1e-4
+    assert abs(rf["achieved"] - rf["algorithmic_GB_per_launch"] / (rf["avg_launch_ms"] * 1e-3)) <= 0.01 * rf["achieved"]
+    cb = out["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "root_equals_hip_root"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == out["unit"] and cb["root_equals_hip_root"] is True
+
+
+@pytest.mark.gpu
 def test_bench_refuses_more_ranks_than_devices():
     n = torch.cuda.device_count() + 1
     r = _run(["--gpus", str(n), "--steps", "1", "--warmup", "0", "--log-len", "20"], timeout=300)

@@ -408,11 +408,12 @@ def test_brakedown_packed_tail_rows(oracle, n_rows):
     coeffs = O.random_elems(fid, n_rows * n_per_row - 3, 50 + n_rows)
     oc = O.Commit.commit(coeffs, oenc, n_threads=8)
     c = LcCommit.commit(coeffs, enc)
-    os.environ["LCPC_SDIG_NO_TAIL"] = "1"
+    os.environ["LCPC_SDIG_NO_TAIL"] = "1"          # (switches are read once, when an encoder is created)
     try:
-        d = LcCommit.commit(coeffs, enc)
+        enc_nt = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 9)
     finally:
         del os.environ["LCPC_SDIG_NO_TAIL"]
+    d = LcCommit.commit(coeffs, enc_nt)
     assert c.get_root() == oc.get_root() == d.get_root()
     assert (c.hashes() == oc.hashes()).all()
     assert (c.comm() == oc.comm()).all() and (d.comm() == oc.comm()).all()

@@ -124,11 +124,12 @@ def test_tile_group_orders_agree(oracle, fid, log_n):
             assert c.get_root() == oc.get_root() and (c.comm() == oc.comm()).all()
         ref_comm, ref_hashes = c.comm(), c.hashes()
         for g in ("0", "1", "2", "4", "6", "9"):
-            os.environ["LCPC_NTT_TILE_GROUP"] = g
+            os.environ["LCPC_NTT_TILE_GROUP"] = g          # (switches are read once, when an encoder is created)
             try:
-                d = LcCommit.commit(coeffs, enc)
+                enc_g = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
             finally:
                 del os.environ["LCPC_NTT_TILE_GROUP"]
+            d = LcCommit.commit(coeffs, enc_g)
             assert (d.comm() == ref_comm).all() and (d.hashes() == ref_hashes).all() and (d.coeffs() == coeffs_padded(coeffs, n_rows, n_per_row, L)).all(), (n_rows, g)
 
 

@@ -65,16 +65,17 @@ def test_limb_intermediate_modes_agree(oracle, log_n, mid_mb):
     coeffs = O.random_elems(fid, n_rows * n_per_row - 5, 11 + log_n)
     enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
     c = LcCommit.commit(coeffs, enc)
-    os.environ["LCPC_NTT_MID_MAX_MB"] = mid_mb
+    os.environ["LCPC_NTT_MID_MAX_MB"] = mid_mb           # (switches are read once, when an encoder is created)
     try:
-        g = LcCommit.commit(coeffs, enc)
-        rows = np.zeros((n_rows * n_cols, 4), np.uint64)
-        for r in range(n_rows):
-            seg = coeffs[r * n_per_row:(r + 1) * n_per_row]
-            rows[r * n_cols:r * n_cols + len(seg)] = seg
-        e = enc.encode(rows)
+        enc_m = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
     finally:
         del os.environ["LCPC_NTT_MID_MAX_MB"]
+    g = LcCommit.commit(coeffs, enc_m)
+    rows = np.zeros((n_rows * n_cols, 4), np.uint64)
+    for r in range(n_rows):
+        seg = coeffs[r * n_per_row:(r + 1) * n_per_row]
+        rows[r * n_cols:r * n_cols + len(seg)] = seg
+    e = enc_m.encode(rows)
     oc = O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4)
     assert (g.comm() == c.comm()).all() and (g.hashes() == c.hashes()).all() and (g.coeffs() == c.coeffs()).all()
     assert g.get_root() == oc.get_root() and (c.comm() == oc.comm()).all()

@@ -15,23 +15,35 @@ from lcpc_amd.distributed import HipShardEngine
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind,fid,n_rows,n_per_row,n_cols", [
-    ("ligero", 3, 512, 256, 512),      # headline row count: 17 BLAKE3 chunks per leaf
-    ("ligero", 3, 20, 64, 128),        # single chunk
-    ("ligero", 0, 300, 128, 256),
-    ("sdig", 3, 70, 300, 0),
+@pytest.mark.parametrize("kind,fid,n_rows,n_per_row,n_cols,slices", [
+    ("ligero", 3, 512, 256, 512, None),      # headline row count: 17 BLAKE3 chunks per leaf (too narrow to slice)
+    ("ligero", 3, 20, 64, 128, None),        # single chunk
+    ("ligero", 0, 300, 128, 256, None),
+    ("sdig", 3, 70, 300, 0, None),
+    ("ligero", 3, 512, 2048, 4096, None),    # the default: 4 column slices, the exchange of each on the commitment's second stream
+    ("ligero", 3, 512, 2048, 4096, "1"),     # LCPC_SHARD_SLICES=1: everything in sequence on the caller's stream
+    ("ligero", 3, 20, 4096, 8192, "7"),      # single chunk (the slice's "node" is its digest), 7 slices
+    ("ligero", 0, 300, 2048, 4096, "3"),
+    ("sdig", 3, 70, 3000, 0, None),          # 4500-odd columns: slice ends at multiples of 256, position-major commitment
+    ("sdig", 3, 70, 3000, 0, "16"),          # asks for more slices than 1024-column slices fit: clamped
 ])
-def test_native_exchange_world1(oracle, kind, fid, n_rows, n_per_row, n_cols):
+def test_native_exchange_world1(oracle, kind, fid, n_rows, n_per_row, n_cols, slices):
+    import os
     O = oracle
     L = O.limbs(fid)
     coeffs = O.random_elems(fid, n_rows * n_per_row, 61)
-    if kind == "ligero":
-        enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=(0, 1))
-        oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
-    else:
-        oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 11, 3)
-        _, _, nc = oenc.get_dims(n_per_row)
-        enc = SdigEncoding(fid, None, 11, 3, 0, (0, 1), _dims=(n_per_row, nc))
+    if slices is not None:
+        os.environ["LCPC_SHARD_SLICES"] = slices          # (read once, when the encoder is created)
+    try:
+        if kind == "ligero":
+            enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=(0, 1))
+            oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+        else:
+            oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 11, 3)
+            _, _, nc = oenc.get_dims(n_per_row)
+            enc = SdigEncoding(fid, None, 11, 3, 0, (0, 1), _dims=(n_per_row, nc))
+    finally:
+        os.environ.pop("LCPC_SHARD_SLICES", None)
     eng = HipShardEngine(enc)
     with pytest.raises(lcpc_amd.LcpcError) as e:          # no communicator yet
         eng.commit_native(torch.zeros(8, dtype=torch.int64, device="cuda"), n_rows)

@@ -17,12 +17,12 @@ total = 26
 for k in [int(x) for x in sys.argv[1:]] or (13, 15, 16, 17, 18, 19):
     n_cols, n_per_row = 1 << k, 1 << (k - 1)
     n = 1 << total
-    enc = LigeroEncoding.new_from_dims(3, n_per_row, n_cols)
     coeffs = B.rand_coeffs(n, 4, 5)
     st = torch.cuda.current_stream().cuda_stream
     res = {}
     for mode in ("0", "6144", "0", "6144"):
-        os.environ["LCPC_NTT_MID_MAX_MB"] = mode
+        os.environ["LCPC_NTT_MID_MAX_MB"] = mode          # read once, when the encoder is created
+        enc = LigeroEncoding.new_from_dims(3, n_per_row, n_cols)
         c = LcCommit(enc)
         for _ in range(3):
             LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False, into=c)
@@ -36,4 +36,4 @@ for k in [int(x) for x in sys.argv[1:]] or (13, 15, 16, 17, 18, 19):
         del c
     print(json.dumps({"log_n_cols": k, "first_pass_stages": k - 10, "run_elems": 1 << (20 - k), "rows": n // n_per_row,
                       "encode_ms_packed": res["0"], "encode_ms_limbs": res["6144"]}), flush=True)
-    del enc, coeffs
+    del coeffs
