@@ -125,7 +125,12 @@ int  lcpc_encode_rows(lcpc_ctx *ctx, uint64_t *rows_host, uint64_t n_rows);
 /* ---- LcCommit (lcpc-2d/src/lib.rs:172-184, 270-312) ---- */
 /* An empty LcCommit bound to `enc` (no device memory yet); every commit entry point below fills it.  Filling it
  * again replaces the commitment and reuses the buffers (a benchmark loop commits into one object; the reference
- * would drop and reallocate its Vecs).  The object holds a reference on `enc`. */
+ * would drop and reallocate its Vecs).  The object holds a reference on `enc`.
+ * Refilling across streams: a fill that only enqueues (lcpc_commit_device and the sharded entry points with a NULL
+ * `root`) records an event; the next fill -- on any stream, or from host memory -- and every reader of the library
+ * (prove, collapse, open, the getters) is ordered behind that event by the library.  What the library cannot see is
+ * the caller's own device-side reader: work enqueued with lcpc_collapse_device on stream A must have completed, or be
+ * ordered by the caller, before the object is refilled on another stream B. */
 int  lcpc_commit_create(lcpc_ctx *enc, lcpc_commit_t **out);
 void lcpc_commit_destroy(lcpc_commit_t *cm);
 const char *lcpc_commit_last_error(const lcpc_commit_t *cm);

@@ -251,11 +251,11 @@ class LcCommit:
         return cm._refresh()
 
     @classmethod
-    def from_parts(cls, enc, comm, coeffs, n_rows):
+    def from_parts(cls, enc, comm, coeffs, n_rows, into=None):
         """test hook = lcpc-2d/src/tests.rs:435-466 random_comm + merkleize."""
         comm = _elems(comm, enc.L)
         cp = _ptr(_elems(coeffs, enc.L)) if coeffs is not None else None
-        cm = cls(enc)
+        cm = into if into is not None else cls(enc)
         cm._check(_lib.lib().lcpc_commit_from_parts(cm._h, _ptr(comm), cp, n_rows, None))
         return cm._refresh()
 

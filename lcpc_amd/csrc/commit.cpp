@@ -60,6 +60,7 @@ int merkle_top(lcpc_commit_t* m, hipStream_t st) {
         if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) { m->h_root = static_cast<uint32_t*>(hp); m->d_root_alias = static_cast<uint32_t*>(dp); }
         else (void)hipHostFree(hp);
       }
+      if (!m->h_root) (void)hipGetLastError();   // the failed call's error must not surface at the next launch check
     }
     HIPCHK(m, launch_merkle_tree(m->d_hashes, c->np2, st, m->d_root_alias));
     m->launches[2]++;
@@ -115,14 +116,19 @@ int finish_timing(lcpc_commit_t* m, hipStream_t st) {
   return 0;
 }
 
-// a new commit starts: whatever the object held is gone, and stays gone if anything below fails
-static void begin_commit(lcpc_commit_t* m, uint64_t n_rows_total, uint64_t row_begin, uint64_t n_rows_local) {
+// a new commit starts: whatever the object held is gone, and stays gone if anything below fails.  `st` -- the stream that
+// will rewrite the object's buffers -- is first ordered behind the commit that filled them last (which may still be running
+// on another, non-blocking stream of the caller: lcpc_commit_device only enqueues)
+static int begin_commit(lcpc_commit_t* m, hipStream_t st, uint64_t n_rows_total, uint64_t row_begin, uint64_t n_rows_local) {
+  int rc = order_after_commit(m, st);
+  if (rc) return rc;
   m->committed = false;
   m->comm_t = false;
   m->comm_rows_valid = false;
   m->coeffs_view = nullptr;
   m->n_rows = n_rows_total; m->row_begin = row_begin; m->n_rows_local = n_rows_local;
   m->launches[0] = m->launches[1] = m->launches[2] = 0;
+  return 0;
 }
 
 // encode the local rows of `src` (row-major, n_per_row per row; flat elements >= n_src_total read as zero) into the
@@ -348,11 +354,11 @@ int lcpc_commit_device(lcpc_commit_t* m, const uint64_t* coeffs_dev, uint64_t n_
   HIPCHK(m, hipSetDevice(c->prm.device));
   hipStream_t st = (hipStream_t)stream;
   const uint64_t n_rows = (n_coeffs + c->n_per_row - 1) / c->n_per_row;    // get_dims (ligero lib.rs:166-169)
-  begin_commit(m, n_rows, 0, n_rows);
+  int rc = begin_commit(m, st, n_rows, 0, n_rows);
+  if (rc) return rc;
   const uint64_t padded = n_rows * c->n_per_row;
   const bool borrow = (flags & LCPC_COMMIT_BORROW_COEFFS) && padded == n_coeffs;
-  int rc = ensure_commit_buffers(m, n_rows, !borrow);
-  if (rc) return rc;
+  if ((rc = ensure_commit_buffers(m, n_rows, !borrow))) return rc;
   const uint32_t* src = reinterpret_cast<const uint32_t*>(coeffs_dev);
   const size_t eb = elem_bytes(c);
   if (m->timing) HIPCHK(m, hipEventRecord(m->ev[0], st));
@@ -384,9 +390,9 @@ int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uin
   std::lock_guard<std::mutex> g(m->mu);
   HIPCHK(m, hipSetDevice(c->prm.device));
   const uint64_t n_rows = (n_coeffs + c->n_per_row - 1) / c->n_per_row;
-  begin_commit(m, n_rows, 0, n_rows);
-  int rc = ensure_commit_buffers(m, n_rows, true);
+  int rc = begin_commit(m, nullptr, n_rows, 0, n_rows);
   if (rc) return rc;
+  if ((rc = ensure_commit_buffers(m, n_rows, true))) return rc;
   const size_t eb = elem_bytes(c);
   const uint64_t padded = n_rows * c->n_per_row;
   const size_t total_bytes = (size_t)n_coeffs * eb;
@@ -410,7 +416,10 @@ int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uin
   constexpr int NB = 16;
   for (auto& e : m->ev_batch)
     if (!e) HIPCHK(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  HIPCHK(m, hipDeviceSynchronize());                       // earlier work on this object's buffers (null stream) is done
+  // Earlier work on this object's buffers: the last fill is ordered by its event (begin_commit put the null stream behind it;
+  // the two streams of this path wait for it as well), and every host-pointer reader (prove, collapse, open, the getters) has
+  // synchronised before it returned.  No device-wide synchronisation: other contexts and streams of the process keep running.
+  if ((rc = order_after_commit(m, m->s_copy)) || (rc = order_after_commit(m, m->s_comp))) return rc;
   if (padded > n_coeffs)
     HIPCHK(m, hipMemsetAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + total_bytes, 0, (size_t)(padded - n_coeffs) * eb, m->s_copy));
   const uint64_t rows_per = (n_rows + NB - 1) / NB;
@@ -433,6 +442,7 @@ int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uin
   if ((rc = merkleize_device(m, m->s_comp))) return rc;
   if (root) HIPCHK(m, hipMemcpyAsync(root, m->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, m->s_comp));
   HIPCHK(m, hipStreamSynchronize(m->s_comp));              // later calls use the null stream / caller streams
+  HIPCHK(m, hipStreamSynchronize(m->s_copy));              // (the tail memset when no batch followed it)
   m->committed = true;
   return 0;
   LCPC_CATCH(m)
@@ -444,10 +454,10 @@ int lcpc_commit_from_parts(lcpc_commit_t* m, const uint64_t* comm, const uint64_
   LCPC_TRY
   std::lock_guard<std::mutex> g(m->mu);
   HIPCHK(m, hipSetDevice(c->prm.device));
-  begin_commit(m, n_rows, 0, n_rows);
-  const size_t eb = elem_bytes(c);
-  int rc = ensure_commit_buffers(m, n_rows, true);
+  int rc = begin_commit(m, nullptr, n_rows, 0, n_rows);
   if (rc) return rc;
+  const size_t eb = elem_bytes(c);
+  if ((rc = ensure_commit_buffers(m, n_rows, true))) return rc;
   if (!m->d_comm || m->cap_comm_rows < n_rows) {           // (Brakedown, position-major path: ensure_commit_buffers leaves comm for later)
     dev_free(m->d_comm); m->d_comm = nullptr; m->cap_comm_rows = 0;
     if ((rc = dev_alloc(&m->err, &m->d_comm, (size_t)n_rows * c->n_cols * eb))) return rc;
@@ -528,9 +538,15 @@ int lcpc_commit_from_bincode(lcpc_commit_t* m, lcpc_read_fn fn, void* user, uint
   if (n_comm == 0 || n_comm % c->n_cols) return LCPC_ERR_COMMIT;             // check_comm: comm.len() == n_rows * n_cols
   const uint64_t n_rows = n_comm / c->n_cols;
   if (n_rows > ((uint64_t)1 << 40) / c->n_cols) return LCPC_ERR_COMMIT;
-  begin_commit(m, n_rows, 0, n_rows);
-  int rc = ensure_commit_buffers(m, n_rows, true);
+  {
+    // untrusted length: nothing is freed or allocated for a commitment that could not fit this device anyway
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(m, hipMemGetInfo(&free_b, &total_b));
+    if (n_rows * (c->n_cols + c->n_per_row) > total_b / eb) return LCPC_ERR_COMMIT;
+  }
+  int rc = begin_commit(m, nullptr, n_rows, 0, n_rows);
   if (rc) return rc;
+  if ((rc = ensure_commit_buffers(m, n_rows, true))) return rc;
   if (!m->d_comm || m->cap_comm_rows < n_rows) {           // (Brakedown, position-major path: ensure_commit_buffers leaves comm for later)
     dev_free(m->d_comm); m->d_comm = nullptr; m->cap_comm_rows = 0;
     if ((rc = dev_alloc(&m->err, &m->d_comm, (size_t)n_rows * c->n_cols * eb))) return rc;

@@ -129,7 +129,12 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
     uint64_t rb = ws->mid_failed ? 0 : ntt_mid_rows(c, n_rows);
     if (rb) {
       std::string scratch_err;
-      if (ensure_dev(&scratch_err, &ws->d_mid, &ws->mid_cap, rb * c->n_cols * 36)) { ws->mid_failed = true; ws->mid_cap = 0; rb = 0; }
+      // (test hook sw_debug_fail_mid: an allocation no device can satisfy, so that the real failure path runs)
+      const uint64_t want = c->sw_debug_fail_mid ? ((uint64_t)1 << 62) : rb * c->n_cols * 36;
+      if (ensure_dev(&scratch_err, &ws->d_mid, &ws->mid_cap, want)) {
+        (void)hipGetLastError();           // HIP keeps a failed call's error until it is read: it must not surface at the next launch check
+        ws->mid_failed = true; ws->mid_cap = 0; rb = 0;
+      }
     }
     const uint64_t step = rb ? rb : n_rows;
     for (uint64_t r0 = 0; r0 < n_rows; r0 += step) {
@@ -734,6 +739,7 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
   if (const char* ev = getenv("LCPC_NTT_MID_MAX_MB")) c->sw_ntt_mid_max_mb = (int64_t)strtoull(ev, nullptr, 10);
   if (const char* ev = getenv("LCPC_NTT_TILE_GROUP")) c->sw_ntt_tile_group = (int32_t)strtoul(ev, nullptr, 10);
   c->sw_sdig_tail = !getenv("LCPC_SDIG_NO_TAIL");
+  c->sw_debug_fail_mid = getenv("LCPC_DEBUG_FAIL_MID") != nullptr;
   if (const char* ev = getenv("LCPC_SHARD_SLICES")) c->shard_slices = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)strtoul(ev, nullptr, 10), LCPC_MAX_SHARD_SLICES));
   int rc = 0;
   // row sharding needs rows that do not straddle BLAKE3 chunks (F | 1024)

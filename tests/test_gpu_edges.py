@@ -499,3 +499,60 @@ def test_commit_device_only_enqueues(kind, fid):
         t2 = time.perf_counter()
         best = min(best, (t1 - t0) / (t2 - t0))
     assert best < 0.6, "enqueueing took %.0f %% of the run time: something in the commit path synchronises" % (best * 100)
+
+
+def test_refill_on_another_stream_right_after_async_commit(oracle):
+    """An LcCommit refilled on stream B while the fill enqueued on (non-blocking) stream A may still be running: the library puts
+    B behind A's fill by the object's event (lcpc_hip.h, "Refilling across streams").  Without that order the two fills write
+    comm / coeffs / hashes concurrently.  A: a 2^24 commit (~3 ms); B: at once, a different 2^24 vector into the same object --
+    then the same with B = the host-pointer entry points (small path, 64 MiB+ batched path, from_parts).  Every result is the
+    oracle's for the LAST vector."""
+    import torch
+    O, fid, n = oracle, 3, 1 << 24
+    enc, oenc = LigeroEncoding.new(fid, n), O.Encoding.ligero(fid, n)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    x, y = O.random_elems(fid, n, 311), O.random_elems(fid, n, 312)
+    dx, dy = torch.from_numpy(x.view(np.int64)).cuda(), torch.from_numpy(y.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    oy = O.Commit.commit(y, oenc, n_threads=8)
+    c = LcCommit(enc)
+    for it in range(3):
+        LcCommit.commit_device(dx.data_ptr(), n, enc, a.cuda_stream, sync=False, into=c)
+        LcCommit.commit_device(dy.data_ptr(), n, enc, b.cuda_stream, sync=False, into=c)
+        assert c.get_root() == oy.get_root()
+        assert (c.hashes() == oy.hashes()).all()
+    assert (c.comm() == oy.comm()).all() and (c.coeffs() == oy.coeffs()).all()
+    # host-pointer refills behind an async device fill: the batched path (>= 64 MiB of coefficients, >= 16 rows) ...
+    LcCommit.commit_device(dx.data_ptr(), n, enc, a.cuda_stream, sync=False, into=c)
+    LcCommit.commit(y, enc, into=c)
+    assert c.get_root() == oy.get_root() and (c.hashes() == oy.hashes()).all()
+    assert (c.comm() == oy.comm()).all() and (c.coeffs() == oy.coeffs()).all()
+    # ... and from_parts (null stream)
+    LcCommit.commit_device(dx.data_ptr(), n, enc, a.cuda_stream, sync=False, into=c)
+    LcCommit.from_parts(enc, oy.comm(), oy.coeffs(), oy.n_rows, into=c)
+    assert c.get_root() == oy.get_root() and (c.hashes() == oy.hashes()).all()
+    a.synchronize(); b.synchronize()
+
+
+def test_limb_intermediate_allocation_failure_degrades(oracle):
+    """K1s keeps the rows between its two passes as 29-bit limbs in a separate buffer (n_cols <= 2^15: on by default).  When that
+    buffer cannot be allocated the commit must fall back to the packed intermediate, not fail: HIP keeps a failed call's error
+    until it is read, and the next launch check would otherwise return it.  LCPC_DEBUG_FAIL_MID (read at
+    context creation) makes the allocation a request no device can satisfy, so the real hipMalloc failure path runs."""
+    import os
+    O, fid = oracle, 3
+    n_per_row, n_cols, n_rows = 8192, 16384, 9
+    oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+    coeffs = O.random_elems(fid, n_rows * n_per_row - 5, 313)
+    oc = O.Commit.commit(coeffs, oenc)
+    os.environ["LCPC_DEBUG_FAIL_MID"] = "1"
+    try:
+        enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    finally:
+        del os.environ["LCPC_DEBUG_FAIL_MID"]
+    for _ in range(2):                    # the first commit meets the failure, the second runs with mid_failed set
+        c = LcCommit.commit(coeffs, enc)
+        assert c.get_root() == oc.get_root()
+        assert (c.comm() == oc.comm()).all() and (c.hashes() == oc.hashes()).all()
+    ref = LcCommit.commit(coeffs, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols))
+    assert ref.get_root() == oc.get_root()
