@@ -73,6 +73,7 @@ struct lcpc_ctx {
   int64_t sw_ntt_mid_max_mb = -1;  // LCPC_NTT_MID_MAX_MB: -1 = the default rule of ntt_mid_rows
   int32_t sw_ntt_tile_group = -1;  // LCPC_NTT_TILE_GROUP: -1 = the default rule of ntt_tile_group_of
   bool sw_sdig_tail = true;        // LCPC_SDIG_NO_TAIL unset
+  uint32_t sw_sdig_row_group = 0;  // LCPC_SDIG_ROW_GROUP: Brakedown Ft255 wide levels in row groups of <= this many rows (0 = off)
   bool sw_debug_fail_mid = false;  // LCPC_DEBUG_FAIL_MID (test hook): the K1s limb-intermediate allocation fails -> packed intermediate
   uint32_t shard_slices = 4;       // native sharded commit: column slices whose exchange overlaps the next slice's hashing
                                    // (LCPC_SHARD_SLICES at context creation; 1 = everything in sequence on one stream)

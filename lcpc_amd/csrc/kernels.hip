@@ -1323,9 +1323,10 @@ __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a, u32 n_main) {
 // lanes run over (output, tail row) pairs back to back, so that a wave holds the tails of two or three outputs and is full.
 // The price: matrix entries are per lane (vector loads; 64 lanes share two or three distinct entries, L1 hits) instead of
 // scalar, and a wave runs as long as its longest output.  Same dot products, same reduction points (every <= 60 terms).
-__global__ void __launch_bounds__(256) spmm_t_tail_kernel(SpmmTArgs a, u32 n_main) {
+// (tail = 0: rows [n_main, n_rows); otherwise the `tail` rows from n_main on -- one row group of a grouped launch)
+__global__ void __launch_bounds__(256) spmm_t_tail_kernel(SpmmTArgs a, u32 n_main, u32 tail_rows) {
   constexpr int NL = 8;
-  const u32 tail = (u32)a.n_rows - n_main;
+  const u32 tail = tail_rows ? tail_rows : (u32)a.n_rows - n_main;
   const u64 total = a.m * tail;
   const u64 flat = (u64)blockIdx.x * 256 + threadIdx.x;
   if ((flat & ~(u64)63) >= total) return;
@@ -1416,7 +1417,15 @@ __global__ void __launch_bounds__(128 * SL) spmm_t_sliced_kernel(SpmmTArgs a) {
 }
 hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st) {
   if (a.m == 0 || a.n_rows == 0) return hipSuccess;
-  if (a.m >= 8192) {
+  if (a.m >= 8192 && a.row_group && nl == 8 && a.vals29 != nullptr && a.n_rows > a.row_group) {
+    // row groups: equal groups of <= row_group rows, each one launch of the packed (output, row) kernel over all outputs
+    const u32 G = (u32)((a.n_rows + a.row_group - 1) / a.row_group), per = (u32)((a.n_rows + G - 1) / G);
+    for (u32 r0 = 0; r0 < (u32)a.n_rows; r0 += per) {
+      const u32 cnt = r0 + per < (u32)a.n_rows ? per : (u32)a.n_rows - r0;
+      const u64 total = a.m * cnt;
+      hipLaunchKernelGGL(spmm_t_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, r0, cnt);
+    }
+  } else if (a.m >= 8192) {
     // a last group of <= 48 rows goes to the packed-tail kernel (Ft255 limb path), the whole 64-row groups stay lane = row
     u32 n_main = (u32)a.n_rows;
     const u32 tail = (u32)(a.n_rows & 63);
@@ -1427,7 +1436,7 @@ hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st) {
     }
     if (n_main != (u32)a.n_rows) {
       const u64 total = a.m * (a.n_rows - n_main);
-      hipLaunchKernelGGL(spmm_t_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, n_main);
+      hipLaunchKernelGGL(spmm_t_tail_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, n_main, 0u);
     }
   } else if (a.m > 2048) {
     dim3 grid((unsigned)a.m, (unsigned)((a.n_rows + 127) / 128));

@@ -893,21 +893,24 @@ void lo_hash_column(int fid, const u64 *col, u64 n_rows, u8 out[32]) {
   }
   b3_final(&d, out);
 }
-/* chunk CV of one column: chunk `ch` of the message 0^32 || repr(col[0]) || ... (bytes [1024 ch, 1024 ch + 1024)) */
-int lo_leaf_chunk_cvs(int fid, const u64 *comm, u64 n_cols, u64 row_base, u64 n_local, u64 n_rows, u64 cb, u64 ce, u8 *cvs) {
+/* chunk CV of one column: chunk `ch` of the message 0^32 || repr(col[0]) || ... (bytes [1024 ch, 1024 ch + 1024)).
+ * (_mt: columns spread over nthreads; the streaming whole-tree check of the full-size tests uses it.) */
+int lo_leaf_chunk_cvs_mt(int fid, const u64 *comm, u64 n_cols, u64 row_base, u64 n_local, u64 n_rows, u64 cb, u64 ce, u8 *cvs, int nthreads) {
   const fld_t *f = getf(fid);
   if (!f) return LO_ERR_ARG;
   const int L = f->L;
   const u64 F = 8 * L, total = 32 + F * n_rows, n_chunks = (total + 1023) / 1024;
-  u8 *msg = malloc(1024);
-  for (u64 ch = cb; ch < ce; ch++)
-    for (u64 col = 0; col < n_cols; col++) {
+  int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(| : bad)
+  for (u64 col = 0; col < n_cols; col++) {
+    u8 msg[1024];
+    for (u64 ch = cb; ch < ce && !bad; ch++) {
       const u64 off = ch * 1024, len = total - off < 1024 ? total - off : 1024;
       for (u64 b = 0; b < len;) {              /* assemble the chunk's bytes from the prefix and the local rows */
         const u64 pos = off + b;
         if (pos < 32) { msg[b++] = 0; continue; }
         const u64 row = (pos - 32) / F, within = (pos - 32) % F;
-        if (row < row_base || row >= row_base + n_local) { free(msg); return LO_ERR_ARG; }
+        if (row < row_base || row >= row_base + n_local) { bad = 1; break; }
         u64 t[MAXL];
         DISPATCH_L(f, fcanon(t, comm + ((row - row_base) * n_cols + col) * L, f, L));
         u64 take = F - within;
@@ -915,6 +918,7 @@ int lo_leaf_chunk_cvs(int fid, const u64 *comm, u64 n_cols, u64 row_base, u64 n_
         memcpy(msg + b, (const u8 *)t + within, take);
         b += take;
       }
+      if (bad) break;
       u32 cv[8];
       memcpy(cv, B3_IV, 32);
       const u64 nb = (len + 63) / 64;
@@ -927,8 +931,11 @@ int lo_leaf_chunk_cvs(int fid, const u64 *comm, u64 n_cols, u64 row_base, u64 n_
       }
       memcpy(cvs + ((ch - cb) * n_cols + col) * 32, cv, 32);
     }
-  free(msg);
-  return 0;
+  }
+  return bad ? LO_ERR_ARG : 0;
+}
+int lo_leaf_chunk_cvs(int fid, const u64 *comm, u64 n_cols, u64 row_base, u64 n_local, u64 n_rows, u64 cb, u64 ce, u8 *cvs) {
+  return lo_leaf_chunk_cvs_mt(fid, comm, n_cols, row_base, n_local, n_rows, cb, ce, cvs, 1);
 }
 static void b3_tree_from_cvs(const u32 (*cv)[8], u64 n, int is_root, u32 out[8]) {
   if (n == 1) { memcpy(out, cv[0], 32); return; }
@@ -940,21 +947,41 @@ static void b3_tree_from_cvs(const u32 (*cv)[8], u64 n, int is_root, u32 out[8])
   memcpy(out, B3_IV, 32);
   b3_compress(out, blk, 0, 64, B3_PARENT | (is_root ? B3_ROOT : 0));
 }
-int lo_finish_from_cvs(const u8 *all, u64 n_chunks, u64 n_cols, u8 *hashes) {
+static void merkle_pair(const u8 *in, u8 *out);
+int lo_finish_from_cvs_mt(const u8 *all, u64 n_chunks, u64 n_cols, u8 *hashes, int nthreads) {
   const u64 w0 = np2(n_cols);
   memset(hashes, 0, (2 * w0 - 1) * 32);
-  u32 (*tmp)[8] = malloc(n_chunks * 32);
-  for (u64 col = 0; col < n_cols; col++) {
-    for (u64 ch = 0; ch < n_chunks; ch++) memcpy(tmp[ch], all + (ch * n_cols + col) * 32, 32);
-    u32 out[8];
-    b3_tree_from_cvs((const u32 (*)[8])tmp, n_chunks, 1, out);
-    memcpy(hashes + 32 * col, out, 32);
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+  {
+    u32 (*tmp)[8] = malloc(n_chunks * 32);
+#pragma omp for schedule(static)
+    for (u64 col = 0; col < n_cols; col++) {
+      for (u64 ch = 0; ch < n_chunks; ch++) memcpy(tmp[ch], all + (ch * n_cols + col) * 32, 32);
+      u32 out[8];
+      b3_tree_from_cvs((const u32 (*)[8])tmp, n_chunks, 1, out);
+      memcpy(hashes + 32 * col, out, 32);
+    }
+    free(tmp);
   }
-  free(tmp);
   u64 width = w0, ins = 0, outs = w0;
-  while (width > 1) {
+  while (width > 1) {                           /* merkle_tree / merkle_layer, lib.rs:747-785 */
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) if (width > 64)
     for (u64 i = 0; i < width / 2; i++) merkle_pair(hashes + 32 * (ins + 2 * i), hashes + 32 * (outs + i));
     ins = outs; outs += width / 2; width /= 2;
+  }
+  return 0;
+}
+int lo_finish_from_cvs(const u8 *all, u64 n_chunks, u64 n_cols, u8 *hashes) { return lo_finish_from_cvs_mt(all, n_chunks, n_cols, hashes, 1); }
+/* the encode loop of commit alone (lib.rs:648-653): n_rows rows of n_per_row coefficients -> n_rows x n_cols, rows over threads */
+int lo_encode_rows(const lo_enc *e, const u64 *coeffs, u64 n_rows, int nthreads, u64 *comm) {
+  if (!e || !coeffs || !comm) return LO_ERR_ARG;
+  const int L = e->f->L;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+  for (u64 r = 0; r < n_rows; r++) {
+    u64 *row = comm + r * e->n_cols * L;
+    memcpy(row, coeffs + r * e->n_per_row * L, e->n_per_row * L * 8);
+    memset(row + e->n_per_row * L, 0, (e->n_cols - e->n_per_row) * L * 8);
+    lo_enc_encode(e, row);
   }
   return 0;
 }

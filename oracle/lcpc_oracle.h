@@ -117,6 +117,14 @@ int  lo_leaf_chunk_cvs(int fid, const uint64_t *comm_local, uint64_t n_cols, uin
                        uint64_t n_rows_total, uint64_t chunk_begin, uint64_t chunk_end, uint8_t *cvs);
 /* fold all chunk CVs of every column into leaf digests (BLAKE3 parent rule), then the Merkle tree */
 int  lo_finish_from_cvs(const uint8_t *all_cvs, uint64_t n_chunks, uint64_t n_cols, uint8_t *hashes /* (2*np2-1)*32 */);
+/* the same two with the columns spread over n_threads, and the encode loop of commit alone (lib.rs:648-653): together a
+ * STREAMING commit -- encode a chunk-aligned block of rows, reduce it to chunk CVs, drop it -- whose host memory is a few
+ * row blocks instead of the whole commitment (tests/oracle_lib.py commit_streaming: the 2^28 whole-tree check) */
+int  lo_leaf_chunk_cvs_mt(int fid, const uint64_t *comm_local, uint64_t n_cols, uint64_t row_base, uint64_t n_rows_local,
+                          uint64_t n_rows_total, uint64_t chunk_begin, uint64_t chunk_end, uint8_t *cvs, int n_threads);
+int  lo_finish_from_cvs_mt(const uint8_t *all_cvs, uint64_t n_chunks, uint64_t n_cols, uint8_t *hashes, int n_threads);
+int  lo_encode_rows(const lo_enc *, const uint64_t *coeffs /* n_rows x n_per_row */, uint64_t n_rows, int n_threads,
+                    uint64_t *comm /* n_rows x n_cols */);
 
 /* ---- prove / verify (bincode 1.3 wire format) ---- */
 int  lo_prove(const lo_commit *, const lo_enc *, const uint64_t *outer_tensor, uint64_t n_outer,

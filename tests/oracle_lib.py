@@ -87,6 +87,9 @@ def lib():
             "lo_hash_column": (None, [C.c_int, vp, C.c_uint64, vp]),
             "lo_leaf_chunk_cvs": (C.c_int, [C.c_int, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]),
             "lo_finish_from_cvs": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),
+            "lo_leaf_chunk_cvs_mt": (C.c_int, [C.c_int, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_int]),
+            "lo_finish_from_cvs_mt": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, C.c_int]),
+            "lo_encode_rows": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp]),
             "lo_prove": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp, vp, vp]),
             "lo_verify": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp, vp]),
             "lo_free": (None, [vp]),
@@ -371,4 +374,39 @@ def finish_from_cvs(all_cvs, n_cols):
     np2 = 1 << max(0, (n_cols - 1).bit_length())
     hashes = np.zeros((2 * np2 - 1, 32), np.uint8)
     lib().lo_finish_from_cvs(ptr(all_cvs), n_chunks, n_cols, ptr(hashes))
+    return hashes
+
+
+def commit_streaming(enc, n_coeffs, rows_of, n_threads=1, chunks_per_step=1):
+    """LcCommit::commit (lcpc-2d/src/lib.rs:622-671) WITHOUT holding comm: the rows are encoded a chunk-aligned block at a time
+    (lib.rs:648-653), each block is reduced to the BLAKE3 chunk chaining values of every column's leaf message
+    (hash_columns, lib.rs:706-745: the digest of 0^32 || repr(col[0]) || ... is a tree over 1 KiB chunks) and dropped; the
+    leaf digests and the Merkle tree (lib.rs:747-785) follow from the chaining values.  Host memory: one block of encoded
+    rows + 32 bytes per (chunk, column) -- ~2 GB at 2^28 Ft255 coefficients where Commit.commit needs ~40 GB.
+    rows_of(r0, r1) returns the coefficients of rows [r0, r1) as an (elements, L) uint64 array (a ragged last row is padded
+    here).  Returns the `hashes` array (2 * np2 - 1, 32).  Needs F | 1024 (rows that do not straddle chunks): Ft63, Ft127, Ft255."""
+    fid, L = enc.fid, enc.L
+    F = 8 * L
+    if 1024 % F:
+        raise ValueError("commit_streaming: element size must divide 1024")
+    n_rows, n_per_row, n_cols = enc.get_dims(n_coeffs)
+    n_chunks = (32 + F * n_rows + 1023) // 1024
+    first_row = lambda ch: 0 if ch == 0 else min(n_rows, (ch * 1024 - 32) // F)
+    cvs = np.zeros((n_chunks, n_cols, 32), np.uint8)
+    for cb in range(0, n_chunks, chunks_per_step):
+        ce = min(n_chunks, cb + chunks_per_step)
+        r0, r1 = first_row(cb), (n_rows if ce >= n_chunks else first_row(ce))
+        blk = np.zeros(((r1 - r0) * n_per_row, L), np.uint64)
+        got = np.ascontiguousarray(rows_of(r0, r1), np.uint64).reshape(-1, L)
+        blk[:got.shape[0]] = got
+        comm = np.empty(((r1 - r0) * n_cols, L), np.uint64)
+        if lib().lo_encode_rows(enc.h, ptr(blk), r1 - r0, n_threads, ptr(comm)):
+            raise RuntimeError("lo_encode_rows failed")
+        out = cvs[cb:ce]
+        if lib().lo_leaf_chunk_cvs_mt(fid, ptr(comm), n_cols, r0, r1 - r0, n_rows, cb, ce, ptr(out), n_threads):
+            raise RuntimeError("lo_leaf_chunk_cvs_mt failed")
+        del comm, blk, got
+    np2 = 1 << max(0, (n_cols - 1).bit_length())
+    hashes = np.zeros((2 * np2 - 1, 32), np.uint8)
+    lib().lo_finish_from_cvs_mt(ptr(cvs), n_chunks, n_cols, ptr(hashes), n_threads)
     return hashes

@@ -556,3 +556,25 @@ def test_limb_intermediate_allocation_failure_degrades(oracle):
         assert (c.comm() == oc.comm()).all() and (c.hashes() == oc.hashes()).all()
     ref = LcCommit.commit(coeffs, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols))
     assert ref.get_root() == oc.get_root()
+
+
+@pytest.mark.parametrize("n_rows,group", [(101, 34), (101, 26), (70, 64), (130, 17), (65, 1)])
+def test_brakedown_row_groups(oracle, n_rows, group):
+    """LCPC_SDIG_ROW_GROUP=g (read at context creation): the wide levels of an Ft255 Brakedown encode run as one launch of the packed
+    (output, row) kernel per group of <= g rows (equal groups), so that a group's gather range can stay in the Infinity Cache.
+    Same dot products, same reduction points: root, hashes and comm equal the oracle's and the ungrouped path's."""
+    import os
+    O, fid, n_per_row = oracle, 3, 70000
+    oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 9)
+    _, _, n_cols = oenc.get_dims(n_per_row)
+    coeffs = O.random_elems(fid, n_rows * n_per_row - 3, 150 + n_rows)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=8)
+    os.environ["LCPC_SDIG_ROW_GROUP"] = str(group)
+    try:
+        enc = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 9)
+    finally:
+        del os.environ["LCPC_SDIG_ROW_GROUP"]
+    c = LcCommit.commit(coeffs, enc)
+    assert c.get_root() == oc.get_root()
+    assert (c.hashes() == oc.hashes()).all()
+    assert (c.comm() == oc.comm()).all()

@@ -10,8 +10,11 @@
   * the reference's other two published rate series (lcpc-ligero-pc/src/tests.rs:59-98: rho = 1/4 default, 38/39 "isz") at
     2^26 and 2^25, whole tree + proof bytes.
 A whole-tree comparison that cannot run for lack of host memory FAILS (it used to skip): a skipped comparison would silently
-downgrade a full-size parity claim to a sampled one; at 2^28 (needs ~40 GB) it runs when the host has >= 48 GB free and the
-test's last line records which of the two happened."""
+downgrade a full-size parity claim to a sampled one.  At 2^28 the oracle's Commit.commit would need ~40 GB of host memory, so
+the whole `hashes` array is compared with the oracle's STREAMING commit instead (tests/oracle_lib.py commit_streaming: ~2 GB;
+tests/test_oracle_streaming.py pins it to Commit.commit) -- unconditionally; only the comparison of the proof bytes with the
+oracle PROVER's, which needs the whole commitment on the host, is left to the smaller sizes there (the oracle VERIFIER checks
+the 2^28 proof)."""
 import random
 
 import numpy as np
@@ -53,17 +56,15 @@ def host_memory_available():
     return avail
 
 
-def check_whole_tree(O, c, coeffs_dev, oenc, n_threads=16, need_factor=12, must=True):
+def check_whole_tree(O, c, coeffs_dev, oenc, n_threads=16, need_factor=12):
     """the oracle commits the same coefficients on the host; every digest of LcCommit.hashes must agree.  Returns the oracle's
-    commitment (for proof-byte comparisons), or None when must=False and host memory does not allow it."""
+    commitment (for proof-byte comparisons).  Not enough host memory = failure, never a skip."""
     n = coeffs_dev.shape[0]
     need = need_factor * n * 8 * coeffs_dev.shape[1]          # coeffs (numpy + oracle copy) + comm (+ slack)
     avail = host_memory_available()
     if avail is not None and avail < need + (6 << 30):
-        if must:
-            pytest.fail("not enough host memory for the oracle's whole-tree comparison at this size (%d GB free, %d GB needed): "
-                        "the full-size parity claim cannot be checked on this box" % (avail >> 30, (need + (6 << 30)) >> 30))
-        return None
+        pytest.fail("not enough host memory for the oracle's whole-tree comparison at this size (%d GB free, %d GB needed): "
+                    "the full-size parity claim cannot be checked on this box" % (avail >> 30, (need + (6 << 30)) >> 30))
     host = coeffs_dev.cpu().numpy().view(np.uint64)
     oc = O.Commit.commit(host, oenc, n_threads=n_threads)
     assert c.get_root() == oc.get_root()
@@ -124,12 +125,16 @@ def run_ligero_fullsize(O, log_len, rho, dims, linearity):
     # the evaluation equals <inner, eval_outer(outer)> recomputed by the oracle from the proof's p_eval
     ev_prod = pf.verify(root, outer, inner, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
     assert (ev_prod == ev).all()
-    # whole tree, and the oracle PROVER's bytes on the same transcript (lcpc-2d/src/lib.rs:1004-1093).  2^28: ~40 GB of host
-    # memory for the oracle's commitment -- done when the box has it
-    big = log_len > 26
-    oc = check_whole_tree(O, c, coeffs, oenc, need_factor=(5 if big else 12), must=not big)
-    WHOLE_TREE_DONE[(log_len, rho)] = oc is not None
-    if oc is not None:
+    # whole tree, and the oracle PROVER's bytes on the same transcript (lcpc-2d/src/lib.rs:1004-1093).  2^28: the oracle's
+    # streaming commit (row blocks fetched from the device, ~2 GB of host memory) gives the same `hashes` array
+    if log_len > 26:
+        rows_of = lambda r0, r1: coeffs[r0 * npr:min(n, r1 * npr)].cpu().numpy().view(np.uint64)
+        oh = O.commit_streaming(oenc, n, rows_of, n_threads=16)
+        assert oh[-1].tobytes() == root
+        assert (c.hashes() == oh).all()
+        del oh
+    else:
+        oc = check_whole_tree(O, c, coeffs, oenc)
         opf, _ = oc.prove(outer, oenc, mk_transcript(O.Transcript, root, oenc.get_n_col_opens()))
         assert pf.to_bytes() == opf, "proof bytes differ from the oracle prover's"
         del oc, opf
@@ -158,20 +163,12 @@ def run_ligero_fullsize(O, log_len, rho, dims, linearity):
     assert not (vs.reshape(-1, 4) == a_h).all()
 
 
-WHOLE_TREE_DONE = {}
-
-
 @pytest.mark.parametrize("log_len", [24, 26, 28])
 def test_ligero_ft255_fullsize(oracle, log_len):
     """BASELINE configs[1] (2^24), the headline / configs[4] (2^26) and configs[3]'s commitment (2^28, here on ONE
     GPU: 8 + 16 GiB, 33 BLAKE3 chunks per leaf): commit + prove at full size, whole tree and proof bytes against the oracle."""
     dims = {24: (256, 65536, 131072), 26: (512, 131072, 262144), 28: (1024, 262144, 524288)}[log_len]
     run_ligero_fullsize(oracle, log_len, (1, 2), dims, linearity=log_len <= 26)
-    if log_len <= 26:
-        assert WHOLE_TREE_DONE[(log_len, (1, 2))]
-    else:
-        print("2^28 whole-tree comparison against the oracle: %s" % ("done" if WHOLE_TREE_DONE[(28, (1, 2))] else
-              "NOT done (host memory < 48 GB): rows, columns, paths and the oracle-verified proof only"))
 
 
 @pytest.mark.parametrize("log_len,rho,dims", [(26, (1, 4), (1024, 65536, 262144)), (25, (38, 39), (132, 255422, 262144))])
@@ -180,7 +177,6 @@ def test_ligero_ft255_fullsize_other_rates(oracle, log_len, rho, dims):
     20210807_64c_255bit_ligero_{dfl,isz}.txt): rho = 1/4 at 2^26 (8 GiB of comm, 33 chunks per leaf) and rho = 38/39 at 2^25
     (ragged last row, no zero half in the first NTT round)."""
     run_ligero_fullsize(oracle, log_len, rho, dims, linearity=False)
-    assert WHOLE_TREE_DONE[(log_len, rho)]
 
 
 def test_brakedown_ft255_2e24(oracle):
