@@ -143,7 +143,14 @@ int  lcpc_commit(lcpc_commit_t *cm, const uint64_t *coeffs_host, uint64_t n_coef
  * caller's buffer (prove / collapse), which must stay valid and unchanged until the commitment is replaced or
  * destroyed.  Honoured when n_coeffs fills whole rows (n_coeffs == n_rows * n_per_row); a ragged vector is copied
  * (the padded tail has to exist somewhere). */
-enum { LCPC_COMMIT_BORROW_COEFFS = 1 };
+enum {
+  LCPC_COMMIT_BORROW_COEFFS = 1,
+  /* lcpc_commit_sharded_device only: the exchange, the leaf digests and the Merkle tree run on the commitment's own stream and
+   * `stream` does not wait for them -- it is free again after the local column hash, so the next commit on `stream` (into
+   * ANOTHER lcpc_commit_t; a refill of the same one waits for it) encodes while this one's node values are on the wire.  The
+   * commitment is complete behind its event, which every reader of the library waits for; `root` != NULL still synchronises. */
+  LCPC_COMMIT_ASYNC_TAIL = 2
+};
 int  lcpc_commit_device(lcpc_commit_t *cm, const uint64_t *coeffs_dev, uint64_t n_coeffs, void *stream, uint32_t flags,
                         uint8_t *root);
 /* test hook for lcpc-2d/src/tests.rs:435-466 `random_comm` + `merkleize` (tests.rs:136-149): install a
@@ -232,12 +239,14 @@ int  lcpc_shard_nodes(uint64_t n_chunks_total, uint32_t shard_count, uint32_t sh
 int  lcpc_comm_unique_id(uint8_t id[128]);
 int  lcpc_comm_init(lcpc_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_t world);
 int  lcpc_comm_destroy(lcpc_ctx *ctx);
-/* whole sharded commit: encode the local rows (coeffs_local_dev = this rank's rows, row-major) on `stream`, then per SLICE
- * of columns (4 by default; LCPC_SHARD_SLICES=<1..16> when the encoder is created) the local column hash on `stream` and --
- * on a second stream owned by the commitment, behind an event -- ncclAllGather (+ grouped ncclBroadcasts) of that slice's
- * node chaining values and its leaf digests, so that the wire time of slice s hides behind the hashing of slice s + 1 and
- * only the last slice's exchange is exposed; `stream` then waits for the last slice and builds the Merkle tree (replicated).
- * No host synchronisation unless `root` is non-NULL.  flags as lcpc_commit_device.
+/* whole sharded commit: encode the local rows (coeffs_local_dev = this rank's rows, row-major) and hash their columns down to
+ * node chaining values on `stream`, ONE exchange of those (ncclAllGather + grouped ncclBroadcasts for the few ranks that own a
+ * second node), leaf digests and the Merkle tree (replicated) -- by default all on `stream`, in sequence.  Two ways to take the
+ * wire off the critical path, both bit-identical in result: LCPC_COMMIT_ASYNC_TAIL in `flags` (above: overlap with the NEXT
+ * commit's encode; what a prover committing several polynomials wants), and LCPC_SHARD_SLICES=<2..16> when the encoder is
+ * created (column slices: the exchange of slice s on the commitment's second stream while `stream` hashes slice s + 1; hides at
+ * most the hash time and costs extra launches -- measured neutral to slightly negative, hence off by default).
+ * No host synchronisation unless `root` is non-NULL.  flags: LCPC_COMMIT_BORROW_COEFFS as for lcpc_commit_device.
  * Collectives on one communicator must be issued in the same order on every rank: drive the sharded commits / proves of
  * one encoder from ONE host thread per rank, in the same program order everywhere (the library only keeps two commitments
  * of one process from interleaving their slices). */

@@ -206,6 +206,7 @@ class SdigEncoding(_Encoding):
 
 
 BORROW_COEFFS = 1      # LCPC_COMMIT_BORROW_COEFFS
+ASYNC_TAIL = 2         # LCPC_COMMIT_ASYNC_TAIL (lcpc_commit_sharded_device)
 
 
 class LcCommit:

@@ -285,7 +285,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
     nl++;
     uint64_t in_start = 0;
     SpmmTArgs a{};
-    a.t = ws->d_t; a.n_rows = n_rows; a.tail_on = c->sw_sdig_tail; a.row_group = c->sw_sdig_row_group;
+    a.t = ws->d_t; a.n_rows = n_rows; a.tail_on = c->sw_sdig_tail; a.row_group = c->sw_sdig_row_group; a.price = c->sw_debug_k2_price;
     auto set_mat = [&](const DevCsr& m) { a.rowptr = m.rowptr; a.colidx = m.colidx; a.vals = m.vals; a.vals29 = m.vals29; a.m = m.n_out; };
     for (size_t i = 0; i + 1 < t; i++) {
       const uint64_t in_end = in_start + c->d_pre[i].n_in;
@@ -740,6 +740,7 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
   if (const char* ev = getenv("LCPC_NTT_TILE_GROUP")) c->sw_ntt_tile_group = (int32_t)strtoul(ev, nullptr, 10);
   c->sw_sdig_tail = !getenv("LCPC_SDIG_NO_TAIL");
   c->sw_debug_fail_mid = getenv("LCPC_DEBUG_FAIL_MID") != nullptr;
+  if (const char* ev = getenv("LCPC_DEBUG_K2_PRICE")) c->sw_debug_k2_price = (uint32_t)strtoul(ev, nullptr, 10);
   if (const char* ev = getenv("LCPC_SDIG_ROW_GROUP")) c->sw_sdig_row_group = std::min<uint32_t>(64, (uint32_t)strtoul(ev, nullptr, 10));
   if (const char* ev = getenv("LCPC_SHARD_SLICES")) c->shard_slices = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)strtoul(ev, nullptr, 10), LCPC_MAX_SHARD_SLICES));
   int rc = 0;

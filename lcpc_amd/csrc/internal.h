@@ -74,9 +74,10 @@ struct lcpc_ctx {
   int32_t sw_ntt_tile_group = -1;  // LCPC_NTT_TILE_GROUP: -1 = the default rule of ntt_tile_group_of
   bool sw_sdig_tail = true;        // LCPC_SDIG_NO_TAIL unset
   uint32_t sw_sdig_row_group = 0;  // LCPC_SDIG_ROW_GROUP: Brakedown Ft255 wide levels in row groups of <= this many rows (0 = off)
+  uint32_t sw_debug_k2_price = 0;  // LCPC_DEBUG_K2_PRICE (experiment, wrong results): price of a limb-form T in the wide SpMM levels
   bool sw_debug_fail_mid = false;  // LCPC_DEBUG_FAIL_MID (test hook): the K1s limb-intermediate allocation fails -> packed intermediate
-  uint32_t shard_slices = 4;       // native sharded commit: column slices whose exchange overlaps the next slice's hashing
-                                   // (LCPC_SHARD_SLICES at context creation; 1 = everything in sequence on one stream)
+  uint32_t shard_slices = 1;       // native sharded commit: column slices whose exchange overlaps the next slice's hashing
+                                   // (LCPC_SHARD_SLICES at context creation; 1, the default = everything in sequence on one stream)
   const lcpc::FieldDesc* f = nullptr;
   int L = 0, NL = 0;
   uint64_t n_per_row = 0, n_cols = 0, np2 = 0;
@@ -118,6 +119,9 @@ struct lcpc_ctx {
   // RCCL communicator of a sharded encoder (lcpc_comm_init); opaque ncclComm_t
   void* comm = nullptr;
   std::mutex xchg_mu;              // serialises the submission of collectives on `comm` (several commitments, several host threads)
+  hipEvent_t ev_xchg = nullptr;    // recorded behind the last collective enqueued on `comm`; the next one's stream waits for it: the
+                                   // collectives of one communicator run in submission order whatever streams they are enqueued on
+                                   // (two commitments' exchange streams, a prove stream) -- under xchg_mu
   std::atomic<int> refs{1};        // the handle itself + one per live lcpc_commit
   std::string err;
   std::mutex mu;

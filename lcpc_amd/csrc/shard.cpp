@@ -99,12 +99,20 @@ int fail_nccl(std::string* err, int rc, const char* what) {
   if (err) *err = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "nccl error") ;
   return LCPC_ERR_XCHG;
 }
+// collectives of one communicator in submission order, whatever streams carry them (call with xchg_mu held)
+hipError_t xchg_order_before(lcpc_ctx* c, hipStream_t s) {
+  if (!c->ev_xchg) return hipEventCreateWithFlags(&c->ev_xchg, hipEventDisableTiming);
+  return hipStreamWaitEvent(s, c->ev_xchg, 0);
+}
+hipError_t xchg_order_after(lcpc_ctx* c, hipStream_t s) { return hipEventRecord(c->ev_xchg, s); }
 // lcpc_allgather_fn on the encoder's communicator: enqueued on the commitment's prove stream, nothing waits on the host
 int rccl_allgather_cb(void* user, uint64_t bytes) {
   lcpc_commit_t* m = static_cast<lcpc_commit_t*>(user);
   std::lock_guard<std::mutex> xg(m->enc->xchg_mu);
+  if (xchg_order_before(m->enc, m->s_prove) != hipSuccess) { m->err = "hipStreamWaitEvent (exchange order)"; return 1; }
   int rc = rccl().AllGather(m->d_xsend, m->d_xrecv, (size_t)bytes, NCCL_UINT8, m->enc->comm, m->s_prove);
   if (rc != 0) { fail_nccl(&m->err, rc, "ncclAllGather"); return 1; }
+  if (xchg_order_after(m->enc, m->s_prove) != hipSuccess) { m->err = "hipEventRecord (exchange order)"; return 1; }
   return 0;
 }
 }  // namespace
@@ -112,6 +120,7 @@ int rccl_allgather_cb(void* user, uint64_t bytes) {
 void comm_release(lcpc_ctx* c) {
   if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
   c->comm = nullptr;
+  if (c->ev_xchg) { (void)hipEventDestroy(c->ev_xchg); c->ev_xchg = nullptr; }
 }
 
 // ---- sharded prove pieces ---------------------------------------------------------------------------------
@@ -527,12 +536,17 @@ static uint32_t shard_slices(const lcpc_ctx* c, uint64_t* bounds) {
   return n;
 }
 
-// One commit on a row shard with the exchange inside: encode on `stream`; then per slice of columns (shard_slices) the local
-// hash on `stream`, and on the commitment's exchange stream -- behind an event -- the collectives of that slice (node 0 of
-// every rank by ncclAllGather, the few second / third nodes by one ncclBroadcast each, grouped) and the leaf digests of that
-// slice.  The wire time of slice s overlaps the hashing of slice s + 1: only the last slice's exchange is exposed.  `stream`
-// then waits for the exchange stream and builds the Merkle tree.  One slice (LCPC_SHARD_SLICES=1) = everything in sequence on
-// `stream`.
+// One commit on a row shard with the exchange inside: encode and the local column hash on `stream`; the collectives (node 0 of
+// every rank by ncclAllGather, the few second / third nodes by one ncclBroadcast each, grouped), the leaf digests and the Merkle
+// tree follow
+//   * by default on `stream` itself, everything in sequence (one slice);
+//   * with LCPC_SHARD_SLICES=S > 1 per slice of columns on the commitment's exchange stream, behind an event, while `stream`
+//     hashes the next slice; `stream` then waits for the exchange stream and builds the tree.  Measured (profiles/
+//     r04_shard_slices*.jsonl): what this can hide is bounded by the hash time (<= 0.2 ms of a 1.5 ms rank step at 8 GPUs) and the
+//     extra launches and hand-overs cost about as much -- hence not the default;
+//   * with LCPC_COMMIT_ASYNC_TAIL in `flags` on the exchange stream WITHOUT `stream` waiting for them: `stream` is free again
+//     after the column hash, so the next commit (another lcpc_commit_t of the same encoder) encodes while this one's node
+//     values are on the wire.  The commitment is complete behind its event, which every reader and a refill wait for.
 int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint32_t flags, uint8_t* root) {
   if (!m || n_rows_total == 0) return LCPC_ERR_ARG;
   lcpc_ctx* c = m->enc;
@@ -558,14 +572,18 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
     if (r == me && n_nodes_of[r] > 1) my_slots = n_nodes_of[r];
   }
   const uint64_t tot_slots = (uint64_t)my_slots + G + extras;
-  int rc = ensure_dev(&m->err, &m->d_gather, &m->gather_cap, tot_slots * c->n_cols * 32);
+  // (the refill order of shard_encode_phase comes first: the buffer below may still be read by the previous fill's exchange)
+  int rc = order_after_commit(m, st);
   if (rc) return rc;
+  if (tot_slots * c->n_cols * 32 > m->gather_cap && m->ev_done) HIPCHK(m, hipEventSynchronize(m->ev_done));
+  if ((rc = ensure_dev(&m->err, &m->d_gather, &m->gather_cap, tot_slots * c->n_cols * 32))) return rc;
   uint64_t bounds[LCPC_MAX_SHARD_SLICES + 1];
   const uint32_t S = shard_slices(c, bounds);
+  const bool async_tail = (flags & LCPC_COMMIT_ASYNC_TAIL) != 0;
   if ((rc = shard_encode_phase(m, coeffs_local, n_rows_total, st, flags))) return rc;
   if ((rc = shard_node_table(m, 0, st))) return rc;           // (one-off per shape; no synchronisation inside the slice loop)
   hipStream_t sx = st;
-  if (S > 1) {
+  if (S > 1 || async_tail) {
     if (!m->s_xchg) HIPCHK(m, hipStreamCreateWithFlags(&m->s_xchg, hipStreamNonBlocking));
     for (uint32_t s = 0; s <= S; s++)
       if (!m->ev_slice[s]) HIPCHK(m, hipEventCreateWithFlags(&m->ev_slice[s], hipEventDisableTiming));
@@ -582,12 +600,12 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
       uint8_t* send = m->d_gather + tot_slots * c0 * 32;
       uint8_t* recv = send + slot_bytes * my_slots;
       if ((rc = shard_hash_cols(m, c0, c1, st, send))) return rc;
-      if (S > 1) {
+      if (sx != st) {
         HIPCHK(m, hipEventRecord(m->ev_slice[s], st));
         HIPCHK(m, hipStreamWaitEvent(sx, m->ev_slice[s], 0));
-      } else if (m->timing) {
-        HIPCHK(m, hipEventRecord(m->ev[2], st));
       }
+      if (m->timing && s + 1 == S) HIPCHK(m, hipEventRecord(m->ev[2], st));     // the last slice's hash is done here
+      HIPCHK(m, xchg_order_before(c, sx));
       int nrc = rccl().GroupStart();
       if (nrc == 0) nrc = rccl().AllGather(send, recv, (size_t)slot_bytes, NCCL_UINT8, c->comm, sx);
       uint32_t x = G;
@@ -599,16 +617,21 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
       const int erc = rccl().GroupEnd();
       if (nrc == 0) nrc = erc;
       if (nrc != 0) return fail_nccl(&m->err, nrc, "ncclAllGather / ncclBroadcast");
+      HIPCHK(m, xchg_order_after(c, sx));
       if ((rc = shard_finish_cols(m, recv, 0, c0, c1, sx))) return rc;
     }
   }
-  if (S > 1) {
-    if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], st));          // the last slice's hash is done here ...
-    HIPCHK(m, hipEventRecord(m->ev_slice[S], sx));
-    HIPCHK(m, hipStreamWaitEvent(st, m->ev_slice[S], 0));            // ... and here its exchange + leaf digests
+  hipStream_t tail = st;                     // the stream the tree is built on (and the commitment's event recorded on)
+  if (sx != st) {
+    if (async_tail) {
+      tail = sx;                             // `st` is not held up: it is free for the next commit's encode
+    } else {
+      HIPCHK(m, hipEventRecord(m->ev_slice[S], sx));
+      HIPCHK(m, hipStreamWaitEvent(st, m->ev_slice[S], 0));            // the last slice's exchange + leaf digests
+    }
   }
-  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[4], st));
-  if ((rc = shard_merkle_phase(m, st, root))) return rc;
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[4], tail));
+  if ((rc = shard_merkle_phase(m, tail, root))) return rc;
   if (m->timing) (void)hipEventElapsedTime(&m->last.exchange_exposed_ms, m->ev[2], m->ev[4]);
   return 0;
   LCPC_CATCH(m)

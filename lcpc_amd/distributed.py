@@ -200,13 +200,16 @@ class HipShardEngine:
             raise LcpcError(rc)
         self.enc._check(lib.lcpc_comm_init(self.enc._h, idb, rank, world))
 
-    def commit_native(self, local_coeffs, n_rows_total, want_root=True, borrow=False):
+    def commit_native(self, local_coeffs, n_rows_total, want_root=True, borrow=False, async_tail=False):
+        """lcpc_commit_sharded_device.  async_tail: LCPC_COMMIT_ASYNC_TAIL -- the exchange, the leaf digests and the tree run on the
+        commitment's own stream and the caller's stream is free again after the column hash (a second engine of the same encoder
+        can then encode the next commitment while this one's node values are on the wire)."""
         rb, re, _, _, _ = self.layout(n_rows_total)
         st = torch.cuda.current_stream().cuda_stream
         root = (C.c_uint8 * 32)() if want_root else None
         ptr = local_coeffs.data_ptr() if re > rb else None
         self.cm._check(_lib.lib().lcpc_commit_sharded_device(self.cm._h, C.c_void_p(ptr), n_rows_total, C.c_void_p(st),
-                                                             1 if borrow else 0, root))
+                                                             (1 if borrow else 0) | (2 if async_tail else 0), root))
         if want_root:
             self.cm._refresh()
         return bytes(root) if want_root else None

@@ -20,8 +20,8 @@ pytestmark = pytest.mark.gpu
     ("ligero", 3, 20, 64, 128, None),        # single chunk
     ("ligero", 0, 300, 128, 256, None),
     ("sdig", 3, 70, 300, 0, None),
-    ("ligero", 3, 512, 2048, 4096, None),    # the default: 4 column slices, the exchange of each on the commitment's second stream
-    ("ligero", 3, 512, 2048, 4096, "1"),     # LCPC_SHARD_SLICES=1: everything in sequence on the caller's stream
+    ("ligero", 3, 512, 2048, 4096, None),    # the default: everything in sequence on the caller's stream
+    ("ligero", 3, 512, 2048, 4096, "4"),     # LCPC_SHARD_SLICES=4: column slices, the exchange of each on the commitment's second stream
     ("ligero", 3, 20, 4096, 8192, "7"),      # single chunk (the slice's "node" is its digest), 7 slices
     ("ligero", 0, 300, 2048, 4096, "3"),
     ("sdig", 3, 70, 3000, 0, None),          # 4500-odd columns: slice ends at multiples of 256, position-major commitment
@@ -86,3 +86,48 @@ def test_comm_init_argument_checks():
     assert lib.lcpc_comm_init(enc._h, idb, 0, 4) == lcpc_amd.ERR_ARG      # rank != shard_rank
     assert lib.lcpc_comm_init(enc._h, idb, 1, 2) == lcpc_amd.ERR_ARG      # world != shard_count
     assert lib.lcpc_comm_init(enc._h, idb, 5, 4) == lcpc_amd.ERR_ARG
+
+
+@pytest.mark.parametrize("slices", [None, "3"])
+def test_native_exchange_async_tail_two_commitments(oracle, slices):
+    """LCPC_COMMIT_ASYNC_TAIL: exchange, leaf digests and tree on the commitment's own stream, the caller's stream free after the
+    column hash.  Two commitments of ONE sharded encoder are filled alternately, back to back, with different polynomials and no
+    host synchronisation in between (the second one's encode overlaps the first one's exchange; their collectives share the
+    communicator and must keep their order); then a refill of each (which has to wait for the object's own tail).  Roots, whole
+    `hashes`, coeffs and proof bytes of both equal the oracle's for the LAST polynomial committed into each."""
+    import os
+    O, fid, n_rows, n_per_row, n_cols = oracle, 3, 512, 2048, 4096
+    if slices is not None:
+        os.environ["LCPC_SHARD_SLICES"] = slices
+    try:
+        enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=(0, 1))
+    finally:
+        os.environ.pop("LCPC_SHARD_SLICES", None)
+    oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+    a, b = HipShardEngine(enc), HipShardEngine(enc)
+    a.comm_init()                                   # the communicator belongs to the encoder: both engines use it
+    polys = [O.random_elems(fid, n_rows * n_per_row, 700 + i) for i in range(4)]
+    devs = [torch.from_numpy(p.view(np.int64)).cuda() for p in polys]
+    ocs = [O.Commit.commit(p, oenc, n_threads=4) for p in polys]
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        for rep in range(3):
+            assert a.commit_native(devs[0], n_rows, want_root=False, async_tail=True) is None
+            assert b.commit_native(devs[1], n_rows, want_root=False, async_tail=True) is None
+            assert a.commit_native(devs[2], n_rows, want_root=False, async_tail=True) is None      # refill: behind a's own tail
+            assert b.commit_native(devs[3], n_rows, want_root=False, async_tail=True) is None
+        # readers need no synchronisation either: they wait for the commitment's event
+        assert a.cm.get_root() == ocs[2].get_root() and b.cm.get_root() == ocs[3].get_root()
+        assert b.commit_native(devs[1], n_rows, want_root=True, async_tail=True) == ocs[1].get_root()
+    st.synchronize()
+    a.cm._refresh(); b.cm._refresh()
+    assert (a.cm.hashes() == ocs[2].hashes()).all() and (b.cm.hashes() == ocs[1].hashes()).all()
+    assert (a.cm.coeffs() == ocs[2].coeffs()).all() and (b.cm.coeffs() == ocs[1].coeffs()).all()
+    outer = O.random_elems(fid, n_rows, 710)
+    n_open = enc.get_n_col_opens()
+    for eng, oc in ((a, ocs[2]), (b, ocs[1])):
+        root = oc.get_root()
+        opf, _ = oc.prove(outer, oenc, mk_transcript(O.Transcript, root, n_open))
+        data, _ = eng.prove_native(outer, mk_transcript(Transcript, root, n_open))
+        assert data == opf

@@ -17,23 +17,29 @@ import bench_configs as B
 from lcpc_amd import LcCommit, SdigEncoding
 
 n = 1 << 24
-groups = [int(x) for x in (sys.argv[1:] or ["0", "51", "34", "26", "21", "17"])]
+# an integer = a row-group size (0 = the default path); "p1" / "p2" = the pricing experiment LCPC_DEBUG_K2_PRICE=1 / 2 (timing
+# only: what a limb-form T would cost in the wide levels -- no packed -> 29-bit conversion of the gathered operand / that plus the
+# ninth limb's bytes; roots are wrong by construction and not compared)
+groups = [x if x.startswith("p") else int(x) for x in (sys.argv[1:] or ["0", "51", "34", "26", "21", "17"])]
 coeffs = B.rand_coeffs(n, 4, 1)
 st = torch.cuda.current_stream().cuda_stream
 var = {}
 for g in groups:
-    if g:
+    if isinstance(g, str):
+        os.environ["LCPC_DEBUG_K2_PRICE"] = g[1:]
+    elif g:
         os.environ["LCPC_SDIG_ROW_GROUP"] = str(g)
     try:
         enc = SdigEncoding.new(3, n, 0)
     finally:
         os.environ.pop("LCPC_SDIG_ROW_GROUP", None)
+        os.environ.pop("LCPC_DEBUG_K2_PRICE", None)
     c = LcCommit(enc)
     for _ in range(3):
         LcCommit.commit_device(coeffs.data_ptr(), n, enc, st, sync=False, borrow=True, into=c)
     torch.cuda.synchronize()
     var[g] = {"enc": enc, "c": c, "ms": [], "root": c.get_root()}
-assert len({v["root"] for v in var.values()}) == 1, "row-group variants disagree"
+assert len({v["root"] for g, v in var.items() if not isinstance(g, str)}) == 1, "row-group variants disagree"
 for rnd in range(8):
     for g in groups:
         v = var[g]
@@ -55,6 +61,10 @@ for g in groups:
         enc_ms.append(c.timings().encode_ms)
     c.set_timing(False)
     rows = c.n_rows
+    if isinstance(g, str):
+        print(json.dumps({"variant": "LCPC_DEBUG_K2_PRICE=" + g[1:], "commit_ms_mean": round(sum(v["ms"]) / len(v["ms"]), 3),
+                          "commit_ms_min": round(min(v["ms"]), 3), "encode_ms_min": round(min(enc_ms), 3)}), flush=True)
+        continue
     G = (rows + g - 1) // g if g else 1
     print(json.dumps({"row_group": g, "groups": G, "rows_per_group": (rows + G - 1) // G if g else rows,
                       "level0_gather_MB_per_group": round(166292 * ((rows + G - 1) // G if g else rows) * 32 / 1e6, 1),

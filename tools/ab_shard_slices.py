@@ -9,7 +9,8 @@
     the bytes the rank receives per slice are moved by a device-to-device copy (real HBM traffic next to the hashing
     kernels) and the stream is then held (torch.cuda._sleep, one idle wave) until bytes / B seconds have passed, for a few
     assumed in-bound rates B.  Reported: the step with the wire in sequence (one slice) and pipelined (four slices), and
-    the strong-scaling ceiling each gives against this run's unsharded step.  Nobody has measured RCCL's all-gather rate on
+    the same with the whole tail (wire, leaf digests, tree) on the side stream and two commitments filled alternately (async2:
+    what LCPC_COMMIT_ASYNC_TAIL does natively), and the strong-scaling ceiling each gives against this run's unsharded step.  Nobody has measured RCCL's all-gather rate on
     an 8-GPU MI355X node for this size from here; B is a parameter, not a claim.
 One JSON line per measurement (profiles/r04_shard_slices.jsonl)."""
 import json
@@ -51,7 +52,7 @@ def timeit(step, n=10, reps=5):
     return out
 
 
-# ---- A: native world-1, sliced vs unsliced, interleaved ----------------------------------------------------------------------
+# ---- A: native world-1: one slice (default) | 4 slices | async tail on two alternating commitments | plain commit, interleaved ----
 coeffs = rand_coeffs(n_rows)
 engs = {}
 for S in ("1", "4"):
@@ -61,25 +62,39 @@ for S in ("1", "4"):
     e = HipShardEngine(enc)
     e.comm_init()
     engs[S] = e
+pair = [engs["1"], HipShardEngine(engs["1"].enc)]          # two commitments of the one-slice encoder, filled alternately
 plain_enc = LigeroEncoding.new_from_dims(3, npr, nc)
 plain = LcCommit(plain_enc)
 st = torch.cuda.current_stream().cuda_stream
 roots = {S: e.commit_native(coeffs, n_rows) for S, e in engs.items()}
-assert roots["1"] == roots["4"] == LcCommit.commit_device(coeffs.data_ptr(), n_rows * npr, plain_enc, st, into=plain).get_root()
-res = {"1": [], "4": [], "plain": []}
+roots["async"] = pair[1].commit_native(coeffs, n_rows, async_tail=True)
+assert roots["1"] == roots["4"] == roots["async"] == LcCommit.commit_device(coeffs.data_ptr(), n_rows * npr, plain_enc, st, into=plain).get_root()
+res = {"1": [], "4": [], "async2": [], "plain": []}
+turn = [0]
+
+
+def async_step():
+    turn[0] ^= 1
+    pair[turn[0]].commit_native(coeffs, n_rows, want_root=False, async_tail=True)
+
+
 for rnd in range(6):
-    for S in ("1", "4", "plain"):
+    for S in ("1", "4", "async2", "plain"):
         if S == "plain":
             f = lambda: LcCommit.commit_device(coeffs.data_ptr(), n_rows * npr, plain_enc, st, sync=False, into=plain)
+        elif S == "async2":
+            f = async_step
         else:
             f = (lambda e: (lambda: e.commit_native(coeffs, n_rows, want_root=False)))(engs[S])
         res[S] += timeit(f, n=10, reps=2)
 mean = {k: sum(v) / len(v) for k, v in res.items()}
 base_ms = mean["plain"]
-print(json.dumps({"part": "A", "what": "native sharded commit, world 1, 2^%d Ft255: LCPC_SHARD_SLICES=1 vs 4 vs lcpc_commit_device, interleaved" % LOG,
+print(json.dumps({"part": "A", "what": "native sharded commit, world 1, 2^%d Ft255: one slice | 4 slices | async tail on two alternating "
+                  "commitments | lcpc_commit_device, interleaved" % LOG,
                   "ms_mean": {k: round(v, 3) for k, v in mean.items()}, "ms_min": {k: round(min(v), 3) for k, v in res.items()},
-                  "sliced_over_unsliced": round(mean["4"] / mean["1"], 4), "sliced_over_plain": round(mean["4"] / mean["plain"], 4)}), flush=True)
-del engs, plain, coeffs
+                  "sliced_over_unsliced": round(mean["4"] / mean["1"], 4), "unsliced_over_plain": round(mean["1"] / mean["plain"], 4),
+                  "async2_over_plain": round(mean["async2"] / mean["plain"], 4)}), flush=True)
+del engs, pair, plain, coeffs
 
 # ---- B: the last rank of world = 2, 4, 8 with a modelled wire -----------------------------------------------------------------------
 # _sleep calibration: cycles per millisecond of an idle spinning wave
@@ -137,14 +152,37 @@ for world in (2, 4, 8):
             main.wait_stream(side)
         eng.commit_merkle(want_root=False)
 
+    # the async tail: two commitments of the encoder filled alternately; wire + leaf digests + tree on the side stream, which the
+    # main stream does not wait for (a refill of the same commitment does, through the commitment's event)
+    eng2 = HipShardEngine(enc)
+    gathered2 = torch.zeros_like(gathered)
+    flip = [0]
+
+    def step_async(gbps):
+        flip[0] ^= 1
+        e, gbuf = (eng, gathered) if flip[0] else (eng2, gathered2)
+        e.commit_encode(coeffs, n_rows)
+        nodes = e.commit_hash_cols(0, nc)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            nbytes = n_in * nc * 32
+            gbuf.view(-1)[:nbytes].copy_(staging.view(-1)[:nbytes], non_blocking=True)
+            if gbps:
+                torch.cuda._sleep(int(nbytes / (gbps * 1e9) * 1e3 * CYC_PER_MS))
+            gbuf[rank * slots:rank * slots + nodes.shape[0]] = nodes
+            e.commit_finish_cols(gbuf, slots, 0, nc)
+            e.commit_merkle(want_root=False)
+        nodes.record_stream(side)
+
     row = {"part": "B", "world": world, "rank": rank, "rows": re - rb, "chunks": ce - cb, "in_MB_per_commit": round(n_in * nc * 32 / 1e6, 1),
            "unsharded_ms": round(base_ms, 3)}
     for gbps in (0, 300, 150, 75):
-        for S in (1, 4):
-            t = timeit(lambda: step(S, gbps), n=10, reps=3)
+        for S in (1, 4, "async2"):
+            f = (lambda: step_async(gbps)) if S == "async2" else (lambda: step(S, gbps))
+            t = timeit(f, n=10, reps=3)
             m = sum(t) / len(t)
-            key = ("copy_only" if gbps == 0 else "%dGBps" % gbps) + ("_seq" if S == 1 else "_sliced4")
+            key = ("copy_only" if gbps == 0 else "%dGBps" % gbps) + {1: "_seq", 4: "_sliced4", "async2": "_async2"}[S]
             row[key + "_ms"] = round(m, 3)
             row[key + "_ceiling"] = round(base_ms / m, 2)
     print(json.dumps(row), flush=True)
-    del enc, eng, coeffs, gathered, staging
+    del enc, eng, eng2, coeffs, gathered, gathered2, staging
