@@ -1,4 +1,4 @@
-//! Raw declarations of `include/lcpc_hip.h` (ABI version 3): the C ABI of the MI355X-native lcpc-2d commit / prove path.
+//! Raw declarations of `include/lcpc_hip.h` (ABI version 4): the C ABI of the MI355X-native lcpc-2d commit / prove path.
 //!
 //! One item per item of the header, same names, same order of arguments; `tests/test_rust_bindings.py` of the repository
 //! compares this file with the header (symbols, argument types, struct fields, constants) on every run of the CPU test suite,
@@ -11,7 +11,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const LCPC_ABI_VERSION: c_int = 3;
+pub const LCPC_ABI_VERSION: c_int = 4;
 
 // fields of lcpc-test-fields/src/lib.rs:13-59
 pub const LCPC_FT63: u32 = 0;
@@ -50,6 +50,7 @@ pub const LCPC_VERR_ENCODE: c_int = -39;
 pub const LCPC_VERR_MALFORMED: c_int = -40;
 
 pub const LCPC_COMMIT_BORROW_COEFFS: u32 = 1;
+pub const LCPC_COMMIT_ASYNC_TAIL: u32 = 2;
 
 /// an LcEncoding implementor (`enc`): opaque
 #[repr(C)]
@@ -218,6 +219,15 @@ extern "C" {
         n_chunks_total: *mut u64,
     ) -> c_int;
     pub fn lcpc_shard_nodes(
+        n_chunks_total: u64,
+        shard_count: u32,
+        shard_rank: u32,
+        n_nodes: *mut u32,
+        first_chunk: *mut u64,
+        log_size: *mut u32,
+    ) -> c_int;
+    pub fn lcpc_shard_nodes_field(
+        field: u32,
         n_chunks_total: u64,
         shard_count: u32,
         shard_rank: u32,

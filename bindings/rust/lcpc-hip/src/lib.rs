@@ -628,17 +628,20 @@ where
     /// rows (`shard_layout` says which) at `coeffs_local_dev`.  Collective; the encoder needs `comm_init` first.
     ///
     /// # Safety
-    /// as [`HipCommit::recommit_device`]
+    /// as [`HipCommit::recommit_device`].  `async_tail` (`LCPC_COMMIT_ASYNC_TAIL`): exchange, leaf digests and tree run on the
+    /// commitment's own stream and `stream` is free after the local column hash -- fill a second `HipCommit` of the same encoder
+    /// next and its encode overlaps this one's wire time.
     pub unsafe fn recommit_sharded_device(
         &self,
         coeffs_local_dev: *const u64,
         n_rows_total: usize,
         stream: *mut c_void,
         borrow: bool,
+        async_tail: bool,
         want_root: bool,
     ) -> Result<Option<Output<Blake3>>, ProverError<HipError>> {
         let mut root = [0u8; 32];
-        let flags = if borrow { sys::LCPC_COMMIT_BORROW_COEFFS } else { 0 };
+        let flags = (if borrow { sys::LCPC_COMMIT_BORROW_COEFFS } else { 0 }) | (if async_tail { sys::LCPC_COMMIT_ASYNC_TAIL } else { 0 });
         let rp = if want_root { root.as_mut_ptr() } else { std::ptr::null_mut() };
         match sys::lcpc_commit_sharded_device(self.cm, coeffs_local_dev, n_rows_total as u64, stream, flags, rp) {
             0 => Ok(if want_root { Some(Output::<Blake3>::clone_from_slice(&root)) } else { None }),

@@ -31,10 +31,11 @@
 extern "C" {
 #endif
 
-/* 3: the column-range phases of the sharded commit (lcpc_commit_shard_encode_device, lcpc_commit_shard_hash_device,
+/* 4: lcpc_shard_nodes_field (row sharding for Ft191, whose elements straddle BLAKE3 chunks), LCPC_COMMIT_ASYNC_TAIL.
+ * 3: the column-range phases of the sharded commit (lcpc_commit_shard_encode_device, lcpc_commit_shard_hash_device,
  * lcpc_commit_finish_cols_device, lcpc_commit_finish_merkle_device), lcpc_timings.exchange_exposed_ms; the LcCommit bincode
- * entry points of round 3 are part of 3 as well.  A caller checks lcpc_abi_version() == LCPC_ABI_VERSION before anything else. */
-#define LCPC_ABI_VERSION 3
+ * entry points of round 3.  A caller checks lcpc_abi_version() == LCPC_ABI_VERSION before anything else. */
+#define LCPC_ABI_VERSION 4
 
 /* fields of lcpc-test-fields/src/lib.rs:13-59 */
 enum { LCPC_FT63 = 0, LCPC_FT127 = 1, LCPC_FT191 = 2, LCPC_FT255 = 3 };
@@ -229,9 +230,14 @@ int  lcpc_shard_layout(const lcpc_ctx *ctx, uint64_t n_rows_total, uint64_t *row
                        uint64_t *chunk_begin, uint64_t *chunk_end, uint64_t *n_chunks_total);
 /* The chunks of a shard are pre-merged on the GPU into aligned BLAKE3 subtree nodes (a node = 2^log_size
  * consecutive chunks starting at a multiple of its size), which is what crosses the wire.  Pure function of
- * (n_chunks_total, shard_count, shard_rank): node k of that shard starts at chunk first_chunk[k]. */
+ * (field, n_chunks_total, shard_count, shard_rank): node k of that shard starts at chunk first_chunk[k].  A shard begins where
+ * a chunk boundary of the leaf message is also a row boundary: for Ft63 / Ft127 / Ft255 (element size divides 1024) that is
+ * every chunk and shard g owns chunks [n g / G, n (g + 1) / G); for Ft191 (24-byte elements) it is every third chunk
+ * (rows = 84 mod 128) and the even split is moved down to the nearest one.  lcpc_shard_nodes is the first case. */
 int  lcpc_shard_nodes(uint64_t n_chunks_total, uint32_t shard_count, uint32_t shard_rank, uint32_t *n_nodes,
                       uint64_t *first_chunk /* [64] */, uint32_t *log_size /* [64] */);
+int  lcpc_shard_nodes_field(uint32_t field, uint64_t n_chunks_total, uint32_t shard_count, uint32_t shard_rank, uint32_t *n_nodes,
+                            uint64_t *first_chunk /* [64] */, uint32_t *log_size /* [64] */);
 /* (a) native exchange.  One rank calls lcpc_comm_unique_id (ncclGetUniqueId) and distributes the 128 bytes by any
  * means; every rank then calls lcpc_comm_init on its sharded encoder (ncclCommInitRank on the encoder's device;
  * rank / world must equal shard_rank / shard_count; world == 1 is allowed and still goes through RCCL).

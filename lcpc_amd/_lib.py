@@ -6,7 +6,7 @@ import ctypes as C
 import os
 import subprocess
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblcpc_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
@@ -72,6 +72,7 @@ SYMBOLS = {
     "lcpc_free": (None, [_vp]),
     "lcpc_shard_layout": (_i32, [_vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     "lcpc_shard_nodes": (_i32, [_u64, _u32, _u32, _vp, _vp, _vp]),
+    "lcpc_shard_nodes_field": (_i32, [_u32, _u64, _u32, _u32, _vp, _vp, _vp]),
     "lcpc_comm_unique_id": (_i32, [_vp]),
     "lcpc_comm_init": (_i32, [_vp, _vp, _u32, _u32]),
     "lcpc_comm_destroy": (_i32, [_vp]),

@@ -744,8 +744,9 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
   if (const char* ev = getenv("LCPC_SDIG_ROW_GROUP")) c->sw_sdig_row_group = std::min<uint32_t>(64, (uint32_t)strtoul(ev, nullptr, 10));
   if (const char* ev = getenv("LCPC_SHARD_SLICES")) c->shard_slices = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)strtoul(ev, nullptr, 10), LCPC_MAX_SHARD_SLICES));
   int rc = 0;
-  // row sharding needs rows that do not straddle BLAKE3 chunks (F | 1024)
-  if (c->prm.shard_count > 1 && (c->prm.shard_rank >= c->prm.shard_count || 1024 % (8 * f->L) != 0)) rc = LCPC_ERR_ARG;
+  // (row shards begin where a BLAKE3 chunk boundary of the leaf message is also a row boundary: every chunk for Ft63 / Ft127 /
+  // Ft255, every third chunk for Ft191 -- shard.cpp shard_chunk_range)
+  if (c->prm.shard_count > 1 && c->prm.shard_rank >= c->prm.shard_count) rc = LCPC_ERR_ARG;
   if (!rc) rc = ctx_build(c, p);
   if (rc) { ctx_unref(c); return rc; }
   c->np2 = next_pow2(c->n_cols);

@@ -277,6 +277,7 @@ int open_columns_device(lcpc_commit_t* m, const uint64_t* d_cols, uint32_t n, ui
 // ---- shard.cpp --------------------------------------------------------------------------------------
 void shard_layout_of(const lcpc_ctx* c, uint64_t g, uint64_t n_rows, uint64_t* rb, uint64_t* re, uint64_t* cb, uint64_t* ce, uint64_t* nch);
 int shard_nodes(uint64_t c0, uint64_t c1, uint64_t* first, uint32_t* lg);
+void shard_chunk_range(uint64_t F, uint64_t n_chunks, uint64_t G, uint64_t g, uint64_t* c0, uint64_t* c1);
 void comm_release(lcpc_ctx* c);
 // the exchange of a row-sharded prove: every rank contributes `bytes` from send_dev, receives all ranks'
 // blocks in rank order in recv_dev

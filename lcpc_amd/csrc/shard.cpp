@@ -13,16 +13,33 @@ using namespace lcpc;
 
 namespace lcpc {
 
+// Chunk range of shard g of G for elements of F bytes: the leaf message 0^32 || repr(col[0]) || ... (lib.rs:719-735) is cut where
+// a 1 KiB BLAKE3 chunk boundary is also a row boundary, (1024 c - 32) mod F == 0.  For F | 1024 (Ft63 / Ft127 / Ft255) that is
+// every chunk and the split is the even one, n_chunks g / G; for Ft191 (F = 24) it is every third chunk -- c = 2 (mod 3), i.e.
+// rows = 84 (mod 128): 128 rows are exactly three chunks -- and the even split is moved down to the nearest such boundary.
+void shard_chunk_range(uint64_t F, uint64_t n_chunks, uint64_t G, uint64_t g, uint64_t* c0, uint64_t* c1) {
+  auto bound = [&](uint64_t i) -> uint64_t {
+    if (i == 0) return 0;
+    if (i >= G) return n_chunks;
+    uint64_t c = n_chunks * i / G;
+    while (c > 0 && (c * 1024 - 32) % F != 0) c--;
+    return c;
+  };
+  if (G <= 1) { *c0 = 0; *c1 = n_chunks; return; }
+  *c0 = bound(g); *c1 = bound(g + 1);
+}
+
 // rows / chunks of shard `g` (DESIGN.md "multi-GPU"): chunk-aligned row blocks
 void shard_layout_of(const lcpc_ctx* c, uint64_t g, uint64_t n_rows, uint64_t* rb, uint64_t* re, uint64_t* cb, uint64_t* ce, uint64_t* nch) {
   const uint64_t n_chunks = leaf_chunks(c, n_rows);
   const uint64_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
   if (G == 1) g = 0;
-  const uint64_t c0 = n_chunks * g / G, c1 = n_chunks * (g + 1) / G;
   const uint64_t F = elem_bytes(c);
-  auto first_row = [&](uint64_t chunk) -> uint64_t {   // first row whose bytes start in or after this chunk
+  uint64_t c0, c1;
+  shard_chunk_range(F, n_chunks, G, g, &c0, &c1);
+  auto first_row = [&](uint64_t chunk) -> uint64_t {   // the row whose bytes start this chunk (shard_chunk_range: exact)
     if (chunk == 0) return 0;
-    const uint64_t byte = chunk * 1024 - 32;             // F | 1024 is enforced for sharded contexts
+    const uint64_t byte = chunk * 1024 - 32;
     uint64_t r = byte / F;
     return r < n_rows ? r : n_rows;
   };
@@ -310,10 +327,14 @@ static int shard_hash_cols(lcpc_commit_t* m, uint64_t c0, uint64_t c1, hipStream
   la.out = cvs;
   HIPCHK(m, launch_leaf_chunks(c->NL, la, st));
   m->launches[1]++;
+  // a rank that owns the WHOLE message as one node (a power-of-two number of chunks and nobody else has any: world = 1, or an
+  // Ft191 commitment too short for a cut) produces the digest itself -- the parent of the last merge is the tree's root and
+  // takes the ROOT flag here; the finish step then only copies it, as for a single-chunk message
+  const bool whole = n_nodes == 1 && cb == 0 && ce == m->n_chunks;
   for (int k = 0; k < n_nodes; k++) {   // one subtree CV per aligned block of chunks
     uint32_t* blk = cvs + (first[k] - cb) * w * 8;
     uint32_t* out = reinterpret_cast<uint32_t*>(nodes_dev) + (size_t)k * w * 8;
-    HIPCHK(m, launch_leaf_finish_nodes(blk, nullptr, nullptr, 1u << lg[k], w, out, false, st));
+    HIPCHK(m, launch_leaf_finish_nodes(blk, nullptr, nullptr, 1u << lg[k], w, out, whole, st));
     m->launches[1]++;
   }
   return 0;
@@ -333,7 +354,9 @@ static int shard_node_table(lcpc_commit_t* m, uint32_t slots_per_rank, hipStream
   for (uint32_t r = 0; r < G; r++) {
     uint64_t first[64];
     uint32_t lg[64];
-    const int n = shard_nodes(nch * r / G, nch * (r + 1) / G, first, lg);
+    uint64_t c0, c1;
+    shard_chunk_range(elem_bytes(c), nch, G, r, &c0, &c1);
+    const int n = shard_nodes(c0, c1, first, lg);
     if (slots_per_rank && (uint32_t)n > slots_per_rank) return LCPC_ERR_ARG;
     for (int k = 0; k < n; k++) {
       m->node_slot_h.push_back(slots_per_rank ? r * slots_per_rank + (uint32_t)k : (k == 0 ? r : extra++));
@@ -360,7 +383,8 @@ static int shard_finish_cols(lcpc_commit_t* m, uint8_t* gathered, uint32_t slots
   if (rc) return rc;
   const uint32_t n_nodes = (uint32_t)m->node_slot_h.size();
   uint32_t* out = m->d_hashes + c0 * 8;
-  if (m->n_chunks == 1) {   // single-chunk message: the one "node" already carries ROOT (leaf_chunk_kernel)
+  if (m->n_chunks == 1 || n_nodes == 1) {   // single-chunk message, or the whole message as one rank's one node (shard_hash_cols):
+                                            // that "node" already carries ROOT
     HIPCHK(m, hipMemcpyAsync(out, gathered + (size_t)m->node_slot_h[0] * w * 32, (size_t)w * 32, hipMemcpyDeviceToDevice, st));
   } else {
     HIPCHK(m, launch_leaf_finish_nodes(reinterpret_cast<uint32_t*>(gathered), m->d_node_tab, m->d_node_tab + n_nodes, n_nodes, w, out, true, st));
@@ -407,12 +431,18 @@ int lcpc_shard_layout(const lcpc_ctx* c, uint64_t n_rows_total, uint64_t* rb, ui
   return 0;
 }
 
-int lcpc_shard_nodes(uint64_t n_chunks, uint32_t G, uint32_t g, uint32_t* n_nodes, uint64_t* first, uint32_t* lg) {
-  if (!n_nodes || !first || !lg || n_chunks == 0) return LCPC_ERR_ARG;
+int lcpc_shard_nodes_field(uint32_t field, uint64_t n_chunks, uint32_t G, uint32_t g, uint32_t* n_nodes, uint64_t* first, uint32_t* lg) {
+  const FieldDesc* f = field_desc((int)field);
+  if (!f || !n_nodes || !first || !lg || n_chunks == 0) return LCPC_ERR_ARG;
   if (G <= 1) { G = 1; g = 0; }
   if (g >= G) return LCPC_ERR_ARG;
-  *n_nodes = (uint32_t)shard_nodes(n_chunks * g / G, n_chunks * (g + 1) / G, first, lg);
+  uint64_t c0, c1;
+  shard_chunk_range((uint64_t)8 * f->L, n_chunks, G, g, &c0, &c1);
+  *n_nodes = (uint32_t)shard_nodes(c0, c1, first, lg);
   return 0;
+}
+int lcpc_shard_nodes(uint64_t n_chunks, uint32_t G, uint32_t g, uint32_t* n_nodes, uint64_t* first, uint32_t* lg) {
+  return lcpc_shard_nodes_field(LCPC_FT255, n_chunks, G, g, n_nodes, first, lg);    // (any field whose elements divide 1024)
 }
 
 // ---- split phases (a caller-side collective) ----------------------------------------------------------------
@@ -567,7 +597,9 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
   for (uint32_t r = 0; r < G; r++) {
     uint64_t first[64];
     uint32_t lg[64];
-    n_nodes_of[r] = (uint32_t)shard_nodes(nch * r / G, nch * (r + 1) / G, first, lg);
+    uint64_t c0, c1;
+    shard_chunk_range(elem_bytes(c), nch, G, r, &c0, &c1);
+    n_nodes_of[r] = (uint32_t)shard_nodes(c0, c1, first, lg);
     if (n_nodes_of[r] > 1) extras += n_nodes_of[r] - 1;
     if (r == me && n_nodes_of[r] > 1) my_slots = n_nodes_of[r];
   }

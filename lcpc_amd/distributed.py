@@ -33,9 +33,22 @@ import torch.distributed as dist
 from . import _lib
 
 
-def chunk_split(n_chunks, world):
-    """chunks [c_g, c_{g+1}) owned by rank g -- must match shard_layout_of() in csrc/shard.cpp."""
-    return [(n_chunks * g // world, n_chunks * (g + 1) // world) for g in range(world)]
+def chunk_split(n_chunks, world, elem_bytes=32):
+    """chunks [c_g, c_{g+1}) owned by rank g -- must match shard_chunk_range() in csrc/shard.cpp.  A shard begins where a chunk
+    boundary of the leaf message is also a row boundary, (1024 c - 32) % elem_bytes == 0: every chunk when the element size divides
+    1024 (the even split n g / world), every third chunk for Ft191's 24 bytes (the even split moved down to the nearest one)."""
+    def bound(i):
+        if i == 0:
+            return 0
+        if i >= world:
+            return n_chunks
+        c = n_chunks * i // world
+        while c > 0 and (c * 1024 - 32) % elem_bytes:
+            c -= 1
+        return c
+    if world <= 1:
+        return [(0, n_chunks)]
+    return [(bound(g), bound(g + 1)) for g in range(world)]
 
 
 def aligned_nodes(c0, c1):
@@ -51,8 +64,8 @@ def aligned_nodes(c0, c1):
     return out
 
 
-def slots_per_rank(n_chunks, world):
-    return max(1, max(len(aligned_nodes(b, e)) for b, e in chunk_split(n_chunks, world)))
+def slots_per_rank(n_chunks, world, elem_bytes=32):
+    return max(1, max(len(aligned_nodes(b, e)) for b, e in chunk_split(n_chunks, world, elem_bytes)))
 
 
 _xchg_cache = {}
@@ -72,12 +85,12 @@ def slice_bounds(n_cols, slices):
     return b
 
 
-def exchange_nodes(local_nodes, n_chunks_total, group=None):
+def exchange_nodes(local_nodes, n_chunks_total, group=None, elem_bytes=32):
     """all-gather of per-rank [k_g, n_cols, 32] uint8 node CVs, padded to `slots` per rank; returns the raw
     gather buffer [world * slots, n_cols, 32] (rank g's nodes at rows g*slots ...) and `slots`.  The pad / gather
     buffers are allocated once per shape and reused (the finish phase clobbers the gather buffer, nothing keeps it)."""
     world = dist.get_world_size(group)
-    slots = slots_per_rank(n_chunks_total, world)
+    slots = slots_per_rank(n_chunks_total, world, elem_bytes)
     n_cols = local_nodes.shape[1]
     key = (world, slots, n_cols, str(local_nodes.device), dist.get_backend(group))
     bufs = _xchg_cache.get(key)
@@ -114,6 +127,7 @@ class HipShardEngine:
         self.cm = LcCommit(enc)
         self.rank, self.world = enc.params.shard_rank, max(1, enc.params.shard_count)
         self.n_cols = enc.n_cols
+        self.elem_bytes = 8 * enc.L
         self._layout = {}
         self._nodes = None
 
@@ -284,6 +298,7 @@ def sharded_commit(engine, local_coeffs, n_rows_total, group=None, want_root=Tru
     slices > 1: the four-step form -- encode, then per slice of columns hash / all-gather / leaf digests, then the tree (with a
     stream-ordered collective the all-gather of slice s runs while slice s + 1 is hashed; over gloo it is simply sequential)."""
     _, _, _, _, n_chunks = engine.layout(n_rows_total)
+    eb = getattr(engine, "elem_bytes", 32)
     if not isinstance(slices, int) or slices > 1:
         engine.commit_encode(local_coeffs, n_rows_total, borrow) if borrow else engine.commit_encode(local_coeffs, n_rows_total)
         b = slice_bounds(engine.n_cols, slices) if isinstance(slices, int) else list(slices)      # (or explicit boundaries)
@@ -291,14 +306,14 @@ def sharded_commit(engine, local_coeffs, n_rows_total, group=None, want_root=Tru
         for c0, c1 in zip(b[:-1], b[1:]):
             nodes = engine.commit_hash_cols(c0, c1)
             if multi:
-                gathered, slots = exchange_nodes(nodes, n_chunks, group)
+                gathered, slots = exchange_nodes(nodes, n_chunks, group, eb)
             else:
                 gathered, slots = nodes.contiguous(), max(1, nodes.shape[0])
             engine.commit_finish_cols(gathered, slots, c0, c1)
         return engine.commit_merkle(want_root)
     nodes = engine.commit_shard(local_coeffs, n_rows_total, borrow) if borrow else engine.commit_shard(local_coeffs, n_rows_total)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        gathered, slots = exchange_nodes(nodes, n_chunks, group)
+        gathered, slots = exchange_nodes(nodes, n_chunks, group, eb)
     else:
         gathered, slots = nodes.contiguous(), max(1, nodes.shape[0])
     return engine.commit_finish(gathered, n_rows_total, slots, want_root)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "missing export: " + s
     assert sorted(_lib.SYMBOLS) == syms, "ctypes table and header disagree"
-    assert L.lcpc_abi_version() == _lib.ABI_VERSION == 3
+    assert L.lcpc_abi_version() == _lib.ABI_VERSION == 4
     hdr = open(os.path.join(ROOT, "include", "lcpc_hip.h")).read()
     assert int(re.search(r"#define LCPC_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
 
@@ -219,3 +219,18 @@ def test_shard_node_layout_matches_python():
                 lg = (C.c_uint32 * 64)()
                 assert L.lcpc_shard_nodes(n_chunks, world, rank, C.byref(n), first, lg) == 0
                 assert [(first[i], lg[i]) for i in range(n.value)] == aligned_nodes(b, e)
+            # the field-aware form: the same for element sizes that divide 1024; for Ft191 (24 bytes) the cuts move down to the
+            # chunks that start on a row boundary (chunk = 2 mod 3)
+            for field, eb in ((0, 8), (1, 16), (2, 24), (3, 32)):
+                sp = chunk_split(n_chunks, world, eb)
+                assert sp[0][0] == 0 and sp[-1][1] == n_chunks and all(sp[i][1] == sp[i + 1][0] for i in range(len(sp) - 1))
+                if eb != 24:
+                    assert sp == chunk_split(n_chunks, world)
+                for rank, (b, e) in enumerate(sp):
+                    if eb == 24 and 0 < b < n_chunks:
+                        assert b % 3 == 2
+                    n = C.c_uint32()
+                    first = (C.c_uint64 * 64)()
+                    lg = (C.c_uint32 * 64)()
+                    assert L.lcpc_shard_nodes_field(field, n_chunks, world, rank, C.byref(n), first, lg) == 0
+                    assert [(first[i], lg[i]) for i in range(n.value)] == aligned_nodes(b, e)

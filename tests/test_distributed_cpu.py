@@ -25,12 +25,13 @@ class OracleShardEngine:
         self.fid, self.L = fid, O.limbs(fid)
         self.enc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
         self.n_per_row, self.n_cols, self.rank, self.world = n_per_row, n_cols, rank, world
+        self.elem_bytes = 8 * self.L
         self.hashes = None
 
     def layout(self, n_rows):
         F = 8 * self.L
         n_chunks = (32 + F * n_rows + 1023) // 1024
-        cb, ce = chunk_split(n_chunks, self.world)[self.rank]
+        cb, ce = chunk_split(n_chunks, self.world, F)[self.rank]
 
         def first_row(ch):
             return 0 if ch == 0 else min(n_rows, (ch * 1024 - 32) // F)
@@ -66,12 +67,15 @@ class OracleShardEngine:
         cvs = self._cvs
         # pre-merge the chunk CVs into aligned subtree nodes (BLAKE3 parent rule, no ROOT), as the HIP engine does
         nodes = []
-        for first, lg in aligned_nodes(cb, ce):
+        _, _, _, _, n_chunks = self.layout(self._n_rows)
+        an = aligned_nodes(cb, ce)
+        whole = len(an) == 1 and cb == 0 and ce == n_chunks      # this rank's one node is the whole message: its last parent is the root
+        for first, lg in an:
             out = np.zeros((c1 - c0, 32), np.uint8)
             for col in range(c0, c1):
                 cur = [struct.unpack("<8I", cvs[first - cb + i, col].tobytes()) for i in range(1 << lg)]
                 while len(cur) > 1:
-                    cur = [P.b3_parent(cur[2 * i], cur[2 * i + 1], False) for i in range(len(cur) // 2)]
+                    cur = [P.b3_parent(cur[2 * i], cur[2 * i + 1], whole and len(cur) == 2) for i in range(len(cur) // 2)]
                 out[col - c0] = np.frombuffer(struct.pack("<8I", *cur[0]), np.uint8)
             nodes.append(out)
         arr = np.stack(nodes) if nodes else np.zeros((0, c1 - c0, 32), np.uint8)
@@ -82,11 +86,11 @@ class OracleShardEngine:
         _, _, _, _, n_chunks = self.layout(self._n_rows)
         g = gathered.numpy()
         order = []
-        for r, (b, e) in enumerate(chunk_split(n_chunks, self.world)):
+        for r, (b, e) in enumerate(chunk_split(n_chunks, self.world, self.elem_bytes)):
             for k, (first, lg) in enumerate(aligned_nodes(b, e)):
                 order.append((r * slots + k, lg))
         for col in range(c0, c1):
-            if n_chunks == 1:
+            if n_chunks == 1 or len(order) == 1:
                 self.hashes[col] = g[order[0][0], col - c0]
                 continue
             stack, total = [], 0
@@ -143,6 +147,9 @@ def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q, slices=1):
     (2, 3, 70, 32, 64),      # ft255: 3 chunks over 2 ranks (uneven), rows 0..62 | 63..69
     (2, 0, 300, 16, 32),     # ft63: 128 rows per chunk
     (3, 3, 40, 16, 32),      # 2 chunks over 3 ranks: one rank owns nothing
+    (2, 2, 300, 16, 32),     # ft191: 24-byte elements straddle chunks; 8 chunks, the cut moves from chunk 4 down to chunk 2 (row 84)
+    (3, 2, 500, 16, 32),     # ft191: 12 chunks over 3 ranks: cuts at chunks 2 and 8
+    (2, 2, 57, 16, 32),      # ft191: 2 chunks and no possible cut: rank 1 owns the whole message as ONE node, which must carry ROOT
 ])
 @pytest.mark.parametrize("slices", [1, [0, 24, 40, 64]])
 def test_sharded_commit_gloo(world, fid, n_rows, n_per_row, n_cols, slices):

@@ -24,6 +24,9 @@ pytestmark = pytest.mark.gpu
     ("ligero", 3, 512, 2048, 4096, "4"),     # LCPC_SHARD_SLICES=4: column slices, the exchange of each on the commitment's second stream
     ("ligero", 3, 20, 4096, 8192, "7"),      # single chunk (the slice's "node" is its digest), 7 slices
     ("ligero", 0, 300, 2048, 4096, "3"),
+    ("ligero", 2, 700, 128, 256, None),      # ft191 (24-byte elements straddle chunks; world 1: one shard)
+    ("ligero", 3, 40, 64, 128, None),        # 2 chunks, world 1: the rank's one node IS the whole message and must carry ROOT
+    ("ligero", 3, 100, 2048, 4096, "3"),     # 4 chunks, world 1, sliced
     ("sdig", 3, 70, 3000, 0, None),          # 4500-odd columns: slice ends at multiples of 256, position-major commitment
     ("sdig", 3, 70, 3000, 0, "16"),          # asks for more slices than 1024-column slices fit: clamped
 ])

@@ -21,12 +21,13 @@ def run_sharded(mk_enc, G, coeffs_rows, n_rows, slices=None):
         for eng in engines:
             rb, re, cb, ce, nch = eng.layout(n_rows)
             eng.commit_encode(coeffs_rows[rb:re].contiguous(), n_rows)
-        slots = slots_per_rank(nch, G)
+        eb = engines[0].elem_bytes
+        slots = slots_per_rank(nch, G, eb)
         for c0, c1 in slices:
             nodes = [eng.commit_hash_cols(c0, c1) for eng in engines]
             gathered = torch.zeros((G * slots, c1 - c0, 32), dtype=torch.uint8, device="cuda")
             for g, nd in enumerate(nodes):
-                assert nd.shape[0] == len(aligned_nodes(*chunk_split(nch, G)[g]))
+                assert nd.shape[0] == len(aligned_nodes(*chunk_split(nch, G, eb)[g]))
                 gathered[g * slots:g * slots + nd.shape[0]] = nd
             for eng in engines:
                 eng.commit_finish_cols(gathered.clone(), slots, c0, c1)
@@ -36,10 +37,10 @@ def run_sharded(mk_enc, G, coeffs_rows, n_rows, slices=None):
         rb, re, cb, ce, nch = eng.layout(n_rows)
         local = coeffs_rows[rb:re].contiguous()
         nodes.append(eng.commit_shard(local, n_rows))
-        assert (cb, ce) == chunk_split(nch, G)[g]
+        assert (cb, ce) == chunk_split(nch, G, eng.elem_bytes)[g]
         assert nodes[-1].shape[0] == len(aligned_nodes(cb, ce))
     # emulate the all-gather: equal-sized padded blocks, rank g at rows [g*slots, (g+1)*slots)
-    slots = slots_per_rank(nch, G)
+    slots = slots_per_rank(nch, G, engines[0].elem_bytes)
     gathered = torch.zeros((G * slots, nodes[0].shape[1], 32), dtype=torch.uint8, device="cuda")
     for g, nd in enumerate(nodes):
         gathered[g * slots:g * slots + nd.shape[0]] = nd
@@ -58,6 +59,17 @@ def run_sharded(mk_enc, G, coeffs_rows, n_rows, slices=None):
     (0, 260, 4096, 8192, 3),    # ft63 on K1n (canonical comm)
     (1, 130, 2048, 4096, 2),    # ft127 on K1n
     (3, 20, 64, 128, 2),        # single chunk: the "CV" is already the digest
+    # ft191: 24-byte elements straddle the 1 KiB chunks; shards begin where a chunk boundary is a row boundary (rows = 84 mod 128,
+    # every third chunk): 700 rows = 17 chunks, cuts possible at chunks 2, 5, 8, 11, 14
+    (2, 700, 64, 128, 2),
+    (2, 700, 64, 128, 3),
+    (2, 700, 64, 128, 8),       # more ranks than cuts: some ranks own nothing
+    (2, 1500, 2048, 4096, 4),   # K1n rows (canonical comm), 36 chunks
+    (2, 90, 64, 128, 2),        # 3 chunks: the only cut is chunk 2 = row 84
+    (2, 40, 64, 128, 2),        # single chunk
+    (2, 57, 64, 128, 4),        # 2 chunks, no cut possible: the last rank owns the whole message as one node (ROOT in the pre-merge)
+    (2, 170, 64, 128, 1),       # "sharded" over one rank, 4 chunks = one node
+    (3, 40, 64, 128, 1),        # the same for ft255 (2 chunks)
 ])
 @pytest.mark.parametrize("sliced", [False, True])
 def test_sharded_equals_unsharded(oracle, fid, n_rows, n_per_row, n_cols, G, sliced):
@@ -111,14 +123,26 @@ def test_compact_exchange_layout(oracle, fid, n_rows, n_per_row, n_cols, G):
         assert (eng.cm.hashes() == oc.hashes()).all()
 
 
-def test_sharding_rejects_straddling_field():
-    # ft191 rows (24 B) straddle 1 KiB chunk boundaries: row sharding is refused rather than silently wrong
-    with pytest.raises(lcpc_amd.LcpcError) as e:
-        LigeroEncoding.new_from_dims(2, 64, 128, shard=(0, 2))
-    assert e.value.code == lcpc_amd.ERR_ARG
+def test_ft191_shard_boundaries_are_row_boundaries():
+    """Ft191's 24-byte elements straddle the 1 KiB BLAKE3 chunks (round 3 refused to shard the field): a shard may begin only where
+    32 + 24 r is a multiple of 1024, r = 84 (mod 128) -- chunk 2 (mod 3).  lcpc_shard_layout must hand out exactly such cuts, the
+    ranks' row and chunk ranges must partition the commitment, and no rank's range may split a row."""
+    for n_rows in (40, 90, 700, 1500, 5000):
+        for G in (2, 3, 5, 8):
+            seen_r = seen_c = 0
+            for g in range(G):
+                eng = HipShardEngine(LigeroEncoding.new_from_dims(2, 64, 128, shard=(g, G)))
+                rb, re, cb, ce, nch = eng.layout(n_rows)
+                assert nch == (32 + 24 * n_rows + 1023) // 1024
+                assert (rb, cb) == (seen_r, seen_c) and re >= rb and ce >= cb
+                if 0 < cb < nch:
+                    assert cb % 3 == 2 and rb % 128 == 84 and 32 + 24 * rb == 1024 * cb
+                assert (cb, ce) == chunk_split(nch, G, 24)[g]
+                seen_r, seen_c = re, ce
+            assert (seen_r, seen_c) == (n_rows, nch)
 
 
-@pytest.mark.parametrize("fid,n_per_row,n_rows,G", [(3, 300, 70, 2), (3, 300, 70, 4), (0, 400, 300, 2), (3, 257, 40, 8)])
+@pytest.mark.parametrize("fid,n_per_row,n_rows,G", [(3, 300, 70, 2), (3, 300, 70, 4), (0, 400, 300, 2), (3, 257, 40, 8), (2, 300, 300, 3)])
 @pytest.mark.parametrize("sliced", [False, True])
 def test_sharded_brakedown_equals_unsharded(oracle, fid, n_per_row, n_rows, G, sliced):
     """Brakedown shards the same way (rows independent, matrices replicated on every rank): shards with
@@ -170,6 +194,7 @@ class ThreadAllGather:
     ("ligero", 1, 130, 2048, 4096, 2),   # ft127 on K1n: opened columns come out of a canonical comm on every rank
     ("ligero", 3, 20, 64, 128, 2),       # single chunk: rank 1 owns nothing
     ("sdig", 3, 70, 300, 0, 4),
+    ("ligero", 2, 700, 64, 128, 3),      # ft191: shards cut at rows 84 (mod 128)
 ])
 def test_sharded_prove_equals_unsharded(oracle, kind, fid, n_rows, n_per_row, n_cols, G):
     """lcpc_prove_sharded on G shard contexts (threads + an in-process all-gather): every rank returns the proof of the

@@ -21,7 +21,7 @@ from lcpc_amd import LcCommit, LigeroEncoding, SdigEncoding
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rnd = random.Random(4242)
 for case in range(n_cases):
-    fid = rnd.choice([0, 1, 3, 3])
+    fid = rnd.choice([0, 1, 2, 3, 3])
     L = O.limbs(fid)
     log_n = rnd.randrange(2, 16)          # up to 2^15 columns: the specialised two-pass kernels (K1s / K1n, canonical comm) under sharding
     n_cols = 1 << log_n
