@@ -48,7 +48,7 @@ static LeafArgs leaf_args(const lcpc_commit_t* m) {
   return la;
 }
 
-int merkle_top(lcpc_commit_t* m, hipStream_t st) {
+int merkle_top(lcpc_commit_t* m, hipStream_t st, uint32_t levels_done) {
   const lcpc_ctx* c = m->enc;
   if (c->np2 > c->n_cols)   // hashes[n_cols..np2) stay zero (lib.rs:656-666)
     HIPCHK(m, hipMemsetAsync(m->d_hashes + c->n_cols * 8, 0, (size_t)(c->np2 - c->n_cols) * 32, st));
@@ -62,7 +62,7 @@ int merkle_top(lcpc_commit_t* m, hipStream_t st) {
       }
       if (!m->h_root) (void)hipGetLastError();   // the failed call's error must not surface at the next launch check
     }
-    HIPCHK(m, launch_merkle_tree(m->d_hashes, c->np2, st, m->d_root_alias));
+    HIPCHK(m, launch_merkle_tree_from(m->d_hashes, c->np2, levels_done, st, m->d_root_alias));
     m->launches[2]++;
   }
   return 0;
@@ -86,6 +86,13 @@ static int merkleize_device(lcpc_commit_t* m, hipStream_t st) {
   const uint64_t n_chunks = leaf_chunks(c, m->n_rows);
   LeafArgs la = leaf_args(m);
   la.row_base = 0; la.chunk_begin = 0; la.n_chunks_local = (uint32_t)n_chunks; la.n_chunks_total = (uint32_t)n_chunks;
+  if (c->sw_fused_leaf_tree && leaf_tree_supported(la, c->np2)) {
+    // small commitment: leaf digests and the first six levels of the tree in one launch (kernels.hip leaf_tree_kernel)
+    HIPCHK(m, launch_leaf_tree(c->NL, la, m->d_hashes, c->np2, st));
+    m->launches[1]++;
+    if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], st));
+    return merkle_top(m, st, 6);
+  }
   if (n_chunks == 1) {
     la.out = m->d_hashes;
     HIPCHK(m, launch_leaf_chunks(c->NL, la, st));

@@ -740,6 +740,7 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
   if (const char* ev = getenv("LCPC_NTT_TILE_GROUP")) c->sw_ntt_tile_group = (int32_t)strtoul(ev, nullptr, 10);
   c->sw_sdig_tail = !getenv("LCPC_SDIG_NO_TAIL");
   c->sw_debug_fail_mid = getenv("LCPC_DEBUG_FAIL_MID") != nullptr;
+  c->sw_fused_leaf_tree = !getenv("LCPC_NO_FUSED_LEAF_TREE");
   if (const char* ev = getenv("LCPC_DEBUG_K2_PRICE")) c->sw_debug_k2_price = (uint32_t)strtoul(ev, nullptr, 10);
   if (const char* ev = getenv("LCPC_SDIG_ROW_GROUP")) c->sw_sdig_row_group = std::min<uint32_t>(64, (uint32_t)strtoul(ev, nullptr, 10));
   if (const char* ev = getenv("LCPC_SHARD_SLICES")) c->shard_slices = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)strtoul(ev, nullptr, 10), LCPC_MAX_SHARD_SLICES));

@@ -74,6 +74,7 @@ struct lcpc_ctx {
   int32_t sw_ntt_tile_group = -1;  // LCPC_NTT_TILE_GROUP: -1 = the default rule of ntt_tile_group_of
   bool sw_sdig_tail = true;        // LCPC_SDIG_NO_TAIL unset
   uint32_t sw_sdig_row_group = 0;  // LCPC_SDIG_ROW_GROUP: Brakedown Ft255 wide levels in row groups of <= this many rows (0 = off)
+  bool sw_fused_leaf_tree = true;  // LCPC_NO_FUSED_LEAF_TREE unset: small commitments hash their columns and fold six tree levels in one launch
   uint32_t sw_debug_k2_price = 0;  // LCPC_DEBUG_K2_PRICE (experiment, wrong results): price of a limb-form T in the wide SpMM levels
   bool sw_debug_fail_mid = false;  // LCPC_DEBUG_FAIL_MID (test hook): the K1s limb-intermediate allocation fails -> packed intermediate
   uint32_t shard_slices = 1;       // native sharded commit: column slices whose exchange overlaps the next slice's hashing
@@ -262,7 +263,7 @@ int encode_msgs_host(lcpc_ctx* c, const uint64_t* const* msgs, uint64_t n_rows, 
 int ensure_scratch(lcpc_commit_t* m, uint64_t bytes);
 int ensure_cvs(lcpc_commit_t* m, uint64_t n_chunks);
 int ensure_commit_buffers(lcpc_commit_t* m, uint64_t n_rows_local, bool own_coeffs);
-int merkle_top(lcpc_commit_t* m, hipStream_t st);       // zero padding leaves + tree above the leaf digests
+int merkle_top(lcpc_commit_t* m, hipStream_t st, uint32_t levels_done = 0);       // zero padding leaves + tree above the leaf digests (above level `levels_done`)
 int order_after_commit(lcpc_commit_t* m, hipStream_t st);          // st waits for the commit that filled m (event; cheap)
 int fetch_root(lcpc_commit_t* m, hipStream_t st, uint8_t* root);   // root of the commit just enqueued on st -> host (synchronises)
 int finish_timing(lcpc_commit_t* m, hipStream_t st);

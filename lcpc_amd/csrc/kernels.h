@@ -93,6 +93,11 @@ hipError_t launch_leaf_finish_nodes(uint32_t* cvs, const uint32_t* node_slot, co
 // whole tree above the leaf layer in as few launches as possible (hashes = LcCommit.hashes, np2 leaves)
 // root_out (may be null): 8 more words the root is written to by the launch that produces it (host-mapped memory)
 hipError_t launch_merkle_tree(uint32_t* hashes, uint64_t np2, hipStream_t st, uint32_t* root_out);
+hipError_t launch_merkle_tree_from(uint32_t* hashes, uint64_t np2, uint32_t levels_done, hipStream_t st, uint32_t* root_out);
+// small commitments: leaf digests (<= 2 chunks per leaf message) AND the first six tree levels in one launch (np2 == n_cols,
+// n_cols % 64 == 0, n_cols >= 128, n_cols * n_chunks <= 65536); follow with launch_merkle_tree_from(.., 6, ..)
+bool leaf_tree_supported(const LeafArgs& a, uint64_t np2);
+hipError_t launch_leaf_tree(int nl, const LeafArgs& a, uint32_t* hashes, uint64_t np2, hipStream_t st);
 
 struct CollapseArgs {
   const uint32_t* coeffs;      // local rows x n_per_row

@@ -467,6 +467,14 @@ hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream
 // unit a row-sharded multi-GPU commit exchanges.  A second tiny kernel folds the CVs of a column with
 // BLAKE3's parent rule.  Element -> canonical little-endian bytes is one Montgomery reduction.
 // =================================================================================================
+__device__ __forceinline__ void ld8(u32 d[8], const u32* p) {
+  uint4 x = *reinterpret_cast<const uint4*>(p), y = *reinterpret_cast<const uint4*>(p + 4);
+  d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; d[4] = y.x; d[5] = y.y; d[6] = y.z; d[7] = y.w;
+}
+__device__ __forceinline__ void st8(u32* p, const u32 d[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(d[0], d[1], d[2], d[3]);
+  *reinterpret_cast<uint4*>(p + 4) = make_uint4(d[4], d[5], d[6], d[7]);
+}
 template <int NL, int PH> struct LeafRaw {
   static constexpr int NEL = (PH + 16 + NL - 1) / NL;     // elements a 16-word block touches
   Fe<NL> el[NEL];
@@ -504,19 +512,16 @@ __device__ __forceinline__ void leaf_fill_block(u32 m[16], const LeafArgs& a, u6
 // QUAD: four lanes per column, one compression per quad (b3_compress_quad): a small commitment has fewer (column, chunk)
 // pairs than the chip has lanes, and a chunk is a chain of up to 16 dependent compressions -- ~300 instead of ~700 dependent
 // instructions each.  The four lanes build the same message block (their loads coalesce to one); 64 columns per workgroup.
-template <int NL, bool CANON = false, bool QUAD = false>
-__global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
-  const u64 col = QUAD ? (u64)blockIdx.x * 64 + (threadIdx.x >> 2) : (u64)blockIdx.x * 256 + threadIdx.x;
-  const u32 q = threadIdx.x & 3u;
-  if (col >= a.n_cols) return;
-  const u32 chunk = a.chunk_begin + blockIdx.y;
+// Chaining value of chunk `chunk` of column `col`'s leaf message: in cv[8] (one lane per column), or spread over the quad
+// (lane q: words q and 4 + q in cv_lo / cv_hi).
+template <int NL, bool CANON, bool QUAD>
+__device__ __forceinline__ void leaf_chunk_cv(const LeafArgs& a, u64 col, u32 chunk, u32 q, u32 cv[8], u32& cv_lo, u32& cv_hi) {
   const u64 total_len = 32 + (u64)NL * 4 * a.n_rows_total;
   const u64 chunk_off = (u64)chunk * 1024;
   const u32 chunk_len = (u32)((total_len - chunk_off) < 1024 ? (total_len - chunk_off) : 1024);
   const u32 nblocks = (chunk_len + 63) / 64;
-  u32 cv[8];
   b3_set_iv(cv);
-  u32 cv_lo = b3_sel4(q, B3_IV0, B3_IV1, B3_IV2, B3_IV3), cv_hi = b3_sel4(q, B3_IV4, B3_IV5, B3_IV6, B3_IV7);   // QUAD: this lane's two words
+  cv_lo = b3_sel4(q, B3_IV0, B3_IV1, B3_IV2, B3_IV3); cv_hi = b3_sel4(q, B3_IV4, B3_IV5, B3_IV6, B3_IV7);   // QUAD: this lane's two words
   auto compress = [&](const u32* m, u32 blen, u32 flags) {
     if constexpr (QUAD) b3_compress_quad(q, cv_lo, cv_hi, m, chunk, blen, flags);
     else b3_compress(cv, m, chunk, blen, flags);
@@ -559,6 +564,16 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
       compress(m, blen, flags);
     }
   }
+}
+template <int NL, bool CANON = false, bool QUAD = false>
+__global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
+  const u64 col = QUAD ? (u64)blockIdx.x * 64 + (threadIdx.x >> 2) : (u64)blockIdx.x * 256 + threadIdx.x;
+  const u32 q = threadIdx.x & 3u;
+  if (col >= a.n_cols) return;
+  const u32 chunk = a.chunk_begin + blockIdx.y;
+  u32 cv[8];
+  u32 cv_lo, cv_hi;
+  leaf_chunk_cv<NL, CANON, QUAD>(a, col, chunk, q, cv, cv_lo, cv_hi);
   u32* o = a.out + ((u64)blockIdx.y * a.n_cols + col) * 8;
   if constexpr (QUAD) {
     o[q] = cv_lo;
@@ -567,6 +582,77 @@ __global__ void __launch_bounds__(256) leaf_chunk_kernel(LeafArgs a) {
     *reinterpret_cast<uint4*>(o) = make_uint4(cv[0], cv[1], cv[2], cv[3]);
     *reinterpret_cast<uint4*>(o + 4) = make_uint4(cv[4], cv[5], cv[6], cv[7]);
   }
+}
+
+// Small commitments (hash_columns + the first six levels of merkle_tree in one launch; lib.rs:706-745, 747-785): a workgroup of
+// 64 quads hashes 64 columns -- the one or two chunks of a column's leaf message one after the other on its quad, folded with the
+// parent rule -- and then folds its 64 leaf digests six levels up through LDS, one compression per quad, writing every level to
+// its slot of `hashes`.  The launches it replaces (chunk CVs, their fold, the 512-leaf subtree kernel) are each a latency chain on
+// a nearly empty chip; the tail of the tree (launch_merkle_tree_from level 6) follows.  Needs np2 == n_cols, n_cols % 64 == 0.
+template <int NL, bool CANON>
+__global__ void __launch_bounds__(256) leaf_tree_kernel(LeafArgs a, u32* hashes, u64 np2) {
+  __shared__ u32 buf[64 * 8];
+  const u32 tid = threadIdx.x, qd = tid >> 2, q = tid & 3u;
+  const u64 base = (u64)blockIdx.x * 64;
+  const u64 col = base + qd;
+  u32 cv[8];
+  u32 lo, hi;
+  leaf_chunk_cv<NL, CANON, true>(a, col, 0, q, cv, lo, hi);
+  if (a.n_chunks_total == 2) {
+    u32 lo1, hi1, l[8], r[8];
+    leaf_chunk_cv<NL, CANON, true>(a, col, 1, q, cv, lo1, hi1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {          // every lane of the quad needs all eight words of both chaining values
+      l[i] = (u32)__shfl((int)lo, i, 4); l[4 + i] = (u32)__shfl((int)hi, i, 4);
+      r[i] = (u32)__shfl((int)lo1, i, 4); r[4 + i] = (u32)__shfl((int)hi1, i, 4);
+    }
+    b3_hash64_quad(q, lo, hi, l, r, B3_PARENT | B3_ROOT);
+  }
+  {
+    u32* g = hashes + col * 8;
+    g[q] = lo; g[4 + q] = hi;
+    buf[qd * 8 + q] = lo; buf[qd * 8 + 4 + q] = hi;
+  }
+  constexpr u32 FL = B3_CHUNK_START | B3_CHUNK_END | B3_ROOT;
+  u64 w = np2, layer_out = np2;
+  u32 n_out = 32;
+#pragma unroll 1
+  for (u32 j = 1; j <= 6; j++) {
+    __syncthreads();
+    const bool act = qd < n_out;
+    u32 o_lo = 0, o_hi = 0;
+    if (act) {
+      u32 l[8], r[8];
+      ld8(l, buf + (2 * qd) * 8);
+      ld8(r, buf + (2 * qd + 1) * 8);
+      b3_hash64_quad(q, o_lo, o_hi, l, r, FL);
+    }
+    __syncthreads();
+    if (act) {
+      buf[qd * 8 + q] = o_lo; buf[qd * 8 + 4 + q] = o_hi;
+      u32* g = hashes + (layer_out + (base >> j) + qd) * 8;
+      g[q] = o_lo; g[4 + q] = o_hi;
+    }
+    w >>= 1;
+    layer_out += w;
+    n_out >>= 1;
+  }
+}
+bool leaf_tree_supported(const LeafArgs& a, u64 np2) {
+  return a.n_chunks_total <= 2 && a.n_chunks_local == a.n_chunks_total && a.chunk_begin == 0 && np2 == a.n_cols && a.n_cols >= 128 &&
+         (a.n_cols & 63) == 0 && a.n_cols * a.n_chunks_total <= 65536;
+}
+hipError_t launch_leaf_tree(int nl, const LeafArgs& a, u32* hashes, u64 np2, hipStream_t st) {
+  if (!leaf_tree_supported(a, np2)) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)(a.n_cols / 64));
+#define LT_CASE(NLV) case NLV: if (a.canon_in) hipLaunchKernelGGL((leaf_tree_kernel<NLV, true>), grid, dim3(256), 0, st, a, hashes, np2); \
+                               else hipLaunchKernelGGL((leaf_tree_kernel<NLV, false>), grid, dim3(256), 0, st, a, hashes, np2); break;
+  switch (nl) {
+    LT_CASE(2) LT_CASE(4) LT_CASE(6) LT_CASE(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef LT_CASE
+  return hipGetLastError();
 }
 // grid.y is limited to 65535: a commitment with millions of short rows (new_from_dims with a small n_per_row) has more
 // leaf-message chunks than that, so the chunk range is launched in slices
@@ -606,14 +692,6 @@ hipError_t launch_leaf_chunks(int nl, const LeafArgs& a, hipStream_t st) {
   return hipSuccess;
 }
 
-__device__ __forceinline__ void ld8(u32 d[8], const u32* p) {
-  uint4 x = *reinterpret_cast<const uint4*>(p), y = *reinterpret_cast<const uint4*>(p + 4);
-  d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; d[4] = y.x; d[5] = y.y; d[6] = y.z; d[7] = y.w;
-}
-__device__ __forceinline__ void st8(u32* p, const u32 d[8]) {
-  *reinterpret_cast<uint4*>(p) = make_uint4(d[0], d[1], d[2], d[3]);
-  *reinterpret_cast<uint4*>(p + 4) = make_uint4(d[4], d[5], d[6], d[7]);
-}
 
 // BLAKE3 tree over the subtree CVs ("nodes") of each column.  Node j covers 2^node_log[j] consecutive chunks
 // starting at a multiple of its size (aligned power-of-two chunk groups are subtrees of the BLAKE3 tree); its CV
@@ -750,8 +828,11 @@ __global__ void __launch_bounds__(BS) merkle_subtree_kernel(u32* hashes, u64 in_
     if (tid < 8) root_out[tid] = buf[tid];      // node 0 of the last level
   }
 }
-hipError_t launch_merkle_tree(u32* hashes, u64 np2, hipStream_t st, u32* root_out) {
+hipError_t launch_merkle_tree(u32* hashes, u64 np2, hipStream_t st, u32* root_out) { return launch_merkle_tree_from(hashes, np2, 0, st, root_out); }
+// ... from level `levels_done` on (the levels below it are in `hashes` already: leaf_tree_kernel)
+hipError_t launch_merkle_tree_from(u32* hashes, u64 np2, u32 levels_done, hipStream_t st, u32* root_out) {
   u64 in_off = 0, width = np2;
+  for (u32 j = 0; j < levels_done; j++) { in_off += width; width >>= 1; }
   while (width > 1) {
     u32 lw = 0;
     while (((u64)1 << lw) < width) lw++;

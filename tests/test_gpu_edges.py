@@ -93,9 +93,10 @@ def test_constructor_errors():
     with pytest.raises(E) as e:                                  # invalid SDIG code
         SdigEncoding.new(3, 1 << 12, 0, code=7)
     assert e.value.code == lcpc_amd.ERR_ARG
-    with pytest.raises(E) as e:                                  # sharding a field whose elements straddle BLAKE3 chunks
-        LigeroEncoding.new_from_dims(2, 64, 128, shard=(0, 2))
+    with pytest.raises(E) as e:                                  # shard rank outside the shard count
+        LigeroEncoding.new_from_dims(3, 64, 128, shard=(2, 2))
     assert e.value.code == lcpc_amd.ERR_ARG
+    LigeroEncoding.new_from_dims(2, 64, 128, shard=(0, 2))       # (ft191 shards since round 4: tests/test_gpu_sharded.py)
 
 
 def test_state_and_argument_errors(oracle):
@@ -578,3 +579,49 @@ def test_brakedown_row_groups(oracle, n_rows, group):
     assert c.get_root() == oc.get_root()
     assert (c.hashes() == oc.hashes()).all()
     assert (c.comm() == oc.comm()).all()
+
+
+@pytest.mark.parametrize("fid,n_rows,n_per_row,n_cols", [
+    (0, 32, 2048, 4096),        # C1: ft63 2^16, one chunk (32 + 32 * 8 bytes)
+    (0, 200, 64, 128),          # ft63, 2 chunks (1632 bytes), the narrowest tree the fused kernel takes (128 leaves)
+    (1, 16, 128, 256),          # ft127, one chunk
+    (1, 100, 1024, 2048),       # ft127, 2 chunks
+    (2, 40, 256, 512),          # ft191: one chunk of 992 bytes (24-byte elements: blocks start inside elements)
+    (2, 60, 512, 1024),         # ft191: 2 chunks, an element straddles the chunk boundary
+    (3, 8, 1024, 2048),         # ft255 2^13
+    (3, 16, 2048, 4096),        # ft255 2^15
+    (3, 31, 64, 128),           # ft255: exactly one full chunk (1024 bytes)
+    (3, 32, 4096, 8192),        # ft255 2^17: 2 chunks, the second holds 32 bytes
+    (3, 63, 16384, 32768),      # 2 full chunks x 32768 columns = the limit of 65536 (column, chunk) pairs
+    (3, 5, 32768, 65536),       # one chunk x 65536 columns: 1024 workgroups, then the 512-leaf subtree kernel and the tail
+])
+def test_fused_leaf_tree_small_commits(oracle, fid, n_rows, n_per_row, n_cols):
+    """Small commitments hash their columns AND fold the first six Merkle levels in one launch (leaf_tree_kernel: a quad of lanes
+    per column, the one or two chunks of its leaf message in sequence, then 64 leaves -> 1 through LDS), the rest of the tree
+    following from level 6.  The WHOLE `hashes` array -- leaf digests and every layer -- equals the oracle's and the unfused
+    path's (LCPC_NO_FUSED_LEAF_TREE=1 at context creation), for every field, one and two chunks, the narrowest and widest trees."""
+    import os
+    O = oracle
+    coeffs = O.random_elems(fid, n_rows * n_per_row - 1, 900 + n_rows)
+    oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    os.environ["LCPC_NO_FUSED_LEAF_TREE"] = "1"
+    try:
+        enc_plain = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    finally:
+        del os.environ["LCPC_NO_FUSED_LEAF_TREE"]
+    c, d = LcCommit.commit(coeffs, enc), LcCommit.commit(coeffs, enc_plain)
+    assert c.get_root() == oc.get_root() == d.get_root()
+    assert (c.hashes() == oc.hashes()).all() and (d.hashes() == oc.hashes()).all()
+    c.set_timing(True)
+    LcCommit.commit(coeffs, enc, into=c)
+    d.set_timing(True)
+    LcCommit.commit(coeffs, enc_plain, into=d)
+    n_chunks = (32 + 8 * O.limbs(fid) * c.n_rows + 1023) // 1024
+    assert c.timings().hash_launches == 1 and d.timings().hash_launches == n_chunks     # (chunk CVs + their fold when unfused)
+    root = oc.get_root()
+    t = O.random_elems(fid, c.n_rows, 78)
+    pf = c.prove(t, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+    opf, _ = oc.prove(t, oenc, mk_transcript(O.Transcript, root, enc.get_n_col_opens()))
+    assert pf.to_bytes() == opf
