@@ -56,6 +56,17 @@ def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q):
             proof2, _ = eng.prove_native(outer, mk_transcript(Transcript, root2, enc.get_n_col_opens()))
             if root2 != root or proof2 != proof:
                 raise RuntimeError("native RCCL exchange disagrees with the torch.distributed exchange")
+            # LCPC_COMMIT_ASYNC_TAIL on two commitments of the encoder, filled alternately without host synchronisation
+            # (what bench.py --gpus N times): their collectives share the communicator and must keep their order on every rank
+            eng2 = HipShardEngine(enc)
+            for _ in range(3):
+                eng.commit_native(local, n_rows, want_root=False, async_tail=True)
+                eng2.commit_native(local, n_rows, want_root=False, async_tail=True)
+            if eng.cm.get_root() != root or eng2.cm.get_root() != root:
+                raise RuntimeError("async-tail commits disagree with the sequential one")
+            proof3, _ = eng2.prove_native(outer, mk_transcript(Transcript, root, enc.get_n_col_opens()))
+            if proof3 != proof:
+                raise RuntimeError("prove on an async-tail commitment disagrees")
         q.put((rank, root, proof))
     except Exception as e:      # surface the failure instead of a queue timeout
         q.put((rank, repr(e), b""))

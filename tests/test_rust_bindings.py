@@ -199,3 +199,49 @@ def test_high_level_crate_uses_declared_symbols_only():
     # constant names used through sys:: exist there
     sysc = set(re.findall(r"pub const (LCPC_\w+)", open(SYS).read()))
     assert set(re.findall(r"sys::(LCPC_\w+)", hi)) <= sysc
+
+
+def test_rust_sources_are_lexically_balanced():
+    """no rustc here: at least every bracket of the two crates closes in the right order, outside comments, strings and chars
+    (a dropped brace is the commonest way a hand-written file stops compiling), and Cargo manifests name the paths that exist"""
+    base = os.path.join(ROOT, "bindings", "rust")
+    for rel in ("lcpc-hip-sys/src/lib.rs", "lcpc-hip-sys/build.rs", "lcpc-hip/src/lib.rs"):
+        src = open(os.path.join(base, rel), encoding="utf8").read()
+        stack, i, n = [], 0, len(src)
+        pairs = {")": "(", "]": "[", "}": "{"}
+        while i < n:
+            ch = src[i]
+            if src.startswith("//", i):
+                i = src.find("\n", i)
+                i = n if i < 0 else i
+                continue
+            if src.startswith("/*", i):
+                i = src.find("*/", i) + 2
+                continue
+            if ch == '"':
+                i += 1
+                while src[i] != '"':
+                    i += 2 if src[i] == "\\" else 1
+                i += 1
+                continue
+            if ch == "b" and src.startswith('b"', i):
+                i += 1
+                continue
+            if ch == "'":
+                # a char literal ('x', '\n') or a lifetime ('a, 'static, '_): literals close within 4 characters
+                m = re.match(r"'(\\.|[^\\'])'", src[i:])
+                i += len(m.group(0)) if m else 1
+                continue
+            if ch in "([{":
+                stack.append((ch, src.count("\n", 0, i) + 1))
+            elif ch in ")]}":
+                assert stack and stack[-1][0] == pairs[ch], "%s: unbalanced %r at line %d" % (rel, ch, src.count("\n", 0, i) + 1)
+                stack.pop()
+            i += 1
+        assert not stack, "%s: unclosed %r from line %d" % (rel, stack[-1][0], stack[-1][1])
+    for crate in ("lcpc-hip-sys", "lcpc-hip"):
+        man = open(os.path.join(base, crate, "Cargo.toml")).read()
+        assert re.search(r'^name = "%s"' % crate, man, flags=re.M)
+    ws = open(os.path.join(base, "Cargo.toml")).read()
+    assert '"lcpc-hip-sys"' in ws and '"lcpc-hip"' in ws
+    assert 'path = "../lcpc-hip-sys"' in open(os.path.join(base, "lcpc-hip", "Cargo.toml")).read()
