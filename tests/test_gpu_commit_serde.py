@@ -73,6 +73,22 @@ def test_commit_bincode_rejects_bad_streams(oracle):
     assert status(bytes(bad)) == lcpc_amd.ERR_COMMIT
     bad = bytearray(good); bad[0:8] = struct.pack("<Q", nr * nc + 1)                         # comm.len() not a multiple of n_cols
     assert status(bytes(bad)) == lcpc_amd.ERR_COMMIT
+    # an untrusted length the device could not hold (2^28 rows of this encoder: below the format's 2^40-element cap, above any
+    # HBM): refused before anything is freed or allocated -- a commitment held by the object survives the attempt
+    held = LcCommit.commit(coeffs, enc)
+    root = held.get_root()
+    bad = bytearray(good); bad[0:8] = struct.pack("<Q", (1 << 28) * nc)
+    err = []
+    rc = lcpc_amd._lib.lib().lcpc_commit_from_bincode
+    def rd(_u, data, k, src=io.BytesIO(bytes(bad))):
+        b = src.read(k)
+        if len(b) != k:
+            return 1
+        import ctypes as C
+        C.memmove(data, b, k)
+        return 0
+    assert rc(held._h, lcpc_amd._lib.WRITE_FN(rd), None, None) == lcpc_amd.ERR_COMMIT
+    assert held.get_root() == root
     # nothing is left committed after a refused stream
     cm = LcCommit(enc)
     with pytest.raises(LcpcError):
