@@ -241,7 +241,8 @@ int  lcpc_shard_nodes_field(uint32_t field, uint64_t n_chunks_total, uint32_t sh
 /* (a) native exchange.  One rank calls lcpc_comm_unique_id (ncclGetUniqueId) and distributes the 128 bytes by any
  * means; every rank then calls lcpc_comm_init on its sharded encoder (ncclCommInitRank on the encoder's device;
  * rank / world must equal shard_rank / shard_count; world == 1 is allowed and still goes through RCCL).
- * librccl is loaded at run time (dlopen): LCPC_ERR_NO_RCCL if it is absent. */
+ * librccl is loaded at run time (dlopen; a copy already in the process wins, LCPC_RCCL_LIB=<path> names one explicitly):
+ * LCPC_ERR_NO_RCCL if it is absent. */
 int  lcpc_comm_unique_id(uint8_t id[128]);
 int  lcpc_comm_init(lcpc_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_t world);
 int  lcpc_comm_destroy(lcpc_ctx *ctx);

@@ -84,6 +84,11 @@ Rccl& rccl() {
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     // a copy already in the process (torch bundles one) wins, under whatever name it was loaded: every candidate name with
     // RTLD_NOLOAD first, then the global symbol scope (a copy loaded by full path with RTLD_GLOBAL), and only then a load
+    // LCPC_RCCL_LIB=<path>: this library and no other (a site's own RCCL build; the tests' in-process stand-in)
+    if (const char* ov = getenv("LCPC_RCCL_LIB")) {
+      x.h = dlopen(ov, RTLD_NOW | RTLD_LOCAL);
+      if (!x.h) return x;
+    }
     for (const char* n : names) {
       if (x.h) break;
       x.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
