@@ -237,8 +237,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
-    if args.dist_backend != "nccl":
-        args.exchange = "torch"
+    if args.dist_backend != "nccl" and not (args.exchange == "native" and os.environ.get("LCPC_RCCL_LIB")):
+        args.exchange = "torch"          # (debug runs over gloo keep the native exchange only with an explicit stand-in library)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":

@@ -384,17 +384,18 @@ def commit_streaming(enc, n_coeffs, rows_of, n_threads=1, chunks_per_step=1):
     leaf digests and the Merkle tree (lib.rs:747-785) follow from the chaining values.  Host memory: one block of encoded
     rows + 32 bytes per (chunk, column) -- ~2 GB at 2^28 Ft255 coefficients where Commit.commit needs ~40 GB.
     rows_of(r0, r1) returns the coefficients of rows [r0, r1) as an (elements, L) uint64 array (a ragged last row is padded
-    here).  Returns the `hashes` array (2 * np2 - 1, 32).  Needs F | 1024 (rows that do not straddle chunks): Ft63, Ft127, Ft255."""
+    here).  Returns the `hashes` array (2 * np2 - 1, 32).  chunks_per_step counts the possible cuts (every chunk; every third for
+    Ft191, whose 24-byte elements straddle the others)."""
     fid, L = enc.fid, enc.L
     F = 8 * L
-    if 1024 % F:
-        raise ValueError("commit_streaming: element size must divide 1024")
     n_rows, n_per_row, n_cols = enc.get_dims(n_coeffs)
     n_chunks = (32 + F * n_rows + 1023) // 1024
+    # a block of rows may end only where a chunk boundary is a row boundary: every chunk when F | 1024, every third for Ft191
+    cuts = [c for c in range(n_chunks + 1) if c in (0, n_chunks) or (1024 * c - 32) % F == 0]
     first_row = lambda ch: 0 if ch == 0 else min(n_rows, (ch * 1024 - 32) // F)
     cvs = np.zeros((n_chunks, n_cols, 32), np.uint8)
-    for cb in range(0, n_chunks, chunks_per_step):
-        ce = min(n_chunks, cb + chunks_per_step)
+    for i in range(0, len(cuts) - 1, chunks_per_step):
+        cb, ce = cuts[i], cuts[min(i + chunks_per_step, len(cuts) - 1)]
         r0, r1 = first_row(cb), (n_rows if ce >= n_chunks else first_row(ce))
         blk = np.zeros(((r1 - r0) * n_per_row, L), np.uint64)
         got = np.ascontiguousarray(rows_of(r0, r1), np.uint64).reshape(-1, L)

@@ -37,6 +37,36 @@ def test_bench_gpus2_self_launches_two_ranks():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_native_exchange_across_processes(tmp_path, n):
+    """`bench.py --gpus N` exactly as the driver runs it on a multi-GPU node -- one process per rank, the library's OWN exchange
+    (lcpc_comm_init with the id carried by torch.distributed, the timed loop of LCPC_COMMIT_ASYNC_TAIL commits on two commitments
+    per rank, the cross-check against the torch exchange and against an unsharded commit) -- on the one-GPU box: the ranks share
+    device 0, torch.distributed runs over gloo, and RCCL (which refuses two ranks on one device) is replaced by the
+    shared-memory stand-in tests/native/fake_rccl_shm.cpp through LCPC_RCCL_LIB.  No fallback to the torch exchange may happen."""
+    so = str(tmp_path / "libfake_rccl_shm.so")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cc = subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + rocm + "/include",
+                         os.path.join(ROOT, "tests", "native", "fake_rccl_shm.cpp"), "-o", so, "-L" + rocm + "/lib", "-lamdhip64", "-lrt"],
+                        capture_output=True, text=True, timeout=300)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    env = dict(os.environ, LCPC_RCCL_LIB=so)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--log-len", "22",
+                        "--dist-backend", "gloo", "--force-device", "0", "--exchange", "native"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["ranks_seen"] == n
+    assert "exchange_fallback" not in out, out.get("exchange_fallback")
+    assert "RCCL inside the library" in out["config"]["sharding"] and "LCPC_COMMIT_ASYNC_TAIL" in out["config"]["sharding"]
+    assert out["check"]["sharded_root_equals_unsharded_root"] is True
+    assert out["shard_ms"]["async_tail"] is True and out["min_ms_per_step"] is None and out["value"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_n1_json_contract():
     """the N = 1 line the driver records: one JSON object carrying the metric, `roofline` (bound / achieved / peak / frac with
     frac == achieved / peak, per-launch algorithmic bytes and launch time) and `cpu_baseline` (value, cores, kind, sample, and

@@ -54,8 +54,14 @@ def test_streaming_commit_equals_commit_brakedown(oracle):
     assert (h == oc.hashes()).all()
 
 
-def test_streaming_commit_refuses_straddling_field(oracle):
+def test_streaming_commit_ft191_cuts_at_row_boundaries(oracle):
+    """Ft191: 24-byte elements straddle the 1 KiB chunks; the row blocks end at rows = 84 (mod 128) only (every third chunk)"""
     O = oracle
-    enc = O.Encoding.ligero_from_dims(2, 16, 32)          # Ft191: 24-byte elements straddle 1 KiB chunks
-    with pytest.raises(ValueError):
-        O.commit_streaming(enc, 64, lambda a, b: None)
+    for n_rows, short in ((40, 0), (90, 3), (700, 5)):
+        enc = O.Encoding.ligero_from_dims(2, 16, 32)
+        n = n_rows * 16 - short
+        coeffs = O.random_elems(2, n, 4300 + n_rows)
+        oc = O.Commit.commit(coeffs, enc, n_threads=2)
+        for step in (1, 2, 50):
+            h = O.commit_streaming(enc, n, _rows_of(coeffs, 16), n_threads=3, chunks_per_step=step)
+            assert (h == oc.hashes()).all(), (n_rows, step)
