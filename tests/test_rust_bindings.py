@@ -205,7 +205,7 @@ def test_rust_sources_are_lexically_balanced():
     """no rustc here: at least every bracket of the two crates closes in the right order, outside comments, strings and chars
     (a dropped brace is the commonest way a hand-written file stops compiling), and Cargo manifests name the paths that exist"""
     base = os.path.join(ROOT, "bindings", "rust")
-    for rel in ("lcpc-hip-sys/src/lib.rs", "lcpc-hip-sys/build.rs", "lcpc-hip/src/lib.rs"):
+    for rel in ("lcpc-hip-sys/src/lib.rs", "lcpc-hip-sys/build.rs", "lcpc-hip/src/lib.rs", "lcpc-hip/examples/commit_prove.rs"):
         src = open(os.path.join(base, rel), encoding="utf8").read()
         stack, i, n = [], 0, len(src)
         pairs = {")": "(", "]": "[", "}": "{"}
