@@ -487,13 +487,11 @@ def main():
                     "finish": round(float(ph[2]) * 1e3, 3), "gathered_MB": round(gathered.numel() / 1e6, 1)}
     elif distributed:
         # native exchange: the library's own event brackets (encode | hash | exchange + finish), MAX over ranks
-        # exchange_exposed_ms: how long the commit's stream waited, after its last hash launch, for the last column slice to
-        # come back from the exchange stream -- the part of the wire time that the slice pipeline does NOT hide
+        # exchange_exposed_ms: from the end of the local column hash to the arrival of the leaf digests (wire + leaf-digest time)
         ph = torch.tensor([tm.encode_ms, tm.hash_ms, tm.merkle_ms, tm.exchange_exposed_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(ph, op=dist.ReduceOp.MAX)
         shard_ms = {"local_encode": round(float(ph[0]), 3), "local_hash": round(float(ph[1]), 3),
                     "exchange_tail_plus_merkle": round(float(ph[2]), 3), "exchange_exposed_ms": round(float(ph[3]), 3),
-                    "column_slices": int(os.environ.get("LCPC_SHARD_SLICES", "1")),
                     "async_tail": not args.no_async_tail,
                     "note": "one instrumented commit in sequence on the launch stream (MAX over ranks): exchange_exposed_ms is the time between "
                             "the end of the local hash and the arrival of the leaf digests, i.e. the wire + leaf-digest time a lone commit "

@@ -1,4 +1,4 @@
-//! Raw declarations of `include/lcpc_hip.h` (ABI version 4): the C ABI of the MI355X-native lcpc-2d commit / prove path.
+//! Raw declarations of `include/lcpc_hip.h` (ABI version 5): the C ABI of the MI355X-native lcpc-2d commit / prove path.
 //!
 //! One item per item of the header, same names, same order of arguments; `tests/test_rust_bindings.py` of the repository
 //! compares this file with the header (symbols, argument types, struct fields, constants) on every run of the CPU test suite,
@@ -11,7 +11,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const LCPC_ABI_VERSION: c_int = 4;
+pub const LCPC_ABI_VERSION: c_int = 5;
 
 // fields of lcpc-test-fields/src/lib.rs:13-59
 pub const LCPC_FT63: u32 = 0;
@@ -97,6 +97,7 @@ pub struct lcpc_timings {
     pub hash_launches: u32,
     pub merkle_launches: u32,
     pub exchange_exposed_ms: f32,
+    pub staged_slices: u32,
 }
 
 pub type lcpc_write_fn = Option<unsafe extern "C" fn(user: *mut c_void, data: *const u8, len: u64) -> c_int>;
@@ -255,29 +256,6 @@ extern "C" {
         proof_len: *mut u64,
         cols_opened: *mut u64,
     ) -> c_int;
-    pub fn lcpc_commit_shard_encode_device(
-        cm: *mut lcpc_commit_t,
-        coeffs_local_dev: *const u64,
-        n_rows_total: u64,
-        stream: *mut c_void,
-        flags: u32,
-    ) -> c_int;
-    pub fn lcpc_commit_shard_hash_device(
-        cm: *mut lcpc_commit_t,
-        col_begin: u64,
-        col_end: u64,
-        stream: *mut c_void,
-        nodes_dev: *mut u8,
-    ) -> c_int;
-    pub fn lcpc_commit_finish_cols_device(
-        cm: *mut lcpc_commit_t,
-        gathered_dev: *mut u8,
-        slots_per_rank: u32,
-        col_begin: u64,
-        col_end: u64,
-        stream: *mut c_void,
-    ) -> c_int;
-    pub fn lcpc_commit_finish_merkle_device(cm: *mut lcpc_commit_t, stream: *mut c_void, root: *mut u8) -> c_int;
     pub fn lcpc_commit_shard_device(
         cm: *mut lcpc_commit_t,
         coeffs_local_dev: *const u64,
@@ -343,6 +321,6 @@ mod tests {
     #[test]
     fn struct_layouts() {
         assert_eq!(std::mem::size_of::<lcpc_params>(), 72);
-        assert_eq!(std::mem::size_of::<lcpc_timings>(), 32);
+        assert_eq!(std::mem::size_of::<lcpc_timings>(), 36);
     }
 }

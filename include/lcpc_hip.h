@@ -31,11 +31,14 @@
 extern "C" {
 #endif
 
-/* 4: lcpc_shard_nodes_field (row sharding for Ft191, whose elements straddle BLAKE3 chunks), LCPC_COMMIT_ASYNC_TAIL.
+/* 5: the four column-range phases of ABI 3 (lcpc_commit_shard_encode_device, lcpc_commit_shard_hash_device,
+ * lcpc_commit_finish_cols_device, lcpc_commit_finish_merkle_device) are gone -- slicing the exchange was measured neutral to
+ * negative (profiles/r04_shard_slices.jsonl) and nothing called them; lcpc_timings.staged_slices.
+ * 4: lcpc_shard_nodes_field (row sharding for Ft191, whose elements straddle BLAKE3 chunks), LCPC_COMMIT_ASYNC_TAIL.
  * 3: the column-range phases of the sharded commit (lcpc_commit_shard_encode_device, lcpc_commit_shard_hash_device,
  * lcpc_commit_finish_cols_device, lcpc_commit_finish_merkle_device), lcpc_timings.exchange_exposed_ms; the LcCommit bincode
  * entry points of round 3.  A caller checks lcpc_abi_version() == LCPC_ABI_VERSION before anything else. */
-#define LCPC_ABI_VERSION 4
+#define LCPC_ABI_VERSION 5
 
 /* fields of lcpc-test-fields/src/lib.rs:13-59 */
 enum { LCPC_FT63 = 0, LCPC_FT127 = 1, LCPC_FT191 = 2, LCPC_FT255 = 3 };
@@ -248,37 +251,20 @@ int  lcpc_comm_init(lcpc_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_
 int  lcpc_comm_destroy(lcpc_ctx *ctx);
 /* whole sharded commit: encode the local rows (coeffs_local_dev = this rank's rows, row-major) and hash their columns down to
  * node chaining values on `stream`, ONE exchange of those (ncclAllGather + grouped ncclBroadcasts for the few ranks that own a
- * second node), leaf digests and the Merkle tree (replicated) -- by default all on `stream`, in sequence.  Two ways to take the
- * wire off the critical path, both bit-identical in result: LCPC_COMMIT_ASYNC_TAIL in `flags` (above: overlap with the NEXT
- * commit's encode; what a prover committing several polynomials wants), and LCPC_SHARD_SLICES=<2..16> when the encoder is
- * created (column slices: the exchange of slice s on the commitment's second stream while `stream` hashes slice s + 1; hides at
- * most the hash time and costs extra launches -- measured neutral to slightly negative, hence off by default).
+ * second node), leaf digests and the Merkle tree (replicated) -- by default all on `stream`, in sequence.  LCPC_COMMIT_ASYNC_TAIL
+ * in `flags` takes the wire off the critical path (above: overlap with the NEXT commit's encode; what a prover committing several
+ * polynomials wants); the result is bit-identical.
  * No host synchronisation unless `root` is non-NULL.  flags: LCPC_COMMIT_BORROW_COEFFS as for lcpc_commit_device.
  * Collectives on one communicator must be issued in the same order on every rank: drive the sharded commits / proves of
  * one encoder from ONE host thread per rank, in the same program order everywhere (the library only keeps two commitments
- * of one process from interleaving their slices). */
+ * of one process from interleaving their exchanges). */
 int  lcpc_commit_sharded_device(lcpc_commit_t *cm, const uint64_t *coeffs_local_dev, uint64_t n_rows_total, void *stream,
                                 uint32_t flags, uint8_t *root);
 /* LcCommit::prove on a sharded commitment with the three all-gathers on RCCL (see lcpc_prove_sharded). */
 int  lcpc_prove_sharded_rccl(lcpc_commit_t *cm, const uint64_t *outer_tensor, uint64_t n_outer, lcpc_transcript *tr,
                              uint8_t **proof, uint64_t *proof_len, uint64_t *cols_opened);
-/* (b) split phases.  The two calls lcpc_commit_shard_device / lcpc_commit_finish_device below are the unsliced form; a
- * caller that wants to overlap ITS collective with the hashing drives the four steps itself, slicing the middle two by
- * column ranges [col_begin, col_end) that together cover [0, n_cols) (any order, any streams the caller orders correctly;
- * all four refer to the commit started by the encode step):
- *   lcpc_commit_shard_encode_device    encode the local rows (lib.rs:648-653)
- *   lcpc_commit_shard_hash_device      columns [col_begin, col_end) of the local rows -> nodes_dev[k][col_end - col_begin][32 B],
- *                                      k < n_nodes of this rank (this rank's part of hash_columns, lib.rs:706-745)
- *   lcpc_commit_finish_cols_device     gathered_dev[slot][col_end - col_begin][32 B] (slots as for lcpc_commit_finish_device;
- *                                      clobbered) -> the leaf digests of those columns
- *   lcpc_commit_finish_merkle_device   the tree above the leaf digests (lib.rs:747-785), root; the commitment is complete */
-int  lcpc_commit_shard_encode_device(lcpc_commit_t *cm, const uint64_t *coeffs_local_dev, uint64_t n_rows_total, void *stream,
-                                     uint32_t flags);
-int  lcpc_commit_shard_hash_device(lcpc_commit_t *cm, uint64_t col_begin, uint64_t col_end, void *stream, uint8_t *nodes_dev);
-int  lcpc_commit_finish_cols_device(lcpc_commit_t *cm, uint8_t *gathered_dev, uint32_t slots_per_rank, uint64_t col_begin,
-                                    uint64_t col_end, void *stream);
-int  lcpc_commit_finish_merkle_device(lcpc_commit_t *cm, void *stream, uint8_t *root);
-/* phase 1, unsliced: encode the local rows (coeffs_dev = local rows only, row-major, padded) and reduce them to one
+/* (b) split phases: a caller with its own collective (torch.distributed, MPI, a test harness). */
+/* phase 1: encode the local rows (coeffs_dev = local rows only, row-major, padded) and reduce them to one
  * BLAKE3 chaining value per (local node, column): nodes_dev[k * n_cols + col][32 B], k < n_nodes. */
 int  lcpc_commit_shard_device(lcpc_commit_t *cm, const uint64_t *coeffs_local_dev, uint64_t n_rows_total,
                               void *stream, uint32_t flags, uint8_t *nodes_dev);
@@ -319,6 +305,10 @@ typedef struct {
    * the arrival of the last slice's leaf digests from the exchange stream (the part of the exchange that is NOT hidden;
    * contained in merkle_ms).  0 elsewhere. */
   float exchange_exposed_ms;
+  /* lcpc_commit (host pointer) only: H2D copies of the last call that were staged through the library's pinned bounce ring because
+   * the source was pageable memory (0: the source was pinned / registered and was copied from directly).  Set with or without
+   * lcpc_set_timing. */
+  uint32_t staged_slices;
 } lcpc_timings;
 int  lcpc_set_timing(lcpc_commit_t *cm, int enable);
 int  lcpc_get_timings(lcpc_commit_t *cm, lcpc_timings *out);

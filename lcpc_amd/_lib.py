@@ -6,7 +6,7 @@ import ctypes as C
 import os
 import subprocess
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblcpc_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
@@ -22,7 +22,7 @@ class LcpcParams(C.Structure):
 class LcpcTimings(C.Structure):
     _fields_ = [("encode_ms", C.c_float), ("hash_ms", C.c_float), ("merkle_ms", C.c_float), ("total_ms", C.c_float),
                 ("encode_launches", C.c_uint32), ("hash_launches", C.c_uint32), ("merkle_launches", C.c_uint32),
-                ("exchange_exposed_ms", C.c_float)]
+                ("exchange_exposed_ms", C.c_float), ("staged_slices", C.c_uint32)]
 
 
 # every symbol include/lcpc_hip.h declares: name -> (restype, argtypes)
@@ -78,10 +78,6 @@ SYMBOLS = {
     "lcpc_comm_destroy": (_i32, [_vp]),
     "lcpc_commit_sharded_device": (_i32, [_vp, _vp, _u64, _vp, _u32, _vp]),
     "lcpc_prove_sharded_rccl": (_i32, [_vp, _vp, _u64, _vp, _vp, _vp, _vp]),
-    "lcpc_commit_shard_encode_device": (_i32, [_vp, _vp, _u64, _vp, _u32]),
-    "lcpc_commit_shard_hash_device": (_i32, [_vp, _u64, _u64, _vp, _vp]),
-    "lcpc_commit_finish_cols_device": (_i32, [_vp, _vp, _u32, _u64, _u64, _vp]),
-    "lcpc_commit_finish_merkle_device": (_i32, [_vp, _vp, _vp]),
     "lcpc_commit_shard_device": (_i32, [_vp, _vp, _u64, _vp, _u32, _vp]),
     "lcpc_commit_finish_device": (_i32, [_vp, _vp, _u64, _u32, _vp, _vp]),
     "lcpc_collapse_device": (_i32, [_vp, _vp, _u32, _vp, _vp]),

@@ -4,6 +4,9 @@
 // collapse_columns (1095-1123) of /root/reference.  Many commitments may be live under one encoder context
 // (lib.rs:299-311 borrow `&E`); each object owns its comm / coeffs / hashes and its scratch.
 #include "internal.h"
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 
 using namespace lcpc;
 
@@ -29,7 +32,7 @@ int ensure_commit_buffers(lcpc_commit_t* m, uint64_t n_rows_local, bool own_coef
     if ((rc = dev_alloc(&m->err, &m->d_coeffs, (size_t)rows * c->n_per_row * eb))) return rc;
     m->cap_coeff_rows = rows;
   }
-  const bool need_comm = !(c->prm.encoding == LCPC_ENC_SDIG && n_rows_local >= sdig_t_min_rows());   // else made on demand (lcpc_get_comm)
+  const bool need_comm = !(c->prm.encoding == LCPC_ENC_SDIG && n_rows_local >= SDIG_T_MIN_ROWS);   // else made on demand (lcpc_get_comm)
   if (need_comm && (rows > m->cap_comm_rows || !m->d_comm)) {
     dev_free(m->d_comm); m->d_comm = nullptr; m->cap_comm_rows = 0;
     if ((rc = dev_alloc(&m->err, &m->d_comm, (size_t)rows * c->n_cols * eb))) return rc;
@@ -43,7 +46,7 @@ static LeafArgs leaf_args(const lcpc_commit_t* m) {
   const lcpc_ctx* c = m->enc;
   LeafArgs la{};
   la.comm = m->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.col_stride = 1; la.n_cols = c->n_cols;
-  if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = c->t_canon ? 1u : 0u; la.row_stride = 1; la.col_stride = m->n_rows_local; }
+  if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = 1u; la.row_stride = 1; la.col_stride = m->n_rows_local; }
   la.n_rows_total = m->n_rows;
   return la;
 }
@@ -86,7 +89,7 @@ static int merkleize_device(lcpc_commit_t* m, hipStream_t st) {
   const uint64_t n_chunks = leaf_chunks(c, m->n_rows);
   LeafArgs la = leaf_args(m);
   la.row_base = 0; la.chunk_begin = 0; la.n_chunks_local = (uint32_t)n_chunks; la.n_chunks_total = (uint32_t)n_chunks;
-  if (c->sw_fused_leaf_tree && leaf_tree_supported(la, c->np2)) {
+  if (leaf_tree_supported(la, c->np2)) {
     // small commitment: leaf digests and the first six levels of the tree in one launch (kernels.hip leaf_tree_kernel)
     HIPCHK(m, launch_leaf_tree(c->NL, la, m->d_hashes, c->np2, st));
     m->launches[1]++;
@@ -135,6 +138,7 @@ static int begin_commit(lcpc_commit_t* m, hipStream_t st, uint64_t n_rows_total,
   m->coeffs_view = nullptr;
   m->n_rows = n_rows_total; m->row_begin = row_begin; m->n_rows_local = n_rows_local;
   m->launches[0] = m->launches[1] = m->launches[2] = 0;
+  m->last.staged_slices = 0;
   return 0;
 }
 
@@ -146,7 +150,7 @@ static int encode_commit(lcpc_commit_t* m, const uint32_t* src, uint64_t n_src_t
   j.src = src; j.src_stride = c->n_per_row; j.n_valid = c->n_per_row; j.dst = m->d_comm; j.n_rows = m->n_rows_local;
   j.n_src_total = n_src_total;
   j.copy_dst = copy_coeffs ? m->d_coeffs : nullptr;
-  j.canon_out = c->prm.encoding == LCPC_ENC_SDIG ? c->t_canon : c->comm_canon;
+  j.canon_out = c->prm.encoding == LCPC_ENC_SDIG ? true : c->comm_canon;
   j.keep_t = true;
   bool kept = false;
   j.kept_t = &kept;
@@ -157,8 +161,8 @@ static int encode_commit(lcpc_commit_t* m, const uint32_t* src, uint64_t n_src_t
 }
 
 // can the first encode pass write the coeffs copy on the fly?  (Ligero: fused into the first NTT pass; Brakedown with
-// >= sdig_t_min_rows() rows: fused into the input transpose)
-static bool fused_copy(const lcpc_ctx* c, uint64_t n_rows_local) { return c->prm.encoding == LCPC_ENC_LIGERO || n_rows_local >= sdig_t_min_rows(); }
+// >= SDIG_T_MIN_ROWS rows: fused into the input transpose)
+static bool fused_copy(const lcpc_ctx* c, uint64_t n_rows_local) { return c->prm.encoding == LCPC_ENC_LIGERO || n_rows_local >= SDIG_T_MIN_ROWS; }
 
 static int commit_tail(lcpc_commit_t* m, hipStream_t st, uint8_t* root) {
   if (m->timing) HIPCHK(m, hipEventRecord(m->ev[1], st));
@@ -257,7 +261,7 @@ int open_columns_device(lcpc_commit_t* m, const uint64_t* d_cols, uint32_t n, ui
   const lcpc_ctx* c = m->enc;
   if (d_vals && m->n_rows_local) {
     if (m->comm_t)
-      HIPCHK(m, launch_gather_columns(c->NL, m->ws.d_t, m->n_rows_local, 1, m->n_rows_local, d_cols, n, d_vals, c->t_canon ? c->d_r2 : nullptr, st));
+      HIPCHK(m, launch_gather_columns(c->NL, m->ws.d_t, m->n_rows_local, 1, m->n_rows_local, d_cols, n, d_vals, c->d_r2, st));
     else
       HIPCHK(m, launch_gather_columns(c->NL, m->d_comm, m->n_rows_local, c->n_cols, 1, d_cols, n, d_vals, c->comm_canon ? c->d_r2 : nullptr, st));
   }
@@ -335,7 +339,8 @@ int lcpc_commit_create(lcpc_ctx* enc, lcpc_commit_t** out) {
 void lcpc_commit_destroy(lcpc_commit_t* m) {
   if (!m) return;
   (void)hipSetDevice(m->enc->prm.device);
-  dev_free(m->d_coeffs); dev_free(m->d_comm); dev_free(m->d_hashes); dev_free(m->d_cvs); dev_free(m->d_scratch); dev_free(m->d_node_tab);
+  dev_free(m->d_coeffs); dev_free(m->d_comm); dev_free(m->d_hashes); dev_free(m->d_cvs); dev_free(m->d_scratch);
+  for (auto& t : m->node_tabs) dev_free(t.d);
   dev_free(m->d_t29); dev_free(m->ws.d_tmp); dev_free(m->ws.d_t); dev_free(m->ws.d_mid); dev_free(m->d_gather); dev_free(m->d_xsend); dev_free(m->d_xrecv);
   for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : m->ev_batch) if (e) (void)hipEventDestroy(e);
@@ -343,7 +348,7 @@ void lcpc_commit_destroy(lcpc_commit_t* m) {
   if (m->h_root) (void)hipHostFree(m->h_root);
   if (m->s_prove) (void)hipStreamDestroy(m->s_prove);
   if (m->s_xchg) (void)hipStreamDestroy(m->s_xchg);
-  for (auto& e : m->ev_slice) if (e) (void)hipEventDestroy(e);
+  if (m->ev_hashed) (void)hipEventDestroy(m->ev_hashed);
   if (m->ev_done) (void)hipEventDestroy(m->ev_done);
   if (m->s_copy) (void)hipStreamDestroy(m->s_copy);
   if (m->s_comp) (void)hipStreamDestroy(m->s_comp);
@@ -389,9 +394,79 @@ int lcpc_commit_device(lcpc_commit_t* m, const uint64_t* coeffs_dev, uint64_t n_
   LCPC_CATCH(m)
 }
 
+// ---- host memory -> HBM ---------------------------------------------------------------------------------------------
+// LcCommit::commit(&coeffs, &enc) (lcpc-2d/src/lib.rs:299-301, 636-645) takes a slice of ordinary -- pageable -- memory.
+// hipMemcpyAsync from such a pointer is neither asynchronous nor fast: the runtime stages it through its own pinned buffer on
+// the calling thread (one core's memcpy rate, the call returns when the data has left), so the row-batch overlap below is lost.
+// upload_host does the staging itself: slices of the source are copied into a ring of pinned bounce buffers by the host pool
+// (streaming stores: the DMA engine is the only reader) while the previous slices cross the bus; every H2D is a true async copy.
+// The caller's memory is never registered (hipHostRegister would pin pages we do not own, and costs more than the copy).
+static bool host_ptr_is_pinned(const void* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // unknown to the runtime = pageable
+  return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeManaged;                           // hipHostMalloc'ed or registered by its owner
+}
+
+static void stream_copy(uint8_t* dst, const uint8_t* src, size_t n) {
+#if defined(__x86_64__)
+  // 64 B per iteration, non-temporal stores (dst is 64-byte aligned: slices start on 4 KiB multiples of a pinned allocation)
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+      __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i)), b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 16));
+      __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 32)), d = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i + 48));
+      _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i), a); _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 16), b);
+      _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 32), c); _mm_stream_si128(reinterpret_cast<__m128i*>(dst + i + 48), d);
+    }
+    _mm_sfence();
+    if (i < n) memcpy(dst + i, src + i, n - i);
+    return;
+  }
+#endif
+  memcpy(dst, src, n);
+}
+
+// bytes of src (host) -> dst (device) on stream st.  Pinned sources: one async copy.  Pageable sources: through the encoder's bounce ring.
+// `total`: bytes of the whole upload this call is a part of (sizes the ring once).  Under c->stage_mu when !pinned.
+static int upload_host(lcpc_commit_t* m, void* dst, const void* src, size_t bytes, size_t total, hipStream_t st, bool pinned) {
+  lcpc_ctx* c = m->enc;
+  if (bytes == 0) return 0;
+  if (pinned) { HIPCHK(m, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return 0; }
+  // Slice = what one H2D command moves.  Measured at 2^26 Ft255 (2 GiB; tools/bench_host_path.py, profiles/r05_host_path.jsonl): 8 MiB
+  // slices 44.4 ms, 16: 42.3, 32: 41.6-42.0, 64: 41.2 (pinned source 40.7; the runtime's own pageable path 40.6 on pages it has
+  // locked before, 44.4 on fresh ones) -- every copy command costs ~15 us of bus idle time, a slice's latency is paid once.
+  constexpr size_t SLICE = (size_t)64 << 20;
+  const size_t want = std::min(SLICE, std::max<size_t>((size_t)4 << 20, (total / 32 + 4095) & ~(size_t)4095));   // small uploads: small buffers
+  if (c->stage_cap < want) {
+    for (unsigned k = 0; k < lcpc_ctx::N_STAGE; k++) {
+      if (c->ev_stage[k]) HIPCHK(m, hipEventSynchronize(c->ev_stage[k]));
+      if (c->h_stage[k]) { (void)hipHostFree(c->h_stage[k]); c->h_stage[k] = nullptr; }
+      c->stage_cap = 0;
+      HIPCHK(m, hipHostMalloc(reinterpret_cast<void**>(&c->h_stage[k]), want, hipHostMallocDefault));
+      if (!c->ev_stage[k]) HIPCHK(m, hipEventCreateWithFlags(&c->ev_stage[k], hipEventDisableTiming));
+    }
+    c->stage_cap = want;
+  }
+  const size_t slice = c->stage_cap;
+  const uint8_t* s = static_cast<const uint8_t*>(src);
+  uint8_t* d = static_cast<uint8_t*>(dst);
+  for (size_t off = 0; off < bytes; off += slice) {
+    const size_t len = std::min(slice, bytes - off);
+    const unsigned k = c->stage_next++ % lcpc_ctx::N_STAGE;
+    HIPCHK(m, hipEventSynchronize(c->ev_stage[k]));                 // the copy that last read this buffer has left it (a fresh event is complete)
+    uint8_t* hb = c->h_stage[k];
+    const uint8_t* sp = s + off;
+    parallel_for(len, (size_t)256 << 10, [&](uint64_t b, uint64_t e) { stream_copy(hb + b, sp + b, (size_t)(e - b)); });
+    HIPCHK(m, hipMemcpyAsync(d + off, hb, len, hipMemcpyHostToDevice, st));
+    HIPCHK(m, hipEventRecord(c->ev_stage[k], st));
+    m->last.staged_slices++;
+  }
+  return 0;
+}
+
 int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uint8_t* root) {
   if (!m || !coeffs || n_coeffs == 0) return LCPC_ERR_ARG;
-  const lcpc_ctx* c = m->enc;
+  lcpc_ctx* c = m->enc;
   if (c->prm.shard_count > 1) return LCPC_ERR_STATE;
   LCPC_TRY
   std::lock_guard<std::mutex> g(m->mu);
@@ -403,9 +478,15 @@ int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uin
   const size_t eb = elem_bytes(c);
   const uint64_t padded = n_rows * c->n_per_row;
   const size_t total_bytes = (size_t)n_coeffs * eb;
+  // pageable source (a Rust Vec, malloc, numpy): staged through pinned bounce buffers by the host pool; small ones are not worth the ring
+  const bool pinned = c->sw_host_stage == 0 || (c->sw_host_stage < 0 && (total_bytes < ((size_t)4 << 20) || host_ptr_is_pinned(coeffs)));
   // Small inputs, Brakedown (whole-matrix transposes) and timing runs: one copy, then the resident path.
   if (c->prm.encoding != LCPC_ENC_LIGERO || total_bytes < ((size_t)64 << 20) || n_rows < 16 || m->timing) {
-    HIPCHK(m, hipMemcpyAsync(m->d_coeffs, coeffs, total_bytes, hipMemcpyHostToDevice, nullptr));
+    {
+      std::unique_lock<std::mutex> sg(c->stage_mu, std::defer_lock);
+      if (!pinned) sg.lock();
+      if ((rc = upload_host(m, m->d_coeffs, coeffs, total_bytes, total_bytes, nullptr, pinned))) return rc;
+    }
     if (padded > n_coeffs)
       HIPCHK(m, hipMemsetAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + total_bytes, 0, (size_t)(padded - n_coeffs) * eb, nullptr));
     if (m->timing) HIPCHK(m, hipEventRecord(m->ev[0], nullptr));
@@ -430,14 +511,15 @@ int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uin
   if (padded > n_coeffs)
     HIPCHK(m, hipMemsetAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + total_bytes, 0, (size_t)(padded - n_coeffs) * eb, m->s_copy));
   const uint64_t rows_per = (n_rows + NB - 1) / NB;
+  std::unique_lock<std::mutex> sg(c->stage_mu, std::defer_lock);
+  if (!pinned) sg.lock();                                  // one pageable upload at a time per encoder (they share the ring and the bus)
   for (int b = 0; b < NB; b++) {
     const uint64_t r0 = (uint64_t)b * rows_per;
     if (r0 >= n_rows) break;
     const uint64_t r1 = r0 + rows_per < n_rows ? r0 + rows_per : n_rows;
     const uint64_t e0 = r0 * c->n_per_row, e1 = r1 * c->n_per_row < n_coeffs ? r1 * c->n_per_row : n_coeffs;
-    if (e1 > e0)
-      HIPCHK(m, hipMemcpyAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + (size_t)e0 * eb, reinterpret_cast<const uint8_t*>(coeffs) + (size_t)e0 * eb,
-                               (size_t)(e1 - e0) * eb, hipMemcpyHostToDevice, m->s_copy));
+    if (e1 > e0 && (rc = upload_host(m, reinterpret_cast<uint8_t*>(m->d_coeffs) + (size_t)e0 * eb, reinterpret_cast<const uint8_t*>(coeffs) + (size_t)e0 * eb,
+                                     (size_t)(e1 - e0) * eb, total_bytes, m->s_copy, pinned))) return rc;
     HIPCHK(m, hipEventRecord(m->ev_batch[b], m->s_copy));
     HIPCHK(m, hipStreamWaitEvent(m->s_comp, m->ev_batch[b], 0));
     EncodeJob j;
@@ -652,7 +734,7 @@ int lcpc_get_comm(lcpc_commit_t* m, uint64_t row0, uint64_t n, uint64_t* out) {
     m->comm_rows_valid = true;
   }
   const uint32_t* src = m->d_comm + (size_t)(row0 - m->row_begin) * c->n_cols * c->NL;
-  if (!(m->comm_t ? c->t_canon : c->comm_canon)) {
+  if (!(m->comm_t || c->comm_canon)) {
     HIPCHK(m, hipMemcpy(out, src, (size_t)n * c->n_cols * eb, hipMemcpyDeviceToHost));
     return 0;
   }

@@ -12,11 +12,6 @@ using namespace lcpc;
 
 namespace lcpc {
 
-uint64_t sdig_t_min_rows() {
-  static const uint64_t v = getenv("LCPC_SDIG_T_MIN_ROWS") ? strtoull(getenv("LCPC_SDIG_T_MIN_ROWS"), nullptr, 10) : 24;
-  return v;
-}
-
 
 const uint8_t LBL_DT[7] = "$l//DT", LBL_PR[7] = "$l//PR", LBL_PE[7] = "$l//PE", LBL_CO[7] = "$l//CO";  // macros.rs:31-34
 
@@ -29,6 +24,10 @@ static void ctx_free(lcpc_ctx* c) {
   dev_free(c->d_rootsl); dev_free(c->d_rootslc); dev_free(c->d_qpl); dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
   dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->ws.d_mid); dev_free(c->d_scratch);
   if (c->h_varena) (void)hipHostFree(c->h_varena);
+  for (unsigned k = 0; k < lcpc_ctx::N_STAGE; k++) {
+    if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
+    if (c->ev_stage[k]) (void)hipEventDestroy(c->ev_stage[k]);
+  }
   for (auto* v : {&c->d_pre, &c->d_post})
     for (auto& d : *v) { dev_free(d.rowptr); dev_free(d.colidx); dev_free(d.vals); dev_free(d.vals29); }
   delete c;
@@ -72,7 +71,7 @@ static void plan_passes(lcpc_ctx* c) {
   }
   int LT = lt_small;
   auto n_pass = [&](int lt) { unsigned per = lt - ltj_min, rest = k - lt; return 1 + (rest + per - 1) / per; };
-  if (c->d_qp29 && (k == 19 || k == 20) && !getenv("LCPC_NTT_GENERAL") && !getenv("LCPC_NTT_TILE2048")) {
+  if (c->d_qp29 && (k == 19 || k == 20) && !c->sw_ntt_general) {
     // Ft255, 2^19 / 2^20 columns (C4's shape): still two passes on 1024-element tiles for the shape-specialised kernel,
     // whose first pass then moves 64- / 32-byte runs -- affordable because the tiles that share those cache lines run back
     // to back on one XCD (ntt_tile_group below; measured: DESIGN.md section 4 K1s)
@@ -98,17 +97,15 @@ static void plan_passes(lcpc_ctx* c) {
 // workgroups of one XCD.  Its strided runs are run_bytes = F << log_tj long; grouping makes the span that one XCD works on at a
 // time 1 KiB (2 KiB for runs of <= 32 bytes), which is what measured best (build-time A/B in one process, DESIGN.md K1s: n_cols
 // 2^20 -27 % on boxes where the ungrouped order is slow, -4 % elsewhere; 2^19 -3 %; the headline's 128-byte runs -0.5 to -1 %).
-// LCPC_NTT_TILE_GROUP=<log2> at context creation overrides (0 = the plain XCD-aware order)
-static uint32_t ntt_tile_group_of(const lcpc_ctx* c, uint32_t log_n, int L, uint32_t log_tj) {
+static uint32_t ntt_tile_group_of(uint32_t log_n, int L, uint32_t log_tj) {
   const uint32_t tiles_log = log_n - 10;
   if (tiles_log < 3) return 0;
   uint32_t run_log = log_tj;                                              // log2(run bytes)
   for (uint32_t b = 8u * (uint32_t)L; b > 1; b >>= 1) run_log++;
   uint32_t lg = run_log <= 5 ? 11 - run_log : (run_log < 10 ? 10 - run_log : 0);
-  if (c->sw_ntt_tile_group >= 0) lg = (uint32_t)c->sw_ntt_tile_group;
   return std::min(std::min(lg, 6u), tiles_log - 3);
 }
-static uint32_t ntt_tile_group(const lcpc_ctx* c, const Pass& first) { return ntt_tile_group_of(c, c->log_n, c->L, first.log_tj); }
+static uint32_t ntt_tile_group(const lcpc_ctx* c, const Pass& first) { return ntt_tile_group_of(c->log_n, c->L, first.log_tj); }
 
 #define ECHK(call)                                                        \
   do {                                                                    \
@@ -129,8 +126,8 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
     uint64_t rb = ws->mid_failed ? 0 : ntt_mid_rows(c, n_rows);
     if (rb) {
       std::string scratch_err;
-      // (test hook sw_debug_fail_mid: an allocation no device can satisfy, so that the real failure path runs)
-      const uint64_t want = c->sw_debug_fail_mid ? ((uint64_t)1 << 62) : rb * c->n_cols * 36;
+      // (test hook sw_test_fail_mid: an allocation no device can satisfy, so that the real failure path runs)
+      const uint64_t want = c->sw_test_fail_mid ? ((uint64_t)1 << 62) : rb * c->n_cols * 36;
       if (ensure_dev(&scratch_err, &ws->d_mid, &ws->mid_cap, want)) {
         (void)hipGetLastError();           // HIP keeps a failed call's error until it is read: it must not surface at the next launch check
         ws->mid_failed = true; ws->mid_cap = 0; rb = 0;
@@ -189,7 +186,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.n_rows = first ? n_rows : n_rows << s0;
       a.log_n = first ? c->log_n : 20u;
       a.t0 = i == 2 ? 10u : 0u; a.s = p.s; a.log_tj = p.log_tj;
-      a.tile_group = i == 0 ? ntt_tile_group_of(c, c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(c, 20, c->L, 0) : 0u);
+      a.tile_group = i == 0 ? ntt_tile_group_of(c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(20, c->L, 0) : 0u);
       ECHK(launch_ntt_pass_l9s(a, i < 2, c->d_pack[i], c->pack_info[i], st));
       nl++;
     }
@@ -216,7 +213,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.n_rows = first ? n_rows : n_rows << s0;
       a.log_n = first ? c->log_n : 20u;
       a.t0 = i == 2 ? 10u : 0u; a.s = p.s; a.log_tj = p.log_tj;
-      a.tile_group = i == 0 ? ntt_tile_group_of(c, c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(c, 20, c->L, 0) : 0u);
+      a.tile_group = i == 0 ? ntt_tile_group_of(c->log_n, c->L, p.log_tj) : (i == 1 ? ntt_tile_group_of(20, c->L, 0) : 0u);
       ECHK(launch_ntt_pass_lns(c->NL, a, i < 2, c->d_pack[i], c->pack_info[i], st));
       nl++;
     }
@@ -278,14 +275,14 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
   // (capacities in BYTES: ensure_dev rounds to 256, and a capacity kept in elements loses the remainder for 24-byte elements --
   // Ft191 then re-allocated, i.e. hipFree-synchronised, on every call)
   if (int rc = ensure_dev(err, &ws->d_tmp, &ws->tmp_cap, n_rows * pl.n_out * eb)) return rc;
-  if (n_rows >= sdig_t_min_rows()) {
+  if (n_rows >= SDIG_T_MIN_ROWS) {
     // fast path: position-major working copy T[pos][row] (lane = row: contiguous gathers, wave-uniform matrix)
     if (int rc = ensure_dev(err, &ws->d_t, &ws->t_cap, n_rows * c->n_cols * eb)) return rc;
     ECHK(launch_transpose_to_t(c->NL, j.src, j.src_stride, j.n_valid, n_rows, ws->d_t, st, j.n_src_total, j.copy_dst, j.canon_out && j.keep_t));
     nl++;
     uint64_t in_start = 0;
     SpmmTArgs a{};
-    a.t = ws->d_t; a.n_rows = n_rows; a.tail_on = c->sw_sdig_tail; a.row_group = c->sw_sdig_row_group; a.price = c->sw_debug_k2_price;
+    a.t = ws->d_t; a.n_rows = n_rows;
     auto set_mat = [&](const DevCsr& m) { a.rowptr = m.rowptr; a.colidx = m.colidx; a.vals = m.vals; a.vals29 = m.vals29; a.m = m.n_out; };
     for (size_t i = 0; i + 1 < t; i++) {
       const uint64_t in_end = in_start + c->d_pre[i].n_in;
@@ -484,7 +481,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       dev_free(d_pw); dev_free(d_one);
       if (he != hipSuccess) return fail_hip(err, he, "precomp_fft");
     }
-    if (f->L == 4 && !getenv("LCPC_NTT_PACKED")) {
+    if (f->L == 4) {
       // (i - 24) * p for i < 64 as normalised signed 29-bit limbs (limbs 0..7 in [0, 2^29), limb 8 two's complement):
       // the table behind l9::clamp (lazy-limb NTT kernel; QOFF in field_dev.h)
       std::vector<uint32_t> tab(64 * 12, 0);
@@ -506,12 +503,12 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       }
       if ((rc = dev_alloc(err, &c->d_qp29, tab.size() * 4))) return rc;
       HIPCHK(c, hipMemcpy(c->d_qp29, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
-      c->comm_canon = !getenv("LCPC_COMM_MONT");
+      c->comm_canon = true;
     }
     if ((rc = dev_alloc(err, &c->d_r2, 8 * f->L))) return rc;
     HIPCHK(c, hipMemcpy(c->d_r2, f->r2, 8 * f->L, hipMemcpyHostToDevice));
     plan_passes(c);
-    if (c->d_qp29 && !getenv("LCPC_NTT_GENERAL") && ntt_l9s_supported(c->log_n, (uint32_t)c->passes.size(), c->passes[0].log_tile)) {
+    if (c->d_qp29 && !c->sw_ntt_general && ntt_l9s_supported(c->log_n, (uint32_t)c->passes.size(), c->passes[0].log_tile)) {
       // two passes on 1024-element tiles: the shape-specialised kernel with its lane-order twiddle packs
       for (int i = 0; i < 2; i++) {
         const Pass& ps = c->passes[i];
@@ -525,7 +522,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       }
       HIPCHK(c, hipDeviceSynchronize());
       c->l9s = true;
-    } else if (c->d_qp29 && !getenv("LCPC_NTT_GENERAL") && !getenv("LCPC_NTT_NO_3PASS") && ntt_l9s3_supported(c->log_n)) {
+    } else if (c->d_qp29 && !c->sw_ntt_general && ntt_l9s3_supported(c->log_n)) {
       // three passes of the shape-specialised kernel (kernels.h ntt_l9s3_supported): tables for the 2^20-point sub-transforms,
       // pack 0 for the first pass over the whole rows (one class per tile position: 2^(log_n - 10)), packs 1 / 2 = those of a
       // 2^20-column context
@@ -551,7 +548,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
           a.log_n = i == 0 ? k : 20u; a.t0 = i == 2 ? 10u : 0u; a.s = ps.s; a.log_tj = ps.log_tj;
           c->pack_info[i] = ntt_l9s_pack_info(ps.s, first);
           const uint32_t n_classes = i == 0 ? 1u << (k - 10) : (i == 1 ? 1024u : 1u);
-          if (i == 0 && getenv("LCPC_DEBUG_FAIL_3PASS")) return LCPC_ERR_NOMEM;       // (test hook: the fallback below)
+          if (i == 0 && c->sw_test_fail_3pass) return LCPC_ERR_NOMEM;       // (test hook: the fallback below)
           if ((r = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return r;
           HIPCHK(c, launch_ntt_l9s_pack(a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
         }
@@ -572,8 +569,8 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
         return brc;
       }
     }
-    const bool lns3 = !c->d_qp29 && !getenv("LCPC_NTT_GENERAL") && !getenv("LCPC_NTT_NO_3PASS") && ntt_lns3_supported(c->NL, c->log_n);
-    if (!c->d_qp29 && c->passes.size() >= 2 && !getenv("LCPC_NTT_GENERAL") && (ntt_lns_supported(c->NL, c->log_n) || lns3)) {
+    const bool lns3 = !c->d_qp29 && !c->sw_ntt_general && ntt_lns3_supported(c->NL, c->log_n);
+    if (!c->d_qp29 && c->passes.size() >= 2 && !c->sw_ntt_general && (ntt_lns_supported(c->NL, c->log_n) || lns3)) {
       // Ft63 / Ft127 / Ft191 rows that need more than one pass: two passes on 1024-element tiles with the lazy-limb
       // kernel (ntt_lns.hip), its twiddle table in limb form (w^i R' mod p), the clamp table and the lane-order packs
       const std::vector<Pass> general_plan = c->passes;      // (if the tables do not fit the device: the general kernel, as for l9s3)
@@ -640,7 +637,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
           a.log_n = sub ? 20u : k; a.t0 = sub ? (i == 2 ? 10u : 0u) : ps.t0; a.s = ps.s; a.log_tj = ps.log_tj;
           c->pack_info[i] = ntt_lns_pack_info(c->NL, ps.s, first);
           const uint32_t n_classes = !first ? 1u : (sub ? 1024u : 1u << (k - 10));
-          if (lns3 && i == 0 && getenv("LCPC_DEBUG_FAIL_3PASS")) return LCPC_ERR_NOMEM;   // (test hook: the fallback below)
+          if (lns3 && i == 0 && c->sw_test_fail_3pass) return LCPC_ERR_NOMEM;   // (test hook: the fallback below)
           if ((rc_ = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return rc_;
           HIPCHK(c, launch_ntt_lns_pack(c->NL, a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
         }
@@ -660,7 +657,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       if (brc) return brc;
       c->lns = !lns3;
       c->lns3 = lns3;
-      c->comm_canon = !getenv("LCPC_COMM_MONT");               // commits keep comm canonical on the device, as for Ft255
+      c->comm_canon = true;                                    // commits keep comm canonical on the device, as for Ft255
     }
     return 0;
   }
@@ -671,7 +668,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
     if (!sdig_n_per_row(*f, p->n_coeffs, (int)c->prm.sdig_code, &npr)) return LCPC_ERR_ARG;
   }
   std::vector<CsrMatrix> pre, post;
-  const bool dbg = getenv("LCPC_DEBUG_TIMING") != nullptr;
+  const bool dbg = c->sw_debug_timing;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_gen0 = now();
   if (!sdig_generate(*f, c->spec, npr, p->seed, pre, post, c->pre_dims, c->post_dims)) return LCPC_ERR_DIMS;
@@ -680,7 +677,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
   c->n_cols = sdig_codeword_length(c->pre_dims, c->post_dims);
   if (p->n_per_row && p->n_cols && p->n_cols != c->n_cols) return LCPC_ERR_DIMS;   // new_from_dims assert
   uint32_t* d_rprime = nullptr;          // R' = 2^(N W) mod p as a plain integer (Ft127 / Ft191 limb form)
-  if ((f->L == 2 || f->L == 3) && !getenv("LCPC_SDIG_WIDE")) {
+  if (f->L == 2 || f->L == 3) {
     uint64_t rp[MAXL] = {1, 0, 0, 0};
     for (int i = 0; i < ntt_lns_limbs(c->NL) * ntt_lns_limb_bits(c->NL); i++) h_add(*f, rp, rp, rp);
     if ((rc = dev_alloc(err, &d_rprime, 8 * f->L))) return rc;
@@ -717,7 +714,6 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
   if (!rc) rc = dev_alloc(err, &c->d_r2, 8 * f->L);
   if (rc) return rc;
   HIPCHK(c, hipMemcpy(c->d_r2, f->r2, 8 * f->L, hipMemcpyHostToDevice));
-  c->t_canon = !getenv("LCPC_COMM_MONT");                  // commits keep the position-major commitment canonical (kernels.hip transpose_to_t_kernel)
   if (dbg) fprintf(stderr, "[SdigEncoding::new] matgen %.1f ms, convert + upload %.1f ms\n", t_gen1 - t_gen0, now() - t_gen1);
   return 0;
 }
@@ -736,14 +732,15 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
   c->prm = *p;
   c->f = f; c->L = f->L; c->NL = 2 * f->L;
   if (c->prm.sdig_code == 0) c->prm.sdig_code = 3;
+  // the switches: read here, once per context, never on a launch path
+  c->sw_ntt_general = getenv("LCPC_NTT_GENERAL") != nullptr;
   if (const char* ev = getenv("LCPC_NTT_MID_MAX_MB")) c->sw_ntt_mid_max_mb = (int64_t)strtoull(ev, nullptr, 10);
-  if (const char* ev = getenv("LCPC_NTT_TILE_GROUP")) c->sw_ntt_tile_group = (int32_t)strtoul(ev, nullptr, 10);
-  c->sw_sdig_tail = !getenv("LCPC_SDIG_NO_TAIL");
-  c->sw_debug_fail_mid = getenv("LCPC_DEBUG_FAIL_MID") != nullptr;
-  c->sw_fused_leaf_tree = !getenv("LCPC_NO_FUSED_LEAF_TREE");
-  if (const char* ev = getenv("LCPC_DEBUG_K2_PRICE")) c->sw_debug_k2_price = (uint32_t)strtoul(ev, nullptr, 10);
-  if (const char* ev = getenv("LCPC_SDIG_ROW_GROUP")) c->sw_sdig_row_group = std::min<uint32_t>(64, (uint32_t)strtoul(ev, nullptr, 10));
-  if (const char* ev = getenv("LCPC_SHARD_SLICES")) c->shard_slices = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)strtoul(ev, nullptr, 10), LCPC_MAX_SHARD_SLICES));
+  if (const char* ev = getenv("LCPC_HOST_STAGE")) c->sw_host_stage = (int32_t)strtol(ev, nullptr, 10);
+  c->sw_debug_timing = getenv("LCPC_DEBUG_TIMING") != nullptr;
+  if (const char* ev = getenv("LCPC_TEST_FAIL")) {           // test hook: "3pass", "mid" (comma-separated) -- forced allocation failures
+    c->sw_test_fail_3pass = strstr(ev, "3pass") != nullptr;
+    c->sw_test_fail_mid = strstr(ev, "mid") != nullptr;
+  }
   int rc = 0;
   // (row shards begin where a BLAKE3 chunk boundary of the leaf message is also a row boundary: every chunk for Ft63 / Ft127 /
   // Ft255, every third chunk for Ft191 -- shard.cpp shard_chunk_range)

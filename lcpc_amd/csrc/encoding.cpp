@@ -424,13 +424,9 @@ void gen_level(const FieldDesc& f, uint64_t seed, uint64_t level, const LevelDim
     p_acc = ptop / range;
   }
   const double per_entry = 1.02 + (double)f.L / p_acc;
-  const bool dbg = getenv("LCPC_DEBUG_TIMING") != nullptr && level == 0;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double tt[5] = {now(), 0, 0, 0, 0};
   ks.ensure((uint64_t)((double)(pd.n * pd.d + qd.n * qd.d) * per_entry * 1.01) + 65536);
   auto need = [&](uint64_t bound) { if (bound > ks.n_valid) ks.ensure(bound + 65536); };
   uint64_t pos = 0;
-  tt[1] = now();
   for (MatJob& j : jobs) {                                     // step 2: positions of the chunks
     const uint64_t target_chunks = 64;
     j.chunk = std::max<uint64_t>(64, (j.n + target_chunks - 1) / target_chunks);
@@ -440,7 +436,6 @@ void gen_level(const FieldDesc& f, uint64_t seed, uint64_t level, const LevelDim
       pos = gen_columns<false>(f, const_cast<const uint64_t* const&>(ks.w), pos, c0, std::min(j.n, c0 + j.chunk), um, j.d, nullptr, nullptr, need);
     }
   }
-  tt[2] = now();
   RawBuf<uint32_t> ridx;                                       // one pair of entry buffers serves both matrices (no fresh pages)
   RawBuf<uint64_t> vals;
   ridx.alloc(std::max(jobs[0].n * jobs[0].d, jobs[1].n * jobs[1].d));
@@ -451,13 +446,8 @@ void gen_level(const FieldDesc& f, uint64_t seed, uint64_t level, const LevelDim
       for (uint64_t ch = a; ch < b; ch++)
         gen_columns<true>(f, const_cast<const uint64_t* const&>(ks.w), j.start[ch], ch * j.chunk, std::min(j.n, (ch + 1) * j.chunk), um, j.d, ridx.data(), vals.data(), [](uint64_t) {});
     });
-    const double t0 = now();
     transpose_to_csr(f, j, ridx, vals);
-    tt[3] += now() - t0;
   }
-  if (dbg)
-    fprintf(stderr, "[matgen level 0] keystream %.1f ms (%.0f M values), position pass %.1f, generate %.1f, transpose %.1f\n", tt[1] - tt[0],
-            (double)ks.n_valid / 1e6, tt[2] - tt[1], now() - tt[2] - tt[3], tt[3]);
 }
 
 }  // namespace

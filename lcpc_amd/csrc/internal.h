@@ -50,8 +50,8 @@ struct EncodeWs {
 uint64_t ntt_mid_rows(const lcpc_ctx* c, uint64_t n_rows);
 
 // Brakedown: from this many rows on the rows are encoded on a position-major copy (lane = row); below, row-major with
-// lanes over outputs and terms.  LCPC_SDIG_T_MIN_ROWS overrides (A/B only).
-uint64_t sdig_t_min_rows();
+// lanes over outputs and terms
+constexpr uint64_t SDIG_T_MIN_ROWS = 24;
 
 // proof buffers (prove.cpp): lcpc_free hands them back; one is kept for the next proof
 void* proof_buf_alloc(size_t n);
@@ -64,21 +64,15 @@ struct lcpc_transcript {
   lcpc_transcript(const uint8_t* l, size_t n) : t(l, n) {}
 };
 
-constexpr uint32_t LCPC_MAX_SHARD_SLICES = 16;
-
 struct lcpc_ctx {
   lcpc_params prm{};
   // A/B switches, read from the environment ONCE, when the context is created (never on a launch path: getenv next to a
   // setenv of another thread is undefined behaviour, and a context must not change plans under a running commit)
+  bool sw_ntt_general = false;     // LCPC_NTT_GENERAL: every Ligero row on the general kernel (K1) instead of the shape-specialised plans
   int64_t sw_ntt_mid_max_mb = -1;  // LCPC_NTT_MID_MAX_MB: -1 = the default rule of ntt_mid_rows
-  int32_t sw_ntt_tile_group = -1;  // LCPC_NTT_TILE_GROUP: -1 = the default rule of ntt_tile_group_of
-  bool sw_sdig_tail = true;        // LCPC_SDIG_NO_TAIL unset
-  uint32_t sw_sdig_row_group = 0;  // LCPC_SDIG_ROW_GROUP: Brakedown Ft255 wide levels in row groups of <= this many rows (0 = off)
-  bool sw_fused_leaf_tree = true;  // LCPC_NO_FUSED_LEAF_TREE unset: small commitments hash their columns and fold six tree levels in one launch
-  uint32_t sw_debug_k2_price = 0;  // LCPC_DEBUG_K2_PRICE (experiment, wrong results): price of a limb-form T in the wide SpMM levels
-  bool sw_debug_fail_mid = false;  // LCPC_DEBUG_FAIL_MID (test hook): the K1s limb-intermediate allocation fails -> packed intermediate
-  uint32_t shard_slices = 1;       // native sharded commit: column slices whose exchange overlaps the next slice's hashing
-                                   // (LCPC_SHARD_SLICES at context creation; 1, the default = everything in sequence on one stream)
+  bool sw_debug_timing = false;    // LCPC_DEBUG_TIMING: phase times of construction / prove / verify on stderr
+  bool sw_test_fail_3pass = false; // LCPC_TEST_FAIL=3pass (test hook): the three-pass plan's tables "do not fit" -> the general kernel's plan
+  bool sw_test_fail_mid = false;   // LCPC_TEST_FAIL=mid (test hook): the K1s limb-intermediate allocation fails -> packed intermediate
   const lcpc::FieldDesc* f = nullptr;
   int L = 0, NL = 0;
   uint64_t n_per_row = 0, n_cols = 0, np2 = 0;
@@ -89,8 +83,8 @@ struct lcpc_ctx {
   uint32_t* d_roots29 = nullptr;   // Ft255: twiddles in radix-2^29 / R'=2^261 Montgomery form (field_dev.h fe_mul_r29)
   uint32_t* d_qp29 = nullptr;      // Ft255: q*p as 29-bit limbs (l9::clamp); null = packed-form NTT kernel
   uint32_t* d_roots29c = nullptr;  // Ft255 lazy-limb kernel: w^i * 2^5, the table that converts to canonical on the fly
-  bool t_canon = false;            // Brakedown: the position-major commitment of a commit (ws.d_t, >= sdig_t_min_rows() rows) holds
-                                   // canonical values: converted once in the input transpose, kept by every (linear) level
+                                   // (Brakedown: the position-major commitment of a commit -- ws.d_t, >= SDIG_T_MIN_ROWS rows -- always holds
+                                   // canonical values: converted once in the input transpose, kept by every (linear) level)
   bool comm_canon = false;         // d_comm of a commit holds canonical values (x * R^-1), not Montgomery form: the column
                                    // hash reads them as they are; every read-out (get_comm, open_columns) converts back
   std::vector<lcpc::Pass> passes;
@@ -131,6 +125,15 @@ struct lcpc_ctx {
   std::mutex verify_mu;            // held for a whole lcpc_verify call
   uint8_t* h_varena = nullptr;
   size_t h_varena_cap = 0;
+  // lcpc_commit from PAGEABLE host memory (commit.cpp upload_host): a ring of pinned bounce buffers the host pool fills while
+  // the previous slices cross the bus.  Held (stage_mu) for the whole upload of one commit; kept between commits.
+  std::mutex stage_mu;
+  static constexpr unsigned N_STAGE = 4;
+  uint8_t* h_stage[N_STAGE] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_stage[N_STAGE] = {nullptr, nullptr, nullptr, nullptr};   // the H2D copy that last read h_stage[k]
+  size_t stage_cap = 0;            // bytes per buffer
+  unsigned stage_next = 0;
+  int32_t sw_host_stage = -1;      // LCPC_HOST_STAGE: 0 = never stage (the runtime's own pageable path), 1 = always stage, -1 (unset) = by pointer attributes
 };
 
 struct lcpc_commit_s {
@@ -148,9 +151,11 @@ struct lcpc_commit_s {
                                    // element (row, col) at (col * n_rows_local + row)); hash / open read it there, d_comm is only
                                    // filled on demand (lcpc_get_comm) -- no back-transpose on the commit path
   bool comm_rows_valid = false;    // d_comm holds the row-major copy of the commitment in ws.d_t
-  uint32_t* d_node_tab = nullptr;  // sharded finish: node_slot[0..n) then node_log[0..n)
+  uint32_t* d_node_tab = nullptr;  // sharded finish: node_slot[0..n) then node_log[0..n) -- the current shape's entry of node_tabs
   uint64_t node_tab_key = 0;
   std::vector<uint32_t> node_slot_h, node_log_h;
+  struct NodeTab { uint64_t key; uint32_t* d; std::vector<uint32_t> slot, lg; };
+  std::vector<NodeTab> node_tabs;  // one device table per shape seen, freed with the object (never while a finish step may read it)
   uint8_t* d_gather = nullptr;     // native sharded commit (lcpc_commit_sharded_device): this rank's nodes + the all-gather output
   uint64_t gather_cap = 0;
   uint8_t *d_xsend = nullptr, *d_xrecv = nullptr;   // native sharded prove: exchange buffers
@@ -170,9 +175,9 @@ struct lcpc_commit_s {
                                    // the leaf digests (sharded commit: behind the exchange)
   hipStream_t s_prove = nullptr;   // sharded prove: its device steps and the native exchange, ordered behind the commit by ev_done
   hipEvent_t ev_done = nullptr;    // recorded on the commit's stream when a sharded commit has been enqueued completely
-  // native sharded commit, sliced (shard.cpp): the exchange stream and the per-slice hand-over events ([S] = the way back)
+  // native sharded commit (shard.cpp): the exchange stream of an async tail and its hand-over event
   hipStream_t s_xchg = nullptr;
-  hipEvent_t ev_slice[LCPC_MAX_SHARD_SLICES + 1] = {nullptr};
+  hipEvent_t ev_hashed = nullptr;  // recorded on the caller's stream behind the local column hash; s_xchg waits for it
   bool shard_encoded = false;      // split phases: the encode step of a sharded commit has been enqueued, hash / finish / merkle may follow
   hipStream_t s_copy = nullptr, s_comp = nullptr;   // lcpc_commit (host pointer): H2D of row batch b+1 overlaps the NTTs of batch b
   hipEvent_t ev_batch[16] = {nullptr};

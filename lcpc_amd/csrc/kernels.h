@@ -158,10 +158,6 @@ struct SpmmTArgs {
   const uint32_t* vals;         // [nnz][NL]  Montgomery (R = 2^(32 NL))
   const uint32_t* vals29;       // Ft255: [nnz][12]  value * 2^261 mod p as 9 x 29-bit limbs
   uint64_t m;
-  bool tail_on = true;          // a last group of <= 48 rows runs on spmm_t_tail_kernel (false: A/B switch LCPC_SDIG_NO_TAIL of the context)
-  uint32_t price = 0;           // experiment LCPC_DEBUG_K2_PRICE (timing only, results wrong): see spmm_t_terms
-  uint32_t row_group = 0;       // > 0 (Ft255, wide levels): the rows are taken in groups of <= row_group (<= 64), one launch of the packed
-                                // (output, row) kernel per group, so that one group's gather range can stay in the Infinity Cache
 };
 hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st);
 hipError_t launch_sdig_rs_t(int nl, const uint32_t* in_t, uint32_t n_in, uint32_t* t, uint64_t out_off, uint32_t n_out,

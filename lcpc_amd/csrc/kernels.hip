@@ -1287,22 +1287,10 @@ hipError_t launch_transpose_from_t(int nl, const u32* t, u64 n_pos, u64 n_rows, 
 
 typedef u32 __attribute__((address_space(4))) ConstU32;
 // one output's partial dot product over terms [k0, k1) of its CSR row (wave-uniform bounds), gathered from column rr
-// PRICE (experiment, LCPC_DEBUG_K2_PRICE at context creation; results are WRONG for PRICE > 0, timing only): what a limb-form T
-// would cost -- 1: the gathered operand is taken as 9 limbs without the packed -> 29-bit conversion; 2: as 1, plus one more
-// dword per operand read from a [pos][row] plane (the ninth limb's bytes)
-template <int PRICE> __device__ __forceinline__ Fe29 price_to29(const Fe<8>& x, u32 extra) {
-  if constexpr (PRICE == 0) return fe_to29(x);
-  Fe29 r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = x.v[i];
-  r.v[8] = extra;
-  return r;
-}
-template <int NL, int PRICE = 0>
+template <int NL>
 __device__ __forceinline__ Fe<NL> spmm_t_terms(const SpmmTArgs& a, const u32* xin, size_t pstride, u32 k0, u32 k1) {
   Fe<NL> res = fe_zero<NL>();
   if constexpr (NL == 8) {
-    const u32* plane = a.t + (size_t)(a.in_off + a.m) * a.n_rows * 8 + (xin - (a.t + (size_t)a.in_off * a.n_rows * 8)) / 8;   // (PRICE 2)
     // The matrix is read through the constant address space: its wave-uniform addresses become scalar loads (s_load
     // into SGPRs, which the multiplier takes directly) instead of vector loads + readfirstlane (-10 VALU per term).
     const ConstU32* cidx = (const ConstU32*)a.colidx;
@@ -1327,9 +1315,7 @@ __device__ __forceinline__ Fe<NL> spmm_t_terms(const SpmmTArgs& a, const u32* xi
         Fe29 vn;
 #pragma unroll
         for (int i = 0; i < 9; i++) vn.v[i] = cv29[(size_t)kn * 12 + i];
-        u32 extra = 0;
-        if constexpr (PRICE == 2) extra = plane[(size_t)cidx[k] * a.n_rows];
-        lazy29_mac(acc, price_to29<PRICE>(x, extra), v);
+        lazy29_mac(acc, fe_to29(x), v);
         v = vn;
         if (++since == 6) { lazy29_normalize(acc); since = 0; }
         x = xn;
@@ -1392,7 +1378,7 @@ __device__ __forceinline__ Fe<NL> spmm_t_terms(const SpmmTArgs& a, const u32* xi
 
 // OPW = outputs per workgroup (4: the wide levels; narrower ones go to spmm_t_sliced_kernel)
 // n_main: the rows this launch covers, [0, n_main) (all of them, or the whole 64-row groups when spmm_t_tail_kernel takes the rest)
-template <int NL, int SPMM_OPW, int PRICE = 0>
+template <int NL, int SPMM_OPW>
 __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a, u32 n_main) {
   const u64 row = (u64)blockIdx.y * 128 + threadIdx.x;
   if ((row & ~(u64)63) >= n_main) return;            // a wave with no row at all (<= 64 rows: the workgroup's second wave)
@@ -1405,7 +1391,7 @@ __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a, u32 n_main) {
     if (o >= a.m) break;
     const u32 k0 = __builtin_amdgcn_readfirstlane(a.rowptr[o]);
     const u32 k1 = __builtin_amdgcn_readfirstlane(a.rowptr[o + 1]);
-    const Fe<NL> res = spmm_t_terms<NL, PRICE>(a, xin, pstride, k0, k1);
+    const Fe<NL> res = spmm_t_terms<NL>(a, xin, pstride, k0, k1);
     if (live) {
       u32* dst = a.out_alt ? a.out_alt + (o * a.n_rows + row) * NL : a.t + ((a.out_off + o) * a.n_rows + row) * NL;
       fe_store<NL>(dst, res);
@@ -1418,11 +1404,9 @@ __global__ void __launch_bounds__(128) spmm_t_kernel(SpmmTArgs a, u32 n_main) {
 // lanes run over (output, tail row) pairs back to back, so that a wave holds the tails of two or three outputs and is full.
 // The price: matrix entries are per lane (vector loads; 64 lanes share two or three distinct entries, L1 hits) instead of
 // scalar, and a wave runs as long as its longest output.  Same dot products, same reduction points (every <= 60 terms).
-// (tail = 0: rows [n_main, n_rows); otherwise the `tail` rows from n_main on -- one row group of a grouped launch)
-template <int PRICE>
-__global__ void __launch_bounds__(256) spmm_t_tail_kernel(SpmmTArgs a, u32 n_main, u32 tail_rows) {
+__global__ void __launch_bounds__(256) spmm_t_tail_kernel(SpmmTArgs a, u32 n_main) {
   constexpr int NL = 8;
-  const u32 tail = tail_rows ? tail_rows : (u32)a.n_rows - n_main;
+  const u32 tail = (u32)a.n_rows - n_main;
   const u64 total = a.m * tail;
   const u64 flat = (u64)blockIdx.x * 256 + threadIdx.x;
   if ((flat & ~(u64)63) >= total) return;
@@ -1460,9 +1444,7 @@ __global__ void __launch_bounds__(256) spmm_t_tail_kernel(SpmmTArgs a, u32 n_mai
       Fe<NL> xn = x;
       Fe29 vn = v;
       if (i + 1 < len) { xn = fe_load<NL>(xin + (size_t)a.colidx[k0 + i + 1] * pstride); vn = load_v(k0 + i + 1); }
-      u32 extra = 0;
-      if constexpr (PRICE == 2) { if (i < len) extra = (a.t + (size_t)(a.in_off + a.m) * a.n_rows * 8)[(size_t)a.colidx[k0 + i] * a.n_rows + row]; }
-      if (i < len) lazy29_mac(acc, price_to29<PRICE>(x, extra), v);
+      if (i < len) lazy29_mac(acc, fe_to29(x), v);
       if (++since == 6) { lazy29_normalize(acc); since = 0; }
       x = xn; v = vn;
     }
@@ -1515,37 +1497,19 @@ __global__ void __launch_bounds__(128 * SL) spmm_t_sliced_kernel(SpmmTArgs a) {
 }
 hipError_t launch_spmm_t(int nl, const SpmmTArgs& a, hipStream_t st) {
   if (a.m == 0 || a.n_rows == 0) return hipSuccess;
-  if (a.m >= 8192 && a.row_group && nl == 8 && a.vals29 != nullptr && a.n_rows > a.row_group) {
-    // row groups: equal groups of <= row_group rows, each one launch of the packed (output, row) kernel over all outputs
-    const u32 G = (u32)((a.n_rows + a.row_group - 1) / a.row_group), per = (u32)((a.n_rows + G - 1) / G);
-    for (u32 r0 = 0; r0 < (u32)a.n_rows; r0 += per) {
-      const u32 cnt = r0 + per < (u32)a.n_rows ? per : (u32)a.n_rows - r0;
-      const u64 total = a.m * cnt;
-      hipLaunchKernelGGL(spmm_t_tail_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, r0, cnt);
-    }
-  } else if (a.m >= 8192) {
+  if (a.m >= 8192) {
     // a last group of <= 48 rows goes to the packed-tail kernel (Ft255 limb path), the whole 64-row groups stay lane = row
     u32 n_main = (u32)a.n_rows;
     const u32 tail = (u32)(a.n_rows & 63);
-    if (nl == 8 && a.vals29 != nullptr && tail != 0 && tail <= 48 && a.tail_on) n_main -= tail;
+    if (nl == 8 && a.vals29 != nullptr && tail != 0 && tail <= 48) n_main -= tail;
     if (n_main) {
       dim3 grid((unsigned)((a.m + 3) / 4), (unsigned)((n_main + 127) / 128));
-#ifdef LCPC_K2_PRICE_EXPERIMENT      // (make HIPFLAGS+=-DLCPC_K2_PRICE_EXPERIMENT: the timing-only variants of spmm_t_terms; never in the product build)
-      if (nl == 8 && a.price == 1) hipLaunchKernelGGL((spmm_t_kernel<8, 4, 1>), grid, dim3(128), 0, st, a, n_main);
-      else if (nl == 8 && a.price == 2) hipLaunchKernelGGL((spmm_t_kernel<8, 4, 2>), grid, dim3(128), 0, st, a, n_main);
-      else
-#endif
       LCPC_DISPATCH_NL(nl, hipLaunchKernelGGL((spmm_t_kernel<NLV, 4>), grid, dim3(128), 0, st, a, n_main));
     }
     if (n_main != (u32)a.n_rows) {
       const u64 total = a.m * (a.n_rows - n_main);
       const dim3 tg((unsigned)((total + 255) / 256));
-#ifdef LCPC_K2_PRICE_EXPERIMENT
-      if (a.price == 1) hipLaunchKernelGGL(spmm_t_tail_kernel<1>, tg, dim3(256), 0, st, a, n_main, 0u);
-      else if (a.price == 2) hipLaunchKernelGGL(spmm_t_tail_kernel<2>, tg, dim3(256), 0, st, a, n_main, 0u);
-      else
-#endif
-      hipLaunchKernelGGL(spmm_t_tail_kernel<0>, tg, dim3(256), 0, st, a, n_main, 0u);
+      hipLaunchKernelGGL(spmm_t_tail_kernel, tg, dim3(256), 0, st, a, n_main);
     }
   } else if (a.m > 2048) {
     dim3 grid((unsigned)a.m, (unsigned)((a.n_rows + 127) / 128));

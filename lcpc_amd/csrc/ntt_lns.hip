@@ -379,12 +379,7 @@ template <class FT> hipError_t launch_pass_f(const NttPassArgs& a, bool first, c
 // 0.73 / 1.43 / 2.30 ms against 0.76 / 1.63 / 2.90; 2^20 columns 1.97 / 2.26 ms against 2.02 / 3.26 for Ft127 / Ft191.  Ft63's
 // 8-byte first-pass runs lost at 2^20 columns until the first pass ran the tiles that share cache lines back to back on one
 // XCD (NttPassArgs.tile_group): 512 rows x 2^20 columns 12.9 ms on the general plan, 23.3 ungrouped, 11.2 grouped.
-// LCPC_NTT_LNS_MAXK lowers the bound (A/B).
-bool ntt_lns_supported(int nl, uint32_t log_n) {
-  const char* ev = getenv("LCPC_NTT_LNS_MAXK");
-  const uint32_t maxk = ev ? (uint32_t)atoi(ev) : 20;
-  return (nl == 2 || nl == 4 || nl == 6) && log_n >= 11 && log_n <= maxk && log_n <= 20u;
-}
+bool ntt_lns_supported(int nl, uint32_t log_n) { return (nl == 2 || nl == 4 || nl == 6) && log_n >= 11 && log_n <= 20u; }
 bool ntt_lns3_supported(int nl, uint32_t log_n) { return (nl == 2 || nl == 4 || nl == 6) && log_n >= 21 && log_n <= 26; }
 __global__ void __launch_bounds__(256) lns_subtable_kernel(const u32* tab, u32 shift, u64 n, u32 words, u32* sub) {
   for (u64 id = (u64)blockIdx.x * 256 + threadIdx.x; id < n * words; id += (u64)gridDim.x * 256) {

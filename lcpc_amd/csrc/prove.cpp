@@ -92,7 +92,7 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
   Transcript& tr = trw->t;
   const uint64_t n_deg = lcpc_get_n_degree_tests(c), n_open = lcpc_get_n_col_opens(c);
   const uint64_t np = c->n_per_row, nr = m->n_rows;
-  const bool dbg = getenv("LCPC_DEBUG_TIMING") != nullptr;
+  const bool dbg = c->sw_debug_timing;
   double tp[8] = {now_ms(), 0, 0, 0, 0, 0, 0, 0};
   double t_collapse = 0, t_absorb = 0;
   // bincode 1.3 of WrappedLcEvalProof (lib.rs:550-560): n_cols, p_eval, p_random_vec, columns.  The size is known up
@@ -132,8 +132,7 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
     // exchange for both polynomials).  Unsharded: the transcript only waits for p_random; the helper thread collapses
     // p_eval while this one absorbs p_random (a second pass over coeffs on an otherwise idle GPU: -0.3 ms on the wait).
     uint32_t nt = 1;
-    static const bool fused_only = getenv("LCPC_PROVE_EVAL_FUSED") != nullptr;   // A/B: p_eval fused into the first pass as when sharded
-    const bool eval_here = i == 0, eval_beside = eval_here && xchg == nullptr && !fused_only;
+    const bool eval_here = i == 0, eval_beside = eval_here && xchg == nullptr;
     if (eval_here) {
       memcpy(&tensors[nr * L], outer, nr * L * 8);
       if (!eval_beside) nt = 2;
@@ -279,7 +278,7 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
   const int L = f.L;
   const uint64_t F = 8 * L;
   Transcript& tr = trw->t;
-  const bool dbg = getenv("LCPC_DEBUG_TIMING") != nullptr;
+  const bool dbg = c->sw_debug_timing;
   double tv[6] = {now_ms(), 0, 0, 0, 0, 0};
   // every field of the wire layout sits at a multiple of 8 bytes, so the vectors are read in place (a proof handed over
   // at an odd address is copied once)

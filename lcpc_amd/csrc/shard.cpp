@@ -84,8 +84,10 @@ Rccl& rccl() {
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     // a copy already in the process (torch bundles one) wins, under whatever name it was loaded: every candidate name with
     // RTLD_NOLOAD first, then the global symbol scope (a copy loaded by full path with RTLD_GLOBAL), and only then a load
-    // LCPC_RCCL_LIB=<path>: this library and no other (a site's own RCCL build; the tests' in-process stand-in)
-    if (const char* ov = getenv("LCPC_RCCL_LIB")) {
+    // LCPC_RCCL_LIB=<path>: this library and no other (a site's own RCCL build; the tests' in-process stand-in).  The path is
+    // loaded and called as the communicator library: a trusted-environment switch, ignored (secure_getenv) in set-uid / set-gid
+    // or capability-raised processes
+    if (const char* ov = secure_getenv("LCPC_RCCL_LIB")) {
       x.h = dlopen(ov, RTLD_NOW | RTLD_LOCAL);
       if (!x.h) return x;
     }
@@ -251,12 +253,13 @@ int open_sharded(lcpc_commit_t* m, const ShardXchg& x, const uint64_t* cols, uin
 }
 
 // ---- sharded commit phases ----------------------------------------------------------------------------------
-// The commit of a rank is four steps (the column range makes the middle two sliceable, so that the exchange of one slice of
-// columns overlaps the hashing of the next -- lcpc_commit_sharded_device below, or a caller with its own collective):
+// The commit of a rank is four steps:
 //   encode        local rows -> comm                                                     (lib.rs:648-653)
-//   hash_cols     columns [c0, c1) of the local rows -> node chaining values [k][c1 - c0] (lib.rs:706-745, this rank's part)
-//   finish_cols   gathered node CVs of columns [c0, c1) -> leaf digests hashes[c0, c1)   (lib.rs:706-745, the rest)
+//   hash_cols     the columns of the local rows -> node chaining values [k][n_cols]      (lib.rs:706-745, this rank's part)
+//   finish_cols   gathered node CVs -> leaf digests hashes[0, n_cols)                    (lib.rs:706-745, the rest)
 //   merkle        the tree above the leaf digests                                        (lib.rs:747-785)
+// (Round 4 could slice the middle two by column ranges so that one slice's exchange overlapped the next slice's hashing: measured
+// neutral to negative -- LABNOTES "exchange slicing" -- and removed in round 5 together with its four column-range entry points.)
 static int shard_encode_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, hipStream_t st, uint32_t flags) {
   const lcpc_ctx* c = m->enc;
   uint64_t rb, re, cb, ce, nch;
@@ -270,7 +273,7 @@ static int shard_encode_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, ui
   m->launches[0] = m->launches[1] = m->launches[2] = 0;
   m->last.exchange_exposed_ms = 0.f;
   m->shard_encoded = false;
-  const bool fused = c->prm.encoding == LCPC_ENC_LIGERO || m->n_rows_local >= sdig_t_min_rows();
+  const bool fused = c->prm.encoding == LCPC_ENC_LIGERO || m->n_rows_local >= SDIG_T_MIN_ROWS;
   const bool borrow = (flags & LCPC_COMMIT_BORROW_COEFFS) != 0 && m->n_rows_local > 0;   // local rows are always whole rows
   rc = ensure_commit_buffers(m, m->n_rows_local, !borrow);
   if (rc) return rc;
@@ -280,7 +283,7 @@ static int shard_encode_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, ui
     const uint32_t* src = reinterpret_cast<const uint32_t*>(coeffs_local);
     EncodeJob j;
     j.src_stride = c->n_per_row; j.n_valid = c->n_per_row; j.dst = m->d_comm; j.n_rows = m->n_rows_local;
-    j.canon_out = c->prm.encoding == LCPC_ENC_SDIG ? c->t_canon : c->comm_canon; j.keep_t = true;
+    j.canon_out = c->prm.encoding == LCPC_ENC_SDIG ? true : c->comm_canon; j.keep_t = true;
     bool kept = false;
     j.kept_t = &kept;
     if (borrow) {
@@ -305,11 +308,11 @@ static int shard_encode_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, ui
   return 0;
 }
 
-// columns [c0, c1) of the local rows -> one chaining value per (local node, column): nodes_dev[k][c1 - c0][32 B]
-static int shard_hash_cols(lcpc_commit_t* m, uint64_t c0, uint64_t c1, hipStream_t st, uint8_t* nodes_dev) {
+// the columns of the local rows -> one chaining value per (local node, column): nodes_dev[k][n_cols][32 B]
+static int shard_hash_cols(lcpc_commit_t* m, hipStream_t st, uint8_t* nodes_dev) {
   const lcpc_ctx* c = m->enc;
-  const uint64_t cb = m->chunk_begin, ce = m->chunk_end, w = c1 - c0;
-  if (ce <= cb || w == 0) return 0;
+  const uint64_t cb = m->chunk_begin, ce = m->chunk_end, w = c->n_cols;
+  if (ce <= cb) return 0;
   uint64_t first[64];
   uint32_t lg[64];
   const int n_nodes = shard_nodes(cb, ce, first, lg);
@@ -317,8 +320,7 @@ static int shard_hash_cols(lcpc_commit_t* m, uint64_t c0, uint64_t c1, hipStream
   for (int k = 0; k < n_nodes; k++) all_single = all_single && lg[k] == 0;
   LeafArgs la{};
   la.comm = m->d_comm; la.canon_in = c->comm_canon ? 1u : 0u; la.row_stride = c->n_cols; la.col_stride = 1;
-  if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = c->t_canon ? 1u : 0u; la.row_stride = 1; la.col_stride = m->n_rows_local; }
-  la.comm += c0 * la.col_stride * c->NL;          // the kernel's column 0 is column c0 of the matrix
+  if (m->comm_t) { la.comm = m->ws.d_t; la.canon_in = 1u; la.row_stride = 1; la.col_stride = m->n_rows_local; }
   la.n_cols = w; la.row_base = (int64_t)m->row_begin;
   la.n_rows_total = m->n_rows; la.chunk_begin = (uint32_t)cb; la.n_chunks_local = (uint32_t)(ce - cb);
   la.n_chunks_total = (uint32_t)m->n_chunks;
@@ -328,7 +330,7 @@ static int shard_hash_cols(lcpc_commit_t* m, uint64_t c0, uint64_t c1, hipStream
     m->launches[1]++;
     return 0;
   }
-  uint32_t* cvs = m->d_cvs + (ce - cb) * c0 * 8;      // this slice's [chunk][w] block of the CV buffer
+  uint32_t* cvs = m->d_cvs;
   la.out = cvs;
   HIPCHK(m, launch_leaf_chunks(c->NL, la, st));
   m->launches[1]++;
@@ -348,13 +350,13 @@ static int shard_hash_cols(lcpc_commit_t* m, uint64_t c0, uint64_t c1, hipStream
 // node table over all ranks, in chunk order: slot in the gathered buffer + log2(size); cached per shape.  Slot of rank g's
 // node k: padded layout (slots_per_rank > 0) g * slots_per_rank + k; compact layout (slots_per_rank == 0, the native
 // exchange) g for k = 0 and G + (running index over ranks of their nodes k >= 1) otherwise
-static int shard_node_table(lcpc_commit_t* m, uint32_t slots_per_rank, hipStream_t st) {
+static int shard_node_table(lcpc_commit_t* m, uint32_t slots_per_rank) {
   const lcpc_ctx* c = m->enc;
   const uint64_t nch = m->n_chunks;
   const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
   const uint64_t key = (nch << 24) ^ ((uint64_t)slots_per_rank << 8) ^ G;
   if (m->d_node_tab && m->node_tab_key == key) return 0;
-  m->node_slot_h.clear(); m->node_log_h.clear();
+  std::vector<uint32_t> slot, lgs;
   uint32_t extra = G;
   for (uint32_t r = 0; r < G; r++) {
     uint64_t first[64];
@@ -364,30 +366,34 @@ static int shard_node_table(lcpc_commit_t* m, uint32_t slots_per_rank, hipStream
     const int n = shard_nodes(c0, c1, first, lg);
     if (slots_per_rank && (uint32_t)n > slots_per_rank) return LCPC_ERR_ARG;
     for (int k = 0; k < n; k++) {
-      m->node_slot_h.push_back(slots_per_rank ? r * slots_per_rank + (uint32_t)k : (k == 0 ? r : extra++));
-      m->node_log_h.push_back(lg[k]);
+      slot.push_back(slots_per_rank ? r * slots_per_rank + (uint32_t)k : (k == 0 ? r : extra++));
+      lgs.push_back(lg[k]);
     }
   }
-  const uint32_t nn = (uint32_t)m->node_slot_h.size();
-  HIPCHK(m, hipStreamSynchronize(st));        // one-off per shape: the old table may still be read by a finish in flight
-  dev_free(m->d_node_tab);
-  m->d_node_tab = nullptr;
-  int rc = dev_alloc(&m->err, &m->d_node_tab, (size_t)nn * 8);
+  const uint32_t nn = (uint32_t)slot.size();
+  // A table that a finish step still in flight (any stream) may be reading is never freed or overwritten: a new shape gets a NEW
+  // table (a few dozen bytes), the old ones live until the object goes (an object sees one or two shapes).  The blocking copy
+  // below writes memory nothing on the device refers to yet.
+  for (const auto& t : m->node_tabs)
+    if (t.key == key) { m->d_node_tab = t.d; m->node_tab_key = key; m->node_slot_h = t.slot; m->node_log_h = t.lg; return 0; }
+  uint32_t* d = nullptr;
+  int rc = dev_alloc(&m->err, &d, (size_t)nn * 8);
   if (rc) return rc;
-  HIPCHK(m, hipMemcpy(m->d_node_tab, m->node_slot_h.data(), nn * 4, hipMemcpyHostToDevice));
-  HIPCHK(m, hipMemcpy(m->d_node_tab + nn, m->node_log_h.data(), nn * 4, hipMemcpyHostToDevice));
-  m->node_tab_key = key;
+  hipError_t e = hipMemcpy(d, slot.data(), nn * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d + nn, lgs.data(), nn * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { dev_free(d); return fail_hip(&m->err, e, "node table upload"); }
+  m->node_tabs.push_back({key, d, slot, lgs});
+  m->d_node_tab = d; m->node_tab_key = key; m->node_slot_h = slot; m->node_log_h = lgs;
   return 0;
 }
 
-// gathered node CVs of columns [c0, c1) (gathered[slot][c1 - c0][32 B], clobbered) -> leaf digests hashes[c0, c1)
-static int shard_finish_cols(lcpc_commit_t* m, uint8_t* gathered, uint32_t slots_per_rank, uint64_t c0, uint64_t c1, hipStream_t st) {
-  const uint64_t w = c1 - c0;
-  if (w == 0) return 0;
-  int rc = shard_node_table(m, slots_per_rank, st);
+// gathered node CVs (gathered[slot][n_cols][32 B], clobbered) -> leaf digests hashes[0, n_cols)
+static int shard_finish_cols(lcpc_commit_t* m, uint8_t* gathered, uint32_t slots_per_rank, hipStream_t st) {
+  const uint64_t w = m->enc->n_cols;
+  int rc = shard_node_table(m, slots_per_rank);
   if (rc) return rc;
   const uint32_t n_nodes = (uint32_t)m->node_slot_h.size();
-  uint32_t* out = m->d_hashes + c0 * 8;
+  uint32_t* out = m->d_hashes;
   if (m->n_chunks == 1 || n_nodes == 1) {   // single-chunk message, or the whole message as one rank's one node (shard_hash_cols):
                                             // that "node" already carries ROOT
     HIPCHK(m, hipMemcpyAsync(out, gathered + (size_t)m->node_slot_h[0] * w * 32, (size_t)w * 32, hipMemcpyDeviceToDevice, st));
@@ -451,50 +457,8 @@ int lcpc_shard_nodes(uint64_t n_chunks, uint32_t G, uint32_t g, uint32_t* n_node
 }
 
 // ---- split phases (a caller-side collective) ----------------------------------------------------------------
-int lcpc_commit_shard_encode_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint32_t flags) {
-  if (!m || n_rows_total == 0) return LCPC_ERR_ARG;
-  LCPC_TRY
-  std::lock_guard<std::mutex> g(m->mu);
-  HIPCHK(m, hipSetDevice(m->enc->prm.device));
-  return shard_encode_phase(m, coeffs_local, n_rows_total, (hipStream_t)stream, flags);
-  LCPC_CATCH(m)
-}
-
-int lcpc_commit_shard_hash_device(lcpc_commit_t* m, uint64_t col_begin, uint64_t col_end, void* stream, uint8_t* nodes_dev) {
-  if (!m || !nodes_dev || col_begin > col_end || col_end > m->enc->n_cols) return LCPC_ERR_ARG;
-  if (!m->shard_encoded) return LCPC_ERR_STATE;
-  LCPC_TRY
-  std::lock_guard<std::mutex> g(m->mu);
-  HIPCHK(m, hipSetDevice(m->enc->prm.device));
-  int rc = shard_hash_cols(m, col_begin, col_end, (hipStream_t)stream, nodes_dev);
-  if (rc) return rc;
-  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], (hipStream_t)stream));
-  return 0;
-  LCPC_CATCH(m)
-}
-
-int lcpc_commit_finish_cols_device(lcpc_commit_t* m, uint8_t* gathered, uint32_t slots_per_rank, uint64_t col_begin, uint64_t col_end,
-                                   void* stream) {
-  if (!m || !gathered || col_begin > col_end || col_end > m->enc->n_cols) return LCPC_ERR_ARG;
-  if (!m->shard_encoded) return LCPC_ERR_STATE;
-  LCPC_TRY
-  std::lock_guard<std::mutex> g(m->mu);
-  HIPCHK(m, hipSetDevice(m->enc->prm.device));
-  return shard_finish_cols(m, gathered, slots_per_rank, col_begin, col_end, (hipStream_t)stream);
-  LCPC_CATCH(m)
-}
-
-int lcpc_commit_finish_merkle_device(lcpc_commit_t* m, void* stream, uint8_t* root) {
-  if (!m) return LCPC_ERR_ARG;
-  if (!m->shard_encoded) return LCPC_ERR_STATE;
-  LCPC_TRY
-  std::lock_guard<std::mutex> g(m->mu);
-  HIPCHK(m, hipSetDevice(m->enc->prm.device));
-  return shard_merkle_phase(m, (hipStream_t)stream, root);
-  LCPC_CATCH(m)
-}
-
-// the unsliced pair: encode + hash of every column; finish of every column + Merkle
+// A failure in any step after the encode leaves the commit un-started (shard_encoded false): the finish step of a commit whose
+// hash step failed must not build a tree over stale digests.
 int lcpc_commit_shard_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint32_t flags,
                              uint8_t* nodes_dev) {
   if (!m || n_rows_total == 0 || !nodes_dev) return LCPC_ERR_ARG;
@@ -503,22 +467,24 @@ int lcpc_commit_shard_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uin
   HIPCHK(m, hipSetDevice(m->enc->prm.device));
   hipStream_t st = (hipStream_t)stream;
   int rc = shard_encode_phase(m, coeffs_local, n_rows_total, st, flags);
-  if (!rc) rc = shard_hash_cols(m, 0, m->enc->n_cols, st, nodes_dev);
-  if (rc) return rc;
+  if (!rc) rc = shard_hash_cols(m, st, nodes_dev);
+  if (rc) { m->shard_encoded = false; return rc; }
   if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], st));
   return 0;
   LCPC_CATCH(m)
 }
 
 int lcpc_commit_finish_device(lcpc_commit_t* m, uint8_t* gathered, uint64_t n_rows_total, uint32_t slots_per_rank, void* stream, uint8_t* root) {
-  if (!m || !gathered || n_rows_total != m->n_rows) return LCPC_ERR_ARG;
-  if (!m->shard_encoded) return LCPC_ERR_STATE;
+  if (!m || !gathered) return LCPC_ERR_ARG;
   LCPC_TRY
   std::lock_guard<std::mutex> g(m->mu);
+  if (n_rows_total != m->n_rows) return LCPC_ERR_ARG;
+  if (!m->shard_encoded) return LCPC_ERR_STATE;             // (read under the lock: the encode step may run on another host thread)
   HIPCHK(m, hipSetDevice(m->enc->prm.device));
-  int rc = shard_finish_cols(m, gathered, slots_per_rank, 0, m->enc->n_cols, (hipStream_t)stream);
-  if (rc) return rc;
-  return shard_merkle_phase(m, (hipStream_t)stream, root);
+  int rc = shard_finish_cols(m, gathered, slots_per_rank, (hipStream_t)stream);
+  if (!rc) rc = shard_merkle_phase(m, (hipStream_t)stream, root);
+  if (rc) m->shard_encoded = false;                         // whatever failed, this commit cannot be finished any more
+  return rc;
   LCPC_CATCH(m)
 }
 
@@ -557,31 +523,13 @@ int lcpc_comm_destroy(lcpc_ctx* c) {
   return 0;
 }
 
-// column slices of the native exchange: boundaries at multiples of 256 columns (the hash kernels' workgroup width), no slice
-// narrower than 1024 columns.  Returns the number of slices; bounds[s] .. bounds[s + 1] is slice s
-static uint32_t shard_slices(const lcpc_ctx* c, uint64_t* bounds) {
-  uint32_t S = std::max<uint32_t>(1, std::min<uint32_t>(c->shard_slices, LCPC_MAX_SHARD_SLICES));
-  while (S > 1 && c->n_cols / S < 1024) S--;
-  uint32_t n = 0;
-  bounds[0] = 0;
-  for (uint32_t s = 1; s <= S; s++) {
-    uint64_t b = s == S ? c->n_cols : std::min<uint64_t>(c->n_cols, ((c->n_cols * s / S) + 255) & ~(uint64_t)255);
-    if (b > bounds[n]) bounds[++n] = b;
-  }
-  return n;
-}
-
 // One commit on a row shard with the exchange inside: encode and the local column hash on `stream`; the collectives (node 0 of
 // every rank by ncclAllGather, the few second / third nodes by one ncclBroadcast each, grouped), the leaf digests and the Merkle
 // tree follow
-//   * by default on `stream` itself, everything in sequence (one slice);
-//   * with LCPC_SHARD_SLICES=S > 1 per slice of columns on the commitment's exchange stream, behind an event, while `stream`
-//     hashes the next slice; `stream` then waits for the exchange stream and builds the tree.  Measured (profiles/
-//     r04_shard_slices*.jsonl): what this can hide is bounded by the hash time (<= 0.2 ms of a 1.5 ms rank step at 8 GPUs) and the
-//     extra launches and hand-overs cost about as much -- hence not the default;
-//   * with LCPC_COMMIT_ASYNC_TAIL in `flags` on the exchange stream WITHOUT `stream` waiting for them: `stream` is free again
-//     after the column hash, so the next commit (another lcpc_commit_t of the same encoder) encodes while this one's node
-//     values are on the wire.  The commitment is complete behind its event, which every reader and a refill wait for.
+//   * by default on `stream` itself, everything in sequence;
+//   * with LCPC_COMMIT_ASYNC_TAIL in `flags` on the commitment's exchange stream WITHOUT `stream` waiting for them: `stream` is
+//     free again after the column hash, so the next commit (another lcpc_commit_t of the same encoder) encodes while this one's
+//     node values are on the wire.  The commitment is complete behind its event, which every reader and a refill wait for.
 int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, uint64_t n_rows_total, void* stream, uint32_t flags, uint8_t* root) {
   if (!m || n_rows_total == 0) return LCPC_ERR_ARG;
   lcpc_ctx* c = m->enc;
@@ -593,10 +541,10 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
   const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
   const uint32_t me = G > 1 ? c->prm.shard_rank : 0;
   const uint64_t nch = leaf_chunks(c, n_rows_total);
-  // one slot = one chaining value per column of a slice.  What crosses the wire: node 0 of every rank (one all-gather of one
-  // slot each) plus the few second / third nodes some ranks own (one broadcast each: at the headline only the last rank has
-  // one), instead of padding every rank to the largest node count.  Per slice, contiguous:
-  // [ this rank's nodes ][ gathered: G slots of node 0, then the extra nodes in rank order ]
+  // one slot = one chaining value per column.  What crosses the wire: node 0 of every rank (one all-gather of one slot each) plus
+  // the few second / third nodes some ranks own (one broadcast each: at the headline only the last rank has one), instead of
+  // padding every rank to the largest node count.  Contiguous: [ this rank's nodes ][ gathered: G slots of node 0, then the
+  // extra nodes in rank order ]
   uint32_t n_nodes_of[256], extras = 0, my_slots = 1;
   if (G > 256) return LCPC_ERR_ARG;
   for (uint32_t r = 0; r < G; r++) {
@@ -614,61 +562,49 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
   if (rc) return rc;
   if (tot_slots * c->n_cols * 32 > m->gather_cap && m->ev_done) HIPCHK(m, hipEventSynchronize(m->ev_done));
   if ((rc = ensure_dev(&m->err, &m->d_gather, &m->gather_cap, tot_slots * c->n_cols * 32))) return rc;
-  uint64_t bounds[LCPC_MAX_SHARD_SLICES + 1];
-  const uint32_t S = shard_slices(c, bounds);
   const bool async_tail = (flags & LCPC_COMMIT_ASYNC_TAIL) != 0;
   if ((rc = shard_encode_phase(m, coeffs_local, n_rows_total, st, flags))) return rc;
-  if ((rc = shard_node_table(m, 0, st))) return rc;           // (one-off per shape; no synchronisation inside the slice loop)
+  // from here on a failure leaves the object un-committed AND un-started (no split-phase finish may pick it up)
+  struct Unstart { lcpc_commit_t* m; bool armed = true; ~Unstart() { if (armed) m->shard_encoded = false; } } unstart{m};
+  if ((rc = shard_node_table(m, 0))) return rc;
   hipStream_t sx = st;
-  if (S > 1 || async_tail) {
+  if (async_tail) {
     if (!m->s_xchg) HIPCHK(m, hipStreamCreateWithFlags(&m->s_xchg, hipStreamNonBlocking));
-    for (uint32_t s = 0; s <= S; s++)
-      if (!m->ev_slice[s]) HIPCHK(m, hipEventCreateWithFlags(&m->ev_slice[s], hipEventDisableTiming));
+    if (!m->ev_hashed) HIPCHK(m, hipEventCreateWithFlags(&m->ev_hashed, hipEventDisableTiming));
     sx = m->s_xchg;
   }
+  const uint64_t slot_bytes = c->n_cols * 32;
+  uint8_t* send = m->d_gather;
+  uint8_t* recv = send + slot_bytes * my_slots;
+  if ((rc = shard_hash_cols(m, st, send))) return rc;
+  if (sx != st) {
+    HIPCHK(m, hipEventRecord(m->ev_hashed, st));
+    HIPCHK(m, hipStreamWaitEvent(sx, m->ev_hashed, 0));
+  }
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], st));
   {
-    // Collectives of one communicator must be submitted in the same order on every rank.  This lock only keeps the slices of
+    // Collectives of one communicator must be submitted in the same order on every rank.  This lock only keeps the exchanges of
     // two commitments of ONE process from interleaving; it cannot order submissions ACROSS ranks -- one encoder's sharded
     // commits / proves must be issued in the same program order on every rank (one driving thread per communicator).
     std::lock_guard<std::mutex> xg(c->xchg_mu);
-    for (uint32_t s = 0; s < S; s++) {
-      const uint64_t c0 = bounds[s], c1 = bounds[s + 1], w = c1 - c0;
-      const uint64_t slot_bytes = w * 32;
-      uint8_t* send = m->d_gather + tot_slots * c0 * 32;
-      uint8_t* recv = send + slot_bytes * my_slots;
-      if ((rc = shard_hash_cols(m, c0, c1, st, send))) return rc;
-      if (sx != st) {
-        HIPCHK(m, hipEventRecord(m->ev_slice[s], st));
-        HIPCHK(m, hipStreamWaitEvent(sx, m->ev_slice[s], 0));
+    HIPCHK(m, xchg_order_before(c, sx));
+    int nrc = rccl().GroupStart();
+    if (nrc == 0) nrc = rccl().AllGather(send, recv, (size_t)slot_bytes, NCCL_UINT8, c->comm, sx);
+    uint32_t x = G;
+    for (uint32_t r = 0; r < G && nrc == 0; r++)
+      for (uint32_t k = 1; k < n_nodes_of[r] && nrc == 0; k++, x++) {
+        uint8_t* dst = recv + slot_bytes * x;
+        nrc = rccl().Broadcast(r == me ? send + slot_bytes * k : dst, dst, (size_t)slot_bytes, NCCL_UINT8, (int)r, c->comm, sx);
       }
-      if (m->timing && s + 1 == S) HIPCHK(m, hipEventRecord(m->ev[2], st));     // the last slice's hash is done here
-      HIPCHK(m, xchg_order_before(c, sx));
-      int nrc = rccl().GroupStart();
-      if (nrc == 0) nrc = rccl().AllGather(send, recv, (size_t)slot_bytes, NCCL_UINT8, c->comm, sx);
-      uint32_t x = G;
-      for (uint32_t r = 0; r < G && nrc == 0; r++)
-        for (uint32_t k = 1; k < n_nodes_of[r] && nrc == 0; k++, x++) {
-          uint8_t* dst = recv + slot_bytes * x;
-          nrc = rccl().Broadcast(r == me ? send + slot_bytes * k : dst, dst, (size_t)slot_bytes, NCCL_UINT8, (int)r, c->comm, sx);
-        }
-      const int erc = rccl().GroupEnd();
-      if (nrc == 0) nrc = erc;
-      if (nrc != 0) return fail_nccl(&m->err, nrc, "ncclAllGather / ncclBroadcast");
-      HIPCHK(m, xchg_order_after(c, sx));
-      if ((rc = shard_finish_cols(m, recv, 0, c0, c1, sx))) return rc;
-    }
+    const int erc = rccl().GroupEnd();
+    if (nrc == 0) nrc = erc;
+    if (nrc != 0) return fail_nccl(&m->err, nrc, "ncclAllGather / ncclBroadcast");
+    HIPCHK(m, xchg_order_after(c, sx));
   }
-  hipStream_t tail = st;                     // the stream the tree is built on (and the commitment's event recorded on)
-  if (sx != st) {
-    if (async_tail) {
-      tail = sx;                             // `st` is not held up: it is free for the next commit's encode
-    } else {
-      HIPCHK(m, hipEventRecord(m->ev_slice[S], sx));
-      HIPCHK(m, hipStreamWaitEvent(st, m->ev_slice[S], 0));            // the last slice's exchange + leaf digests
-    }
-  }
-  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[4], tail));
-  if ((rc = shard_merkle_phase(m, tail, root))) return rc;
+  if ((rc = shard_finish_cols(m, recv, 0, sx))) return rc;
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[4], sx));
+  if ((rc = shard_merkle_phase(m, sx, root))) return rc;      // (async tail: `st` is not held up, it is free for the next commit's encode)
+  unstart.armed = false;
   if (m->timing) (void)hipEventElapsedTime(&m->last.exchange_exposed_ms, m->ev[2], m->ev[4]);
   return 0;
   LCPC_CATCH(m)

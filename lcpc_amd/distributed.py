@@ -18,12 +18,6 @@ world_size 2/3) with a stand-in engine from the tests while the product engine i
     layout(n_rows_total) -> (row_begin, row_end, chunk_begin, chunk_end, n_chunks_total)
     commit_shard(local_coeffs, n_rows_total) -> uint8 tensor [n_nodes_of_this_rank, n_cols, 32]
     commit_finish(gathered [world * slots, n_cols, 32], n_rows_total, slots) -> 32-byte root
-and, for the sliced form (`sharded_commit(..., slices=S)`: the exchange of one slice of columns overlaps the hashing of
-the next, as lcpc_commit_sharded_device does natively),
-    commit_encode(local_coeffs, n_rows_total)
-    commit_hash_cols(c0, c1) -> uint8 tensor [n_nodes_of_this_rank, c1 - c0, 32]
-    commit_finish_cols(gathered [world * slots, c1 - c0, 32], slots, c0, c1)
-    commit_merkle() -> 32-byte root
 """
 import ctypes as C
 
@@ -69,20 +63,6 @@ def slots_per_rank(n_chunks, world, elem_bytes=32):
 
 
 _xchg_cache = {}
-
-
-def slice_bounds(n_cols, slices):
-    """column slices of a sliced sharded commit: boundaries at multiples of 256, no slice narrower than 1024 columns --
-    the rule of shard_slices() in csrc/shard.cpp"""
-    S = max(1, min(int(slices), 16))
-    while S > 1 and n_cols // S < 1024:
-        S -= 1
-    b = [0]
-    for s in range(1, S + 1):
-        e = n_cols if s == S else min(n_cols, ((n_cols * s // S) + 255) & ~255)
-        if e > b[-1]:
-            b.append(e)
-    return b
 
 
 def exchange_nodes(local_nodes, n_chunks_total, group=None, elem_bytes=32):
@@ -149,35 +129,6 @@ class HipShardEngine:
         self.cm._check(_lib.lib().lcpc_commit_shard_device(self.cm._h, C.c_void_p(ptr), n_rows_total, C.c_void_p(st),
                                                            1 if borrow else 0, C.c_void_p(self._nodes.data_ptr())))
         return self._nodes[:n_nodes]
-
-    # ---- the same commit in four steps, the middle two per column range (lcpc_commit_shard_encode_device ...) ----
-    def commit_encode(self, local_coeffs, n_rows_total, borrow=False):
-        rb, re, _, _, _ = self.layout(n_rows_total)
-        st = torch.cuda.current_stream().cuda_stream
-        ptr = local_coeffs.data_ptr() if re > rb else None
-        self._n_rows_total = n_rows_total
-        self.cm._check(_lib.lib().lcpc_commit_shard_encode_device(self.cm._h, C.c_void_p(ptr), n_rows_total, C.c_void_p(st), 1 if borrow else 0))
-
-    def commit_hash_cols(self, c0, c1):
-        _, _, cb, ce, _ = self.layout(self._n_rows_total)
-        n_nodes = len(aligned_nodes(cb, ce))
-        dev = torch.device("cuda", self.enc.params.device)
-        nodes = torch.empty((max(n_nodes, 1), c1 - c0, 32), dtype=torch.uint8, device=dev)
-        st = torch.cuda.current_stream().cuda_stream
-        self.cm._check(_lib.lib().lcpc_commit_shard_hash_device(self.cm._h, c0, c1, C.c_void_p(st), C.c_void_p(nodes.data_ptr())))
-        return nodes[:n_nodes]
-
-    def commit_finish_cols(self, gathered, slots, c0, c1):
-        st = torch.cuda.current_stream().cuda_stream
-        self.cm._check(_lib.lib().lcpc_commit_finish_cols_device(self.cm._h, C.c_void_p(gathered.data_ptr()), slots, c0, c1, C.c_void_p(st)))
-
-    def commit_merkle(self, want_root=True):
-        st = torch.cuda.current_stream().cuda_stream
-        root = (C.c_uint8 * 32)() if want_root else None
-        self.cm._check(_lib.lib().lcpc_commit_finish_merkle_device(self.cm._h, C.c_void_p(st), root))
-        if want_root:
-            self.cm._refresh()
-        return bytes(root) if want_root else None
 
     def commit_finish(self, gathered, n_rows_total, slots, want_root=True):
         st = torch.cuda.current_stream().cuda_stream
@@ -293,24 +244,10 @@ def sharded_prove(engine, outer_tensor, tr, group=None, allgather=None):
     return data, cols
 
 
-def sharded_commit(engine, local_coeffs, n_rows_total, group=None, want_root=True, borrow=False, slices=1):
-    """one row-sharded commit step: local encode + node CVs, all-gather, finish.  Returns the root.
-    slices > 1: the four-step form -- encode, then per slice of columns hash / all-gather / leaf digests, then the tree (with a
-    stream-ordered collective the all-gather of slice s runs while slice s + 1 is hashed; over gloo it is simply sequential)."""
+def sharded_commit(engine, local_coeffs, n_rows_total, group=None, want_root=True, borrow=False):
+    """one row-sharded commit step: local encode + node CVs, all-gather, finish.  Returns the root."""
     _, _, _, _, n_chunks = engine.layout(n_rows_total)
     eb = getattr(engine, "elem_bytes", 32)
-    if not isinstance(slices, int) or slices > 1:
-        engine.commit_encode(local_coeffs, n_rows_total, borrow) if borrow else engine.commit_encode(local_coeffs, n_rows_total)
-        b = slice_bounds(engine.n_cols, slices) if isinstance(slices, int) else list(slices)      # (or explicit boundaries)
-        multi = dist.is_initialized() and dist.get_world_size(group) > 1
-        for c0, c1 in zip(b[:-1], b[1:]):
-            nodes = engine.commit_hash_cols(c0, c1)
-            if multi:
-                gathered, slots = exchange_nodes(nodes, n_chunks, group, eb)
-            else:
-                gathered, slots = nodes.contiguous(), max(1, nodes.shape[0])
-            engine.commit_finish_cols(gathered, slots, c0, c1)
-        return engine.commit_merkle(want_root)
     nodes = engine.commit_shard(local_coeffs, n_rows_total, borrow) if borrow else engine.commit_shard(local_coeffs, n_rows_total)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         gathered, slots = exchange_nodes(nodes, n_chunks, group, eb)

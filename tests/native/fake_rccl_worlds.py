@@ -8,7 +8,7 @@ Per case: G threads, each with its own sharded encoder (rank r of G), ONE commun
     synchronisation, then a refill of each -> roots / hashes of the LAST polynomial committed into each;
  3. lcpc_prove_sharded_rccl on every rank -> the oracle prover's bytes, identical on every rank;
 for Ligero and Brakedown, the four fields (Ft191's shards cut at rows = 84 mod 128), node layouts with one, two and three nodes
-per rank and ranks that own nothing, with and without column slices (LCPC_SHARD_SLICES, read when the encoders are created).
+per rank and ranks that own nothing.
 Prints one line per case and "all ok"; any mismatch raises."""
 import ctypes as C
 import os
@@ -29,21 +29,21 @@ from lcpc_amd.distributed import HipShardEngine
 assert os.environ.get("LCPC_RCCL_LIB"), "run through tests/test_gpu_fake_rccl.py (LCPC_RCCL_LIB = the stand-in library)"
 
 CASES = [
-    # kind, fid, n_rows, n_per_row, n_cols, G, slices
-    ("ligero", 3, 512, 256, 512, 8, None),       # headline row count: 17 chunks, nodes 1,1,1,1,1,1,1,2 (one broadcast)
-    ("ligero", 3, 512, 2048, 4096, 2, None),     # 2 ranks: 1 + 2 nodes; K1s rows
-    ("ligero", 3, 1024, 128, 256, 8, None),      # C4's row count: 33 chunks
-    ("ligero", 3, 1024, 2048, 4096, 4, "4"),     # column slices on the exchange stream
-    ("ligero", 3, 70, 64, 128, 4, None),         # 3 chunks over 4 ranks: one rank owns nothing
-    ("ligero", 3, 20, 64, 128, 3, None),         # single chunk: two ranks own nothing
-    ("ligero", 3, 40, 64, 128, 2, None),         # 2 chunks
-    ("ligero", 0, 3000, 128, 256, 3, None),      # ft63: 24 chunks over 3 ranks (8 each: one node per rank)
-    ("ligero", 0, 2900, 2048, 4096, 5, "3"),     # ft63 on K1n, 23 chunks over 5 ranks: up to three nodes per rank, sliced
-    ("ligero", 1, 700, 64, 128, 4, None),        # ft127
-    ("ligero", 2, 700, 64, 128, 3, None),        # ft191: cuts at chunks 5 and 11 (rows 212 and 468)
-    ("ligero", 2, 1500, 2048, 4096, 8, None),    # ft191 on K1n: 36 chunks over 8 ranks
-    ("sdig", 3, 140, 300, 0, 4, None),           # Brakedown: position-major shards (>= 24 local rows)
-    ("sdig", 3, 70, 3000, 0, 2, "2"),            # Brakedown, sliced (the position-major commitment read from a column offset)
+    # kind, fid, n_rows, n_per_row, n_cols, G
+    ("ligero", 3, 512, 256, 512, 8),       # headline row count: 17 chunks, nodes 1,1,1,1,1,1,1,2 (one broadcast)
+    ("ligero", 3, 512, 2048, 4096, 2),     # 2 ranks: 1 + 2 nodes; K1s rows
+    ("ligero", 3, 1024, 128, 256, 8),      # C4's row count: 33 chunks
+    ("ligero", 3, 1024, 2048, 4096, 4),     # K1s rows, 33 chunks over 4 ranks
+    ("ligero", 3, 70, 64, 128, 4),         # 3 chunks over 4 ranks: one rank owns nothing
+    ("ligero", 3, 20, 64, 128, 3),         # single chunk: two ranks own nothing
+    ("ligero", 3, 40, 64, 128, 2),         # 2 chunks
+    ("ligero", 0, 3000, 128, 256, 3),      # ft63: 24 chunks over 3 ranks (8 each: one node per rank)
+    ("ligero", 0, 2900, 2048, 4096, 5),     # ft63 on K1n, 23 chunks over 5 ranks: up to three nodes per rank
+    ("ligero", 1, 700, 64, 128, 4),        # ft127
+    ("ligero", 2, 700, 64, 128, 3),        # ft191: cuts at chunks 5 and 11 (rows 212 and 468)
+    ("ligero", 2, 1500, 2048, 4096, 8),    # ft191 on K1n: 36 chunks over 8 ranks
+    ("sdig", 3, 140, 300, 0, 4),           # Brakedown: position-major shards (>= 24 local rows)
+    ("sdig", 3, 70, 3000, 0, 2),            # Brakedown, 4500-odd columns
 ]
 if len(sys.argv) > 1:
     CASES = [CASES[int(a)] for a in sys.argv[1:]]
@@ -51,7 +51,7 @@ if len(sys.argv) > 1:
 lib = _lib.lib()
 
 
-def run_case(kind, fid, n_rows, n_per_row, n_cols, G, slices):
+def run_case(kind, fid, n_rows, n_per_row, n_cols, G):
     L = O.limbs(fid)
     if kind == "ligero":
         oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
@@ -67,12 +67,7 @@ def run_case(kind, fid, n_rows, n_per_row, n_cols, G, slices):
     idb = (C.c_uint8 * 128)()
     assert lib.lcpc_comm_unique_id(idb) == 0
     assert bytes(idb)[8:] == b"\0" * 120 and int.from_bytes(bytes(idb)[:8], "little") > 0, "not the stand-in library: ids of the real RCCL are opaque"
-    if slices:
-        os.environ["LCPC_SHARD_SLICES"] = slices
-    try:
-        encs = [mk((g, G)) for g in range(G)]
-    finally:
-        os.environ.pop("LCPC_SHARD_SLICES", None)
+    encs = [mk((g, G)) for g in range(G)]
     n_open = encs[0].get_n_col_opens()
     opfs = [oc.prove(outer, oenc, mk_transcript(O.Transcript, oc.get_root(), n_open))[0] for oc in ocs]
     errs, bar = [], threading.Barrier(G)
@@ -118,9 +113,9 @@ def run_case(kind, fid, n_rows, n_per_row, n_cols, G, slices):
         t.join(180)
     alive = [t for t in th if t.is_alive()]
     if alive or errs:
-        print("FAILED case %r: %s%s" % ((kind, fid, n_rows, n_per_row, n_cols, G, slices), errs, " (ranks hung)" if alive else ""), flush=True)
+        print("FAILED case %r: %s%s" % ((kind, fid, n_rows, n_per_row, n_cols, G), errs, " (ranks hung)" if alive else ""), flush=True)
         os._exit(1)                         # (ranks blocked inside a collective cannot be joined)
-    print("ok", kind, fid, n_rows, n_per_row, n_cols, "G=%d" % G, "slices=%s" % slices, flush=True)
+    print("ok", kind, fid, n_rows, n_per_row, n_cols, "G=%d" % G, flush=True)
 
 
 for case in CASES:

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "missing export: " + s
     assert sorted(_lib.SYMBOLS) == syms, "ctypes table and header disagree"
-    assert L.lcpc_abi_version() == _lib.ABI_VERSION == 4
+    assert L.lcpc_abi_version() == _lib.ABI_VERSION == 5
     hdr = open(os.path.join(ROOT, "include", "lcpc_hip.h")).read()
     assert int(re.search(r"#define LCPC_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
 

@@ -15,7 +15,7 @@ import oracle_lib as O
 import struct
 
 import pyref as P
-from lcpc_amd.distributed import aligned_nodes, chunk_split, sharded_commit, slice_bounds, slots_per_rank
+from lcpc_amd.distributed import aligned_nodes, chunk_split, sharded_commit, slots_per_rank
 
 
 class OracleShardEngine:
@@ -49,7 +49,7 @@ class OracleShardEngine:
         self.commit_finish_cols(gathered, slots, 0, self.n_cols)
         return self.commit_merkle(want_root)
 
-    # ---- the four-step form (encode | hash a column range | leaf digests of a column range | tree) ----
+    # ---- the steps behind the two calls ----
     def commit_encode(self, local_coeffs, n_rows, borrow=False):
         rb, re, cb, ce, _ = self.layout(n_rows)
         rows = local_coeffs.numpy().view(np.uint64).reshape(re - rb, self.n_per_row, self.L)
@@ -128,7 +128,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q, slices=1):
+def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -137,7 +137,7 @@ def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q, slices=1):
         rb, re, _, _, _ = eng.layout(n_rows)
         coeffs = O.random_elems(fid, n_rows * n_per_row, 17).reshape(n_rows, n_per_row, -1)
         local = torch.from_numpy(coeffs[rb:re].copy().view(np.int64))
-        root = sharded_commit(eng, local, n_rows, slices=slices)
+        root = sharded_commit(eng, local, n_rows)
         q.put((rank, root, eng.hashes.tobytes()))
     finally:
         dist.destroy_process_group()
@@ -151,16 +151,11 @@ def _worker(rank, world, port, fid, n_rows, n_per_row, n_cols, q, slices=1):
     (3, 2, 500, 16, 32),     # ft191: 12 chunks over 3 ranks: cuts at chunks 2 and 8
     (2, 2, 57, 16, 32),      # ft191: 2 chunks and no possible cut: rank 1 owns the whole message as ONE node, which must carry ROOT
 ])
-@pytest.mark.parametrize("slices", [1, [0, 24, 40, 64]])
-def test_sharded_commit_gloo(world, fid, n_rows, n_per_row, n_cols, slices):
-    """slices: the four-step form of the same commit (encode | per column slice: hash, all-gather, leaf digests | tree) with
-    explicit slice boundaries (clipped to n_cols) -- one all-gather per slice, same root and same tree"""
+def test_sharded_commit_gloo(world, fid, n_rows, n_per_row, n_cols):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    if slices != 1:
-        slices = sorted(set(min(b, n_cols) for b in slices))
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fid, n_rows, n_per_row, n_cols, q, slices)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fid, n_rows, n_per_row, n_cols, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -174,19 +169,6 @@ def test_sharded_commit_gloo(world, fid, n_rows, n_per_row, n_cols, slices):
     for rank, root, hashes in res:
         assert root == oc.get_root(), "rank %d" % rank
         assert hashes == oc.hashes().tobytes()
-
-
-def test_slice_bounds_cover_and_align():
-    """the column slices of a sliced sharded commit partition [0, n_cols) at multiples of 256, none narrower than 1024 columns
-    (the rule of shard_slices() in csrc/shard.cpp; the GPU tests check that the library's slices give the unsliced tree)"""
-    for n_cols in (64, 1000, 1024, 2048, 4096, 5000, 252931, 262144, 1 << 20):
-        for S in (1, 2, 3, 4, 7, 16, 40):
-            b = slice_bounds(n_cols, S)
-            assert b[0] == 0 and b[-1] == n_cols and all(x < y for x, y in zip(b, b[1:]))
-            assert all(x % 256 == 0 for x in b[1:-1])
-            assert len(b) - 1 <= max(1, min(S, 16, n_cols // 1024))
-            if len(b) > 2:
-                assert min(y - x for x, y in zip(b, b[1:])) >= 512
 
 
 def test_aligned_nodes_cover_and_align():

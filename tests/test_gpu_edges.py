@@ -331,11 +331,10 @@ def test_concurrent_prove_and_verify_one_encoder(oracle):
         assert not errs, errs
 
 
-@pytest.mark.parametrize("switch", ["LCPC_NTT_PACKED", "LCPC_COMM_MONT"])
+@pytest.mark.parametrize("switch", ["LCPC_NTT_GENERAL"])
 def test_ab_switch_paths_stay_correct(oracle, switch):
-    """the A/B switches select alternative kernels (packed-limb NTT; Montgomery-form comm with the
-    reduction inside the hash kernel).  They are read when the context is created; both paths must keep producing the
-    oracle's commitment and proof."""
+    """LCPC_NTT_GENERAL selects the general NTT kernel (K1) where a shape-specialised plan exists.  It is read
+    when the context is created; the path must keep producing the oracle's commitment and proof."""
     import os
     O = oracle
     n = 3 * 4096 - 5
@@ -357,23 +356,15 @@ def test_ab_switch_paths_stay_correct(oracle, switch):
 
 
 @pytest.mark.parametrize("fid", [0, 1, 2, 3])
-@pytest.mark.parametrize("mont", [False, True])
-def test_brakedown_position_major_commitment_forms(oracle, fid, mont):
-    """Brakedown commits with >= 24 rows keep the commitment position-major on the device, by default as canonical values
-    (converted once in the input transpose; every level is linear and keeps the form; the column hash reads them as they are)
-    and with LCPC_COMM_MONT=1 in Montgomery form (the hash kernel reduces each element).  Everything that leaves the
-    library -- comm, coeffs, hashes, opened columns, proof bytes, the bincode of the commitment -- is the oracle's in both."""
-    import os
+def test_brakedown_position_major_commitment_forms(oracle, fid):
+    """Brakedown commits with >= 24 rows keep the commitment position-major on the device, as canonical values (converted once
+    in the input transpose; every level is linear and keeps the form; the column hash reads them as they are).  Everything that
+    leaves the library -- comm, coeffs, hashes, opened columns, proof bytes, the bincode of the commitment -- is the oracle's."""
     O = oracle
     n_per_row, n_rows = 900, 37
     oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 5)
     _, _, n_cols = oenc.get_dims(n_per_row)
-    if mont:
-        os.environ["LCPC_COMM_MONT"] = "1"
-    try:
-        enc = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 5)
-    finally:
-        os.environ.pop("LCPC_COMM_MONT", None)
+    enc = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 5)
     coeffs = O.random_elems(fid, n_rows * n_per_row - 11, 40 + fid)
     c = LcCommit.commit(coeffs, enc)
     oc = O.Commit.commit(coeffs, oenc, n_threads=4)
@@ -398,10 +389,8 @@ def test_brakedown_position_major_commitment_forms(oracle, fid, mont):
 @pytest.mark.parametrize("n_rows", [37, 40, 48, 49, 101, 130, 167])
 def test_brakedown_packed_tail_rows(oracle, n_rows):
     """Ft255 Brakedown, wide levels: a last group of <= 48 rows is computed by spmm_t_tail_kernel (lanes over (output, row) pairs,
-    per-lane matrix entries) instead of a mostly idle wave of the lane = row kernel; LCPC_SDIG_NO_TAIL=1 keeps the old mapping.
-    Both equal the oracle -- tail only (37, 40, 48 rows), just above the limit (49: no tail kernel), one and two whole groups
+    per-lane matrix entries) instead of a mostly idle wave of the lane = row kernel.  Equal to the oracle -- tail only (37, 40, 48 rows), just above the limit (49: no tail kernel), one and two whole groups
     before the tail (101, 130, 167).  n_per_row is large enough for the first levels to have >= 8192 outputs."""
-    import os
     O, fid, n_per_row = oracle, 3, 70000
     oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 9)
     _, _, n_cols = oenc.get_dims(n_per_row)
@@ -409,15 +398,9 @@ def test_brakedown_packed_tail_rows(oracle, n_rows):
     coeffs = O.random_elems(fid, n_rows * n_per_row - 3, 50 + n_rows)
     oc = O.Commit.commit(coeffs, oenc, n_threads=8)
     c = LcCommit.commit(coeffs, enc)
-    os.environ["LCPC_SDIG_NO_TAIL"] = "1"          # (switches are read once, when an encoder is created)
-    try:
-        enc_nt = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 9)
-    finally:
-        del os.environ["LCPC_SDIG_NO_TAIL"]
-    d = LcCommit.commit(coeffs, enc_nt)
-    assert c.get_root() == oc.get_root() == d.get_root()
+    assert c.get_root() == oc.get_root()
     assert (c.hashes() == oc.hashes()).all()
-    assert (c.comm() == oc.comm()).all() and (d.comm() == oc.comm()).all()
+    assert (c.comm() == oc.comm()).all()
 
 
 def test_many_short_rows_exceed_grid_y(oracle):
@@ -538,7 +521,7 @@ def test_refill_on_another_stream_right_after_async_commit(oracle):
 def test_limb_intermediate_allocation_failure_degrades(oracle):
     """K1s keeps the rows between its two passes as 29-bit limbs in a separate buffer (n_cols <= 2^15: on by default).  When that
     buffer cannot be allocated the commit must fall back to the packed intermediate, not fail: HIP keeps a failed call's error
-    until it is read, and the next launch check would otherwise return it.  LCPC_DEBUG_FAIL_MID (read at
+    until it is read, and the next launch check would otherwise return it.  LCPC_TEST_FAIL=mid (read at
     context creation) makes the allocation a request no device can satisfy, so the real hipMalloc failure path runs."""
     import os
     O, fid = oracle, 3
@@ -546,39 +529,17 @@ def test_limb_intermediate_allocation_failure_degrades(oracle):
     oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
     coeffs = O.random_elems(fid, n_rows * n_per_row - 5, 313)
     oc = O.Commit.commit(coeffs, oenc)
-    os.environ["LCPC_DEBUG_FAIL_MID"] = "1"
+    os.environ["LCPC_TEST_FAIL"] = "mid"
     try:
         enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
     finally:
-        del os.environ["LCPC_DEBUG_FAIL_MID"]
+        del os.environ["LCPC_TEST_FAIL"]
     for _ in range(2):                    # the first commit meets the failure, the second runs with mid_failed set
         c = LcCommit.commit(coeffs, enc)
         assert c.get_root() == oc.get_root()
         assert (c.comm() == oc.comm()).all() and (c.hashes() == oc.hashes()).all()
     ref = LcCommit.commit(coeffs, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols))
     assert ref.get_root() == oc.get_root()
-
-
-@pytest.mark.parametrize("n_rows,group", [(101, 34), (101, 26), (70, 64), (130, 17), (65, 1)])
-def test_brakedown_row_groups(oracle, n_rows, group):
-    """LCPC_SDIG_ROW_GROUP=g (read at context creation): the wide levels of an Ft255 Brakedown encode run as one launch of the packed
-    (output, row) kernel per group of <= g rows (equal groups), so that a group's gather range can stay in the Infinity Cache.
-    Same dot products, same reduction points: root, hashes and comm equal the oracle's and the ungrouped path's."""
-    import os
-    O, fid, n_per_row = oracle, 3, 70000
-    oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 9)
-    _, _, n_cols = oenc.get_dims(n_per_row)
-    coeffs = O.random_elems(fid, n_rows * n_per_row - 3, 150 + n_rows)
-    oc = O.Commit.commit(coeffs, oenc, n_threads=8)
-    os.environ["LCPC_SDIG_ROW_GROUP"] = str(group)
-    try:
-        enc = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 9)
-    finally:
-        del os.environ["LCPC_SDIG_ROW_GROUP"]
-    c = LcCommit.commit(coeffs, enc)
-    assert c.get_root() == oc.get_root()
-    assert (c.hashes() == oc.hashes()).all()
-    assert (c.comm() == oc.comm()).all()
 
 
 @pytest.mark.parametrize("fid,n_rows,n_per_row,n_cols", [
@@ -598,28 +559,19 @@ def test_brakedown_row_groups(oracle, n_rows, group):
 def test_fused_leaf_tree_small_commits(oracle, fid, n_rows, n_per_row, n_cols):
     """Small commitments hash their columns AND fold the first six Merkle levels in one launch (leaf_tree_kernel: a quad of lanes
     per column, the one or two chunks of its leaf message in sequence, then 64 leaves -> 1 through LDS), the rest of the tree
-    following from level 6.  The WHOLE `hashes` array -- leaf digests and every layer -- equals the oracle's and the unfused
-    path's (LCPC_NO_FUSED_LEAF_TREE=1 at context creation), for every field, one and two chunks, the narrowest and widest trees."""
-    import os
+    following from level 6.  The WHOLE `hashes` array -- leaf digests and every layer -- equals the oracle's, for every field, one
+    and two chunks, the narrowest and widest trees (the unfused kernels serve every larger commitment)."""
     O = oracle
     coeffs = O.random_elems(fid, n_rows * n_per_row - 1, 900 + n_rows)
     oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
     oc = O.Commit.commit(coeffs, oenc, n_threads=4)
     enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
-    os.environ["LCPC_NO_FUSED_LEAF_TREE"] = "1"
-    try:
-        enc_plain = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
-    finally:
-        del os.environ["LCPC_NO_FUSED_LEAF_TREE"]
-    c, d = LcCommit.commit(coeffs, enc), LcCommit.commit(coeffs, enc_plain)
-    assert c.get_root() == oc.get_root() == d.get_root()
-    assert (c.hashes() == oc.hashes()).all() and (d.hashes() == oc.hashes()).all()
+    c = LcCommit.commit(coeffs, enc)
+    assert c.get_root() == oc.get_root()
+    assert (c.hashes() == oc.hashes()).all()
     c.set_timing(True)
     LcCommit.commit(coeffs, enc, into=c)
-    d.set_timing(True)
-    LcCommit.commit(coeffs, enc_plain, into=d)
-    n_chunks = (32 + 8 * O.limbs(fid) * c.n_rows + 1023) // 1024
-    assert c.timings().hash_launches == 1 and d.timings().hash_launches == n_chunks     # (chunk CVs + their fold when unfused)
+    assert c.timings().hash_launches == 1
     root = oc.get_root()
     t = O.random_elems(fid, c.n_rows, 78)
     pf = c.prove(t, enc, mk_transcript(Transcript, root, enc.get_n_col_opens()))

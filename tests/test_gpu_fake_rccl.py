@@ -1,5 +1,5 @@
-"""The library's NATIVE sharded commit / prove (lcpc_comm_init, lcpc_commit_sharded_device incl. LCPC_COMMIT_ASYNC_TAIL and column
-slices, lcpc_prove_sharded_rccl) with 2 ... 8 ranks on the single-GPU test box.
+"""The library's NATIVE sharded commit / prove (lcpc_comm_init, lcpc_commit_sharded_device incl. LCPC_COMMIT_ASYNC_TAIL,
+lcpc_prove_sharded_rccl) with 2 ... 8 ranks on the single-GPU test box.
 
 RCCL itself refuses two ranks on one device, so until round 4 these entry points had only ever run with world = 1 (where every
 rank-dependent branch -- the compact node layout, the broadcasts of second and third nodes, ranks that own nothing, the order of
@@ -25,7 +25,7 @@ def test_native_exchange_many_ranks_one_gpu(tmp_path):
                         capture_output=True, text=True, timeout=300)
     assert cc.returncode == 0, cc.stderr[-3000:]
     env = dict(os.environ, LCPC_RCCL_LIB=so)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LCPC_SHARD_SLICES"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "native", "fake_rccl_worlds.py")], capture_output=True, text=True,
                        timeout=1500, env=env)

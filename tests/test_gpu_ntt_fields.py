@@ -108,29 +108,20 @@ def test_lazy_limb_range_stress_small_fields(oracle, fid):
 
 @pytest.mark.parametrize("fid,log_n", [(0, 13), (0, 14), (0, 17), (0, 20), (1, 13), (1, 16), (1, 19), (2, 14), (2, 18), (2, 20), (3, 13), (3, 14), (3, 15),
                                        (3, 17), (3, 18), (3, 19), (3, 20)])
-def test_tile_group_orders_agree(oracle, fid, log_n):
-    """the first pass's workgroup -> tile mapping (2^g neighbouring tiles back to back on one XCD, LCPC_NTT_TILE_GROUP=g; the
-    library clamps g to the tiles a row has) is a permutation of the same work: every order gives the same commitment, with 1, 3
-    and 5 rows (the row count enters the mapping), and the default's equals the oracle's"""
+def test_tile_group_order_row_counts(oracle, fid, log_n):
+    """the first pass's workgroup -> tile mapping (2^g neighbouring tiles back to back on one XCD, g by the run length; the row
+    count enters the mapping) is a permutation of the work: 1, 3 and 5 rows give the oracle's commitment and keep the coeffs copy"""
     O = oracle
     L = fid + 1
     n_cols, n_per_row = 1 << log_n, 1 << (log_n - 1)
     enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
     for n_rows in (1, 3, 5) if log_n <= 18 else (3,):
         coeffs = O.random_elems(fid, n_rows * n_per_row - 7, 5 * log_n + fid + n_rows)
         c = LcCommit.commit(coeffs, enc)
-        if n_rows == 3:
-            oc = O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4)
-            assert c.get_root() == oc.get_root() and (c.comm() == oc.comm()).all()
-        ref_comm, ref_hashes = c.comm(), c.hashes()
-        for g in ("0", "1", "2", "4", "6", "9"):
-            os.environ["LCPC_NTT_TILE_GROUP"] = g          # (switches are read once, when an encoder is created)
-            try:
-                enc_g = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
-            finally:
-                del os.environ["LCPC_NTT_TILE_GROUP"]
-            d = LcCommit.commit(coeffs, enc_g)
-            assert (d.comm() == ref_comm).all() and (d.hashes() == ref_hashes).all() and (d.coeffs() == coeffs_padded(coeffs, n_rows, n_per_row, L)).all(), (n_rows, g)
+        oc = O.Commit.commit(coeffs, oenc, n_threads=4)
+        assert c.get_root() == oc.get_root() and (c.comm() == oc.comm()).all() and (c.hashes() == oc.hashes()).all()
+        assert (c.coeffs() == coeffs_padded(coeffs, n_rows, n_per_row, L)).all()
 
 
 def coeffs_padded(coeffs, n_rows, n_per_row, L):
@@ -161,10 +152,10 @@ def test_commit_three_pass_shapes_small_fields(oracle, fid, log_n, rate):
     rows = np.zeros((n_cols, L), np.uint64)
     rows[:n - n_per_row] = coeffs[n_per_row:]
     assert (enc.encode(rows) == oc.comm()[n_cols:]).all()
-    os.environ["LCPC_NTT_NO_3PASS"] = "1"
+    os.environ["LCPC_NTT_GENERAL"] = "1"
     try:
         enc_g = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, rho=rho)
     finally:
-        del os.environ["LCPC_NTT_NO_3PASS"]
+        del os.environ["LCPC_NTT_GENERAL"]
     g = LcCommit.commit(coeffs, enc_g)
     assert (g.comm() == c.comm()).all() and (g.hashes() == c.hashes()).all()

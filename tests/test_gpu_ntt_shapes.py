@@ -87,7 +87,7 @@ def test_commit_three_pass_shapes(oracle, log_n, rate):
     """2^21 .. 2^26 columns (reachable on a 288 GB device: the reference's 38/39-rate dims at 2^30 .. 2^32 coefficients): s0 =
     log_n - 20 stages with the first-pass kernel over the whole rows, then the 2^20-point two-pass plan on each of the 2^s0 blocks
     of a row, canonical output only in block 0.  Commit (2 rows, the second ragged) and encode_rows against the oracle; the
-    general kernel's three-pass plan (LCPC_NTT_NO_3PASS=1) must give the same bytes."""
+    general kernel's three-pass plan (LCPC_NTT_GENERAL=1) must give the same bytes."""
     O, fid = oracle, 3
     n_cols = 1 << log_n
     n_per_row, rho = {"1/2": (n_cols // 2, (1, 2)), "1/4": (n_cols // 4, (1, 4)), "38/39": (n_cols * 38 // 39, (38, 39)),
@@ -106,11 +106,11 @@ def test_commit_three_pass_shapes(oracle, log_n, rate):
     rows[:n - n_per_row] = coeffs[n_per_row:]
     assert (enc.encode(rows) == oc.comm()[n_cols:]).all()
     if log_n <= 22:
-        os.environ["LCPC_NTT_NO_3PASS"] = "1"
+        os.environ["LCPC_NTT_GENERAL"] = "1"
         try:
             enc_g = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, rho=rho)
         finally:
-            del os.environ["LCPC_NTT_NO_3PASS"]
+            del os.environ["LCPC_NTT_GENERAL"]
         g = LcCommit.commit(coeffs, enc_g)
         assert (g.comm() == c.comm()).all() and (g.hashes() == c.hashes()).all()
 
@@ -118,17 +118,17 @@ def test_commit_three_pass_shapes(oracle, log_n, rate):
 @pytest.mark.parametrize("fid", [3, 1])
 def test_three_pass_tables_do_not_fit(oracle, fid):
     """the three-pass plan's first pack is ~2.3 x one row; when the device cannot hold it the context falls back to the general
-    kernel's plan instead of failing (LCPC_DEBUG_FAIL_3PASS simulates the failed allocation after the sub-sampled tables were
+    kernel's plan instead of failing (LCPC_TEST_FAIL=3pass simulates the failed allocation after the sub-sampled tables were
     made, so the clean-up runs): same commitment, and the context made afterwards without the hook is unaffected."""
     O = oracle
     log_n = 21
     n_cols, n_per_row = 1 << log_n, 1 << (log_n - 1)
     coeffs = O.random_elems(fid, n_per_row + 1000, 9 + fid)
-    os.environ["LCPC_DEBUG_FAIL_3PASS"] = "1"
+    os.environ["LCPC_TEST_FAIL"] = "3pass"
     try:
         enc_f = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
     finally:
-        del os.environ["LCPC_DEBUG_FAIL_3PASS"]
+        del os.environ["LCPC_TEST_FAIL"]
     enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
     a, b = LcCommit.commit(coeffs, enc_f), LcCommit.commit(coeffs, enc)
     assert a.get_root() == b.get_root() and (a.comm() == b.comm()).all()

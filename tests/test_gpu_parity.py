@@ -389,22 +389,71 @@ def test_brakedown_many_rows_vs_oracle(oracle, fid, n_per_row, n_rows, seed, cod
     assert (c.hashes() == oc.hashes()).all() and c.get_root() == oc.get_root()
 
 
-def test_commit_host_pipelined_vs_oracle(oracle):
-    """lcpc_commit from host memory above 64 MiB uploads the matrix in row batches overlapped with the row NTTs
-    (copy stream / compute stream): ragged 2^22-ish Ft255 input, everything compared with the oracle."""
+@pytest.mark.parametrize("source,stage", [("pageable", None), ("pinned", None), ("pinned", "1"), ("pageable", "0")])
+def test_commit_host_pipelined_vs_oracle(oracle, source, stage):
+    """lcpc_commit from host memory (== LcCommit::commit(&coeffs, &enc), lcpc-2d/src/lib.rs:299-301, 636-645) above 64 MiB uploads
+    the matrix in row batches overlapped with the row NTTs (copy stream / compute stream): ragged 2^22-ish Ft255 input, everything
+    compared with the oracle.  source: "pageable" = a plain numpy array (malloc / mmap memory the HIP runtime has never seen:
+    deliberately NOT pinned or registered), which the library stages through its own pinned bounce ring (timings().staged_slices
+    > 0), or "pinned" = hipHostMalloc memory (torch pin_memory), copied from directly (staged_slices == 0).
+    stage: LCPC_HOST_STAGE at context creation -- "1" forces the ring even for a pinned source, "0" leaves pageable memory to
+    the runtime's own path.  Every combination gives the oracle's commitment."""
+    import os
+    import torch
     O = oracle
     n = (1 << 22) - 5
     coeffs = O.random_elems(3, n, 55)
-    enc, oenc = LigeroEncoding.new(3, n), O.Encoding.ligero(3, n)
-    c = LcCommit.commit(coeffs, enc)
+    coeffs2 = O.random_elems(3, n, 56)
+    if source == "pinned":
+        keep = [torch.from_numpy(x.view(np.int64)).pin_memory() for x in (coeffs, coeffs2)]
+        src, src2 = (t.numpy().view(np.uint64) for t in keep)
+        assert keep[0].is_pinned()
+    else:
+        src, src2 = coeffs, coeffs2
+        assert not torch.from_numpy(src.view(np.int64)).is_pinned()
+    if stage is not None:
+        os.environ["LCPC_HOST_STAGE"] = stage
+    try:
+        enc = LigeroEncoding.new(3, n)
+    finally:
+        os.environ.pop("LCPC_HOST_STAGE", None)
+    oenc = O.Encoding.ligero(3, n)
+    c = LcCommit.commit(src, enc)
+    staged = c.timings().staged_slices
+    expect_staged = (source == "pageable" and stage != "0") or stage == "1"
+    assert (staged > 0) == expect_staged, (source, stage, staged)
+    if expect_staged:
+        assert staged >= 16          # one per row batch at least (128 MiB in 16 batches through 4 MiB buffers: 32)
     oc = O.Commit.commit(coeffs, oenc, n_threads=8)
     assert c.get_root() == oc.get_root()
     assert (c.hashes() == oc.hashes()).all()
     assert (c.coeffs() == oc.coeffs()).all()
     assert (c.comm() == oc.comm()).all()
-    # and again on the same context (stream/event reuse), different data
-    coeffs2 = O.random_elems(3, n, 56)
-    assert LcCommit.commit(coeffs2, enc).get_root() == O.Commit.commit(coeffs2, oenc, n_threads=8).get_root()
+    # and again on the same context and object (stream / event / ring reuse), different data
+    assert LcCommit.commit(src2, enc, into=c).get_root() == O.Commit.commit(coeffs2, oenc, n_threads=8).get_root()
+    assert (c.timings().staged_slices > 0) == expect_staged
+
+
+@pytest.mark.parametrize("kind,fid,n", [("sdig", 3, (1 << 19) + 77), ("ligero", 0, (1 << 21) - 3), ("ligero", 3, (1 << 18) + 1)])
+def test_commit_host_single_upload_staged(oracle, kind, fid, n):
+    """the one-copy form of lcpc_commit (Brakedown, commitments below 64 MiB or 16 rows) from pageable memory of >= 4 MiB also goes
+    through the bounce ring -- ring buffers sized for a small upload, slices that do not divide it -- and below 4 MiB it is left to
+    the runtime (staged_slices == 0)."""
+    O = oracle
+    L = O.limbs(fid)
+    coeffs = O.random_elems(fid, n, 91)
+    if kind == "sdig":
+        enc, oenc = SdigEncoding.new(fid, n, 3), O.Encoding.sdig(fid, n, 3)
+    else:
+        enc, oenc = LigeroEncoding.new(fid, n), O.Encoding.ligero(fid, n)
+    c = LcCommit.commit(coeffs, enc)
+    assert c.timings().staged_slices >= (n * 8 * L) // (4 << 20)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=8)
+    assert c.get_root() == oc.get_root() and (c.coeffs() == oc.coeffs()).all() and (c.hashes() == oc.hashes()).all()
+    small = coeffs[:(3 << 20) // (8 * L)]
+    d = LcCommit.commit(small, enc)
+    assert d.timings().staged_slices == 0
+    assert d.get_root() == O.Commit.commit(small, oenc, n_threads=8).get_root()
 
 
 def test_brakedown_commit_device_fused_copy(oracle):
@@ -518,8 +567,7 @@ def test_brakedown_limb_dot_product_small_fields(oracle, fid, n_per_row, n_rows)
     """Ft127 / Ft191 on the position-major path accumulate their dot products carry-free on 5 / 7 limbs of 29 bits
     (field_ln.h lazy_mac, matrix values in the R'-Montgomery limb form) like Ft255's lazy29: a level wide enough for the
     4-outputs-per-workgroup kernel and sliced ones, random rows plus rows of all p-1 (every product at its largest), against
-    the oracle and against the wide-accumulator path (LCPC_SDIG_WIDE=1)."""
-    import os
+    the oracle."""
     import pyref as P
     O = oracle
     F = P.FIELDS[fid]
@@ -533,10 +581,3 @@ def test_brakedown_limb_dot_product_small_fields(oracle, fid, n_per_row, n_rows)
     oc = O.Commit.commit(coeffs, oenc, n_threads=4)
     assert (c.comm() == oc.comm()).all()
     assert (c.hashes() == oc.hashes()).all() and c.get_root() == oc.get_root()
-    os.environ["LCPC_SDIG_WIDE"] = "1"
-    try:
-        enc_w = SdigEncoding.new_from_dims(fid, n_per_row, n_cols, 21, 3)
-    finally:
-        del os.environ["LCPC_SDIG_WIDE"]
-    w = LcCommit.commit(coeffs, enc_w)
-    assert w.get_root() == c.get_root() and (w.hashes() == c.hashes()).all()

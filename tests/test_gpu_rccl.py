@@ -15,38 +15,30 @@ from lcpc_amd.distributed import HipShardEngine
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind,fid,n_rows,n_per_row,n_cols,slices", [
-    ("ligero", 3, 512, 256, 512, None),      # headline row count: 17 BLAKE3 chunks per leaf (too narrow to slice)
-    ("ligero", 3, 20, 64, 128, None),        # single chunk
-    ("ligero", 0, 300, 128, 256, None),
-    ("sdig", 3, 70, 300, 0, None),
-    ("ligero", 3, 512, 2048, 4096, None),    # the default: everything in sequence on the caller's stream
-    ("ligero", 3, 512, 2048, 4096, "4"),     # LCPC_SHARD_SLICES=4: column slices, the exchange of each on the commitment's second stream
-    ("ligero", 3, 20, 4096, 8192, "7"),      # single chunk (the slice's "node" is its digest), 7 slices
-    ("ligero", 0, 300, 2048, 4096, "3"),
-    ("ligero", 2, 700, 128, 256, None),      # ft191 (24-byte elements straddle chunks; world 1: one shard)
-    ("ligero", 3, 40, 64, 128, None),        # 2 chunks, world 1: the rank's one node IS the whole message and must carry ROOT
-    ("ligero", 3, 100, 2048, 4096, "3"),     # 4 chunks, world 1, sliced
-    ("sdig", 3, 70, 3000, 0, None),          # 4500-odd columns: slice ends at multiples of 256, position-major commitment
-    ("sdig", 3, 70, 3000, 0, "16"),          # asks for more slices than 1024-column slices fit: clamped
+@pytest.mark.parametrize("kind,fid,n_rows,n_per_row,n_cols", [
+    ("ligero", 3, 512, 256, 512),      # headline row count: 17 BLAKE3 chunks per leaf
+    ("ligero", 3, 20, 64, 128),        # single chunk
+    ("ligero", 0, 300, 128, 256),
+    ("sdig", 3, 70, 300, 0),
+    ("ligero", 3, 512, 2048, 4096),
+    ("ligero", 3, 20, 4096, 8192),     # single chunk (the "node" is the digest)
+    ("ligero", 0, 300, 2048, 4096),
+    ("ligero", 2, 700, 128, 256),      # ft191 (24-byte elements straddle chunks; world 1: one shard)
+    ("ligero", 3, 40, 64, 128),        # 2 chunks, world 1: the rank's one node IS the whole message and must carry ROOT
+    ("ligero", 3, 100, 2048, 4096),    # 4 chunks, world 1
+    ("sdig", 3, 70, 3000, 0),          # 4500-odd columns, position-major commitment
 ])
-def test_native_exchange_world1(oracle, kind, fid, n_rows, n_per_row, n_cols, slices):
-    import os
+def test_native_exchange_world1(oracle, kind, fid, n_rows, n_per_row, n_cols):
     O = oracle
     L = O.limbs(fid)
     coeffs = O.random_elems(fid, n_rows * n_per_row, 61)
-    if slices is not None:
-        os.environ["LCPC_SHARD_SLICES"] = slices          # (read once, when the encoder is created)
-    try:
-        if kind == "ligero":
-            enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=(0, 1))
-            oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
-        else:
-            oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 11, 3)
-            _, _, nc = oenc.get_dims(n_per_row)
-            enc = SdigEncoding(fid, None, 11, 3, 0, (0, 1), _dims=(n_per_row, nc))
-    finally:
-        os.environ.pop("LCPC_SHARD_SLICES", None)
+    if kind == "ligero":
+        enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=(0, 1))
+        oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+    else:
+        oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 11, 3)
+        _, _, nc = oenc.get_dims(n_per_row)
+        enc = SdigEncoding(fid, None, 11, 3, 0, (0, 1), _dims=(n_per_row, nc))
     eng = HipShardEngine(enc)
     with pytest.raises(lcpc_amd.LcpcError) as e:          # no communicator yet
         eng.commit_native(torch.zeros(8, dtype=torch.int64, device="cuda"), n_rows)
@@ -91,21 +83,14 @@ def test_comm_init_argument_checks():
     assert lib.lcpc_comm_init(enc._h, idb, 5, 4) == lcpc_amd.ERR_ARG
 
 
-@pytest.mark.parametrize("slices", [None, "3"])
-def test_native_exchange_async_tail_two_commitments(oracle, slices):
+def test_native_exchange_async_tail_two_commitments(oracle):
     """LCPC_COMMIT_ASYNC_TAIL: exchange, leaf digests and tree on the commitment's own stream, the caller's stream free after the
     column hash.  Two commitments of ONE sharded encoder are filled alternately, back to back, with different polynomials and no
     host synchronisation in between (the second one's encode overlaps the first one's exchange; their collectives share the
     communicator and must keep their order); then a refill of each (which has to wait for the object's own tail).  Roots, whole
     `hashes`, coeffs and proof bytes of both equal the oracle's for the LAST polynomial committed into each."""
-    import os
     O, fid, n_rows, n_per_row, n_cols = oracle, 3, 512, 2048, 4096
-    if slices is not None:
-        os.environ["LCPC_SHARD_SLICES"] = slices
-    try:
-        enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=(0, 1))
-    finally:
-        os.environ.pop("LCPC_SHARD_SLICES", None)
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=(0, 1))
     oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
     a, b = HipShardEngine(enc), HipShardEngine(enc)
     a.comm_init()                                   # the communicator belongs to the encoder: both engines use it

@@ -13,25 +13,9 @@ from lcpc_amd.distributed import HipShardEngine, aligned_nodes, chunk_split, slo
 pytestmark = pytest.mark.gpu
 
 
-def run_sharded(mk_enc, G, coeffs_rows, n_rows, slices=None):
-    """coeffs_rows: torch int64 cuda tensor [n_rows, n_per_row, L].  slices: None = the two-call form (shard, finish); a list of
-    column boundaries = the four-step form (encode | per slice: hash, gather, leaf digests | tree), slices in the given order"""
+def run_sharded(mk_enc, G, coeffs_rows, n_rows):
+    """coeffs_rows: torch int64 cuda tensor [n_rows, n_per_row, L]: the two-call form (shard, finish) around an emulated all-gather"""
     engines = [HipShardEngine(mk_enc((g, G))) for g in range(G)]
-    if slices is not None:
-        for eng in engines:
-            rb, re, cb, ce, nch = eng.layout(n_rows)
-            eng.commit_encode(coeffs_rows[rb:re].contiguous(), n_rows)
-        eb = engines[0].elem_bytes
-        slots = slots_per_rank(nch, G, eb)
-        for c0, c1 in slices:
-            nodes = [eng.commit_hash_cols(c0, c1) for eng in engines]
-            gathered = torch.zeros((G * slots, c1 - c0, 32), dtype=torch.uint8, device="cuda")
-            for g, nd in enumerate(nodes):
-                assert nd.shape[0] == len(aligned_nodes(*chunk_split(nch, G, eb)[g]))
-                gathered[g * slots:g * slots + nd.shape[0]] = nd
-            for eng in engines:
-                eng.commit_finish_cols(gathered.clone(), slots, c0, c1)
-        return [eng.commit_merkle() for eng in engines], engines
     nodes = []
     for g, eng in enumerate(engines):
         rb, re, cb, ce, nch = eng.layout(n_rows)
@@ -71,16 +55,12 @@ def run_sharded(mk_enc, G, coeffs_rows, n_rows, slices=None):
     (2, 170, 64, 128, 1),       # "sharded" over one rank, 4 chunks = one node
     (3, 40, 64, 128, 1),        # the same for ft255 (2 chunks)
 ])
-@pytest.mark.parametrize("sliced", [False, True])
-def test_sharded_equals_unsharded(oracle, fid, n_rows, n_per_row, n_cols, G, sliced):
-    """sliced: the four-step form with three uneven column slices, not aligned to anything, taken out of order"""
+def test_sharded_equals_unsharded(oracle, fid, n_rows, n_per_row, n_cols, G):
     O = oracle
     L = O.limbs(fid)
     coeffs = O.random_elems(fid, n_rows * n_per_row, 19)
     dev = torch.from_numpy(coeffs.view(np.int64)).cuda().reshape(n_rows, n_per_row, L)
-    a, b = n_cols // 4 + 3, n_cols // 2 + 1
-    slices = [(a, b), (0, a), (b, n_cols)] if sliced else None
-    roots, engines = run_sharded(lambda sh: LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=sh), G, dev, n_rows, slices)
+    roots, engines = run_sharded(lambda sh: LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=sh), G, dev, n_rows)
     ref = LcCommit.commit(coeffs, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols))
     oc = O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4)
     assert ref.get_root() == oc.get_root()
@@ -143,19 +123,16 @@ def test_ft191_shard_boundaries_are_row_boundaries():
 
 
 @pytest.mark.parametrize("fid,n_per_row,n_rows,G", [(3, 300, 70, 2), (3, 300, 70, 4), (0, 400, 300, 2), (3, 257, 40, 8), (2, 300, 300, 3)])
-@pytest.mark.parametrize("sliced", [False, True])
-def test_sharded_brakedown_equals_unsharded(oracle, fid, n_per_row, n_rows, G, sliced):
+def test_sharded_brakedown_equals_unsharded(oracle, fid, n_per_row, n_rows, G):
     """Brakedown shards the same way (rows independent, matrices replicated on every rank): shards with
-    >= 16 local rows take the position-major SpMM path, smaller ones the row-major one.  sliced: the four-step form, two column
-    slices (the position-major commitment is then read from a column offset)."""
+    >= 24 local rows take the position-major SpMM path, smaller ones the row-major one."""
     O = oracle
     L = O.limbs(fid)
     oenc = O.Encoding.sdig_from_dims(fid, n_per_row, 0, 11, 3)
     _, _, n_cols = oenc.get_dims(n_per_row)
     coeffs = O.random_elems(fid, n_rows * n_per_row, 23)
     dev = torch.from_numpy(coeffs.view(np.int64)).cuda().reshape(n_rows, n_per_row, L)
-    slices = [(0, n_cols // 3), (n_cols // 3, n_cols)] if sliced else None
-    roots, engines = run_sharded(lambda sh: SdigEncoding(fid, None, 11, 3, 0, sh, _dims=(n_per_row, n_cols)), G, dev, n_rows, slices)
+    roots, engines = run_sharded(lambda sh: SdigEncoding(fid, None, 11, 3, 0, sh, _dims=(n_per_row, n_cols)), G, dev, n_rows)
     oc = O.Commit.commit(coeffs, oenc, n_threads=4)
     for r in roots:
         assert r == oc.get_root()
@@ -247,19 +224,16 @@ def test_sharded_prove_equals_unsharded(oracle, kind, fid, n_rows, n_per_row, n_
 
 
 def test_split_phase_state_errors():
-    """hash / finish / merkle of the four-step form refuse to run before the encode step (LCPC_ERR_STATE), and column ranges
-    outside [0, n_cols] are LCPC_ERR_ARG"""
+    """the finish step of the split-phase form refuses to run before its shard step (LCPC_ERR_STATE) and with another row count than
+    the shard step's (LCPC_ERR_ARG); after a finish the commit is done: a second finish is refused again"""
     import ctypes as C
     lib = lcpc_amd._lib.lib()
     eng = HipShardEngine(LigeroEncoding.new_from_dims(3, 64, 128, shard=(0, 2)))
     buf = torch.zeros((4, 128, 32), dtype=torch.uint8, device="cuda")
     p = C.c_void_p(buf.data_ptr())
-    assert lib.lcpc_commit_shard_hash_device(eng.cm._h, 0, 128, None, p) == lcpc_amd.ERR_STATE
-    assert lib.lcpc_commit_finish_cols_device(eng.cm._h, p, 1, 0, 128, None) == lcpc_amd.ERR_STATE
-    assert lib.lcpc_commit_finish_merkle_device(eng.cm._h, None, None) == lcpc_amd.ERR_STATE
+    assert lib.lcpc_commit_finish_device(eng.cm._h, p, 40, 1, None, None) in (lcpc_amd.ERR_STATE, lcpc_amd.ERR_ARG)
     rb, re, _, _, _ = eng.layout(40)
-    eng.commit_encode(torch.zeros(((re - rb) * 64, 4), dtype=torch.int64, device="cuda"), 40)
-    assert lib.lcpc_commit_shard_hash_device(eng.cm._h, 0, 129, None, p) == lcpc_amd.ERR_ARG
-    assert lib.lcpc_commit_shard_hash_device(eng.cm._h, 5, 4, None, p) == lcpc_amd.ERR_ARG
-    assert lib.lcpc_commit_finish_cols_device(eng.cm._h, p, 1, 0, 200, None) == lcpc_amd.ERR_ARG
-    assert lib.lcpc_commit_shard_hash_device(eng.cm._h, 7, 7, None, p) == 0            # an empty range is a no-op
+    eng.commit_shard(torch.zeros(((re - rb) * 64, 4), dtype=torch.int64, device="cuda"), 40)
+    assert lib.lcpc_commit_finish_device(eng.cm._h, p, 41, 1, None, None) == lcpc_amd.ERR_ARG
+    assert lib.lcpc_commit_finish_device(eng.cm._h, p, 40, 2, None, None) == 0
+    assert lib.lcpc_commit_finish_device(eng.cm._h, p, 40, 2, None, None) == lcpc_amd.ERR_STATE
