@@ -11,6 +11,10 @@ one synthetic coefficient vector that is already resident in HBM when the timed 
 RCCL exchange of subtree chaining values inside the library (strong scaling; `--scaling weak` keeps 512 rows per GPU).
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 
+Inputs (SURVEY.md 8d "Synthetic inputs"): the job's coefficient vector is Field::random over ChaCha20Rng::from_seed([0; 32]), stream
+0, drawn ON THE DEVICE (lcpc_random_coeffs_device); the cpu_baseline leg draws the same vector on the host with the oracle's
+generator, checks the two element for element, and commits it: `root_equals_hip_root` speaks about the timed data itself.
+
 Timing protocol (mirroring rough_bench, lcpc-ligero-pc/src/tests.rs:78-98): the encoder is built outside
 the timed region; W warm-up steps; K steps between barrier + synchronize brackets give `value` / `ms_per_step` (mean);
 HIP events between the same steps give `min_ms_per_step`; afterwards, untimed: one instrumented step (kernel-group
@@ -47,14 +51,12 @@ def kernel_stamp():
     return h.hexdigest()[:16]
 
 
-def device_random_coeffs(torch, n, L, seed, device):
-    """uniform 64-bit limbs with the top limb masked to 62 bits: every element is < p for all four test
-    fields (their top limbs are >= 2^62), i.e. a valid fully-reduced Montgomery representation."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    t = torch.randint(-(1 << 63), (1 << 63) - 1, (n, L), dtype=torch.int64, device=device, generator=g)
-    t[:, L - 1] &= (1 << 62) - 1
-    return t
+INPUT_SEED = 0              # ChaCha20Rng::from_seed([INPUT_SEED; 32]), stream 0
+
+
+def job_coeffs(enc, n):
+    """the job's coefficient vector on the encoder's device: n x Field::random from the fixed generator (module docstring)"""
+    return enc.random_coeffs_device(n, seed=INPUT_SEED)
 
 
 def sample_power(step, torch, seconds=1.6):
@@ -133,19 +135,16 @@ def host_memory_available():
     return avail
 
 
-def cpu_commit(O, np, log_len, n_per_row, n_cols, threads, seed=1):
-    """one oracle commit (C port of the reference algorithm, OpenMP over rows / 32-column blocks) of 2^log_len Ft255
-    coefficients with the headline row shape; returns (rate, seconds, root, coeffs)."""
-    n = 1 << log_len
+def cpu_commit(O, coeffs, n_per_row, n_cols, threads):
+    """one oracle commit (C port of the reference algorithm, OpenMP over rows / 32-column blocks) of `coeffs` (Ft255 Montgomery
+    limbs on the host) with the headline row shape; returns (rate, seconds, root)."""
     enc = O.Encoding.ligero_from_dims(3, n_per_row, n_cols)
-    rng = np.random.default_rng(seed)
-    coeffs = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)      # < p, as on the GPU side
     t0 = time.perf_counter()
     c = O.Commit.commit(coeffs, enc, n_threads=threads)
     dt = time.perf_counter() - t0
     root = c.get_root()
     del c
-    return n / dt, dt, root, coeffs
+    return len(coeffs) / dt, dt, root
 
 
 def self_launch(args):
@@ -256,7 +255,7 @@ def main():
 
     if not distributed:
         enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=local_rank)
-        coeffs = device_random_coeffs(torch, n_coeffs_job, L, 1234, dev)
+        coeffs = job_coeffs(enc, n_coeffs_job)
         cm = LcCommit(enc)                     # ONE LcCommit object refilled every step (buffers reused; no hipMalloc in the loop)
 
         def step(sync=False, borrow_=borrow):
@@ -266,7 +265,11 @@ def main():
         engine = HipShardEngine(enc)
         cm = engine.cm
         rb, re, cb, ce, n_chunks = engine.layout(n_rows_total)
-        coeffs = device_random_coeffs(torch, max(re - rb, 1) * n_per_row, L, 1234 + rank, dev)
+        # every rank draws the job's whole vector (one serial stream: element i is the i-th accepted candidate) and keeps its rows
+        full = job_coeffs(enc, n_coeffs_job)
+        coeffs = full[rb * n_per_row:max(re, rb + 1) * n_per_row].clone() if re > rb else full[:n_per_row].clone()
+        if args.no_check:
+            del full
         # bring the communicators up outside the measured region (RCCL connects lazily on the first collective)
         t_init = torch.ones(1, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t_init)
@@ -319,16 +322,9 @@ def main():
 
     check = None
     if distributed and not args.no_check:
-        # first step of every N > 1 run (untimed): every rank regenerates the whole coefficient matrix (rank r's rows come
-        # from seed 1234 + r) and compares the sharded root with a plain single-context commit of it
+        # first step of every N > 1 run (untimed): every rank compares the sharded root with a plain single-context commit of
+        # the job's whole vector
         root_sharded = step(sync=True)
-        parts = []
-        for r in range(world):
-            e_r = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=local_rank, shard=(r, world))
-            rb_r, re_r, _, _, _ = HipShardEngine(e_r).layout(n_rows_total)
-            parts.append(device_random_coeffs(torch, max(re_r - rb_r, 1) * n_per_row, L, 1234 + r, dev)[:(re_r - rb_r) * n_per_row])
-            del e_r
-        full = torch.cat(parts, dim=0).contiguous()
         ref = LcCommit.commit_device(full.data_ptr(), n_coeffs_job, LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, device=local_rank), stream)
         ok = ref.get_root() == root_sharded
         print("[rank %d] sharded root %s unsharded root: %s" % (rank, "==" if ok else "!=", root_sharded.hex()), file=sys.stderr)
@@ -338,7 +334,7 @@ def main():
             raise SystemExit("sharded commit root mismatch")
         check = {"sharded_root_equals_unsharded_root": True, "on": "all %d ranks, the job's own coefficients, before the timed region" % world,
                  "root": root_sharded.hex()}
-        del full, parts, ref
+        del full, ref
         torch.cuda.empty_cache()
 
     # setup, not warm-up steps: a device that sat idle while the inputs were generated needs tens of milliseconds to
@@ -372,6 +368,62 @@ def main():
         t = torch.tensor([min_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         min_ms = float(t.item())
+
+    # N > 1, native exchange, untimed region: what ONE run must tell about scaling
+    red_dev = dev if args.dist_backend == "nccl" else "cpu"
+
+    def over_ranks(vals, op):
+        t = torch.tensor(vals, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=op)
+        return [float(x) for x in t]
+
+    scaling_extra = None
+    if distributed and args.exchange == "native":
+        scaling_extra = {}
+        if async_loop:
+            # (a) the roots the async-tail commits of the timed loop left in BOTH objects (they were never looked at)
+            want = check["root"] if check else engines[0].cm.get_root().hex()
+            roots_ok = all(e.cm.get_root().hex() == want for e in engines)
+            if over_ranks([1.0 if roots_ok else 0.0], dist.ReduceOp.MIN)[0] == 0.0:
+                raise SystemExit("bench.py: an async-tail commit of the timed loop left a wrong root")
+            scaling_extra["async_tail_roots_checked"] = "both LcCommit objects of every rank after the timed loop == " + \
+                                                       ("the checked sharded root" if check else "each other")
+        # (b) the serial figure: ONE object, exchange + leaf digests + tree in sequence on the launch stream (what --no-async-tail times;
+        #     comparable with the per-commit numbers of rounds 1-3)
+        def serial_step():
+            return engine.commit_native(coeffs, n_rows_total, want_root=False, borrow=borrow)
+        for _ in range(2):
+            serial_step()
+        fence()
+        sev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t1 = time.perf_counter()
+        sev[0].record()
+        for i in range(args.steps):
+            serial_step()
+            sev[i + 1].record()
+        fence()
+        sdt = time.perf_counter() - t1
+        s_ms = [sev[i].elapsed_time(sev[i + 1]) for i in range(args.steps)]
+        sdt, s_min = over_ranks([sdt, min(s_ms)], dist.ReduceOp.MAX)
+        scaling_extra["serial_ms_per_step"] = round(sdt / args.steps * 1e3, 4)
+        scaling_extra["serial_min_ms_per_step"] = round(s_min, 4)
+        scaling_extra["serial_value"] = n_coeffs_job * args.steps / sdt
+        # (c) the wire alone: 20 x the library's own exchange on the real payload (lcpc_shard_exchange_probe)
+        for _ in range(3):
+            engine.exchange_probe()
+        fence()
+        pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        pe[0].record()
+        for _ in range(20):
+            b_in = engine.exchange_probe()
+        pe[1].record()
+        fence()
+        p_ms, b_max = over_ranks([pe[0].elapsed_time(pe[1]) / 20, float(b_in)], dist.ReduceOp.MAX)
+        scaling_extra["exchange_probe"] = {"bytes_in": int(b_max), "ms": round(p_ms, 4), "GBps_in": round(b_max / (p_ms * 1e-3) / 1e9, 2) if p_ms > 0 else None,
+                                           "reps": 20, "what": "ncclAllGather of node 0 of every rank + grouped ncclBroadcasts of the extra nodes, exactly as the "
+                                                                "commit enqueues them, back to back on the launch stream; bytes_in = received from other ranks "
+                                                                "per exchange, MAX over ranks; ms = MAX over ranks"}
+        scaling_extra["rccl_version"] = HipShardEngine.rccl_version()
 
     # kernel-group timing with HIP events on the launch stream (one extra, untimed, instrumented step)
     cm.set_timing(True)
@@ -444,24 +496,36 @@ def main():
         torch.cuda.synchronize()
         if not args.no_e2e:
             try:
+                import numpy as np
                 host = torch.empty((n_coeffs_job, L), dtype=torch.int64).pin_memory()
                 host.copy_(coeffs)
+                pageable = np.empty((n_coeffs_job, L), dtype=np.int64)      # plain malloc / mmap memory: what a Rust Vec<F> is
+                np.copyto(pageable, host.numpy())
                 cm2 = LcCommit(enc)
                 root_buf = (C.c_uint8 * 32)()
                 lib = _lcpc_lib.lib()
-                ts = []
-                for _ in range(4):
-                    t1 = time.perf_counter()
-                    cm2._check(lib.lcpc_commit(cm2._h, C.c_void_p(host.data_ptr()), n_coeffs_job, root_buf))
-                    ts.append(time.perf_counter() - t1)
-                ts = ts[1:]
                 root_dev = step(sync=True).get_root()
-                e2e = {"ms_mean": round(sum(ts) / len(ts) * 1e3, 2), "ms_min": round(min(ts) * 1e3, 2),
-                       "value": n_coeffs_job / (sum(ts) / len(ts)), "unit": "field-elements/s",
-                       "root_matches_device_commit": bytes(root_buf) == root_dev,
-                       "what": "lcpc_commit from pinned host memory: H2D of the coefficients (row batches overlapped with the NTTs) + "
-                               "commit + root D2H; PCIe-inclusive, reported beside `value`, never as it"}
-                del cm2, host
+
+                def host_leg(ptr):
+                    ts = []
+                    for _ in range(4):
+                        t1 = time.perf_counter()
+                        cm2._check(lib.lcpc_commit(cm2._h, C.c_void_p(ptr), n_coeffs_job, root_buf))
+                        ts.append(time.perf_counter() - t1)
+                    ts = ts[1:]
+                    return {"ms_mean": round(sum(ts) / len(ts) * 1e3, 2), "ms_min": round(min(ts) * 1e3, 2), "value": n_coeffs_job / (sum(ts) / len(ts)),
+                            "root_matches_device_commit": bytes(root_buf) == root_dev, "staged_slices": cm2.timings().staged_slices}
+                pin = host_leg(host.data_ptr())
+                pag = host_leg(pageable.ctypes.data)
+                pag["vs_pinned"] = round(pag["ms_mean"] / pin["ms_mean"], 3)
+                e2e = dict(pin)
+                e2e.update({"unit": "field-elements/s", "pageable": pag,
+                            "what": "lcpc_commit (== LcCommit::commit(&coeffs, &enc), lcpc-2d/src/lib.rs:299-301) from host memory: H2D of the "
+                                    "coefficients (row batches overlapped with the NTTs) + commit + root D2H; PCIe-inclusive, reported beside "
+                                    "`value`, never as it.  Top level: from pinned memory (direct async copies).  `pageable`: from a plain "
+                                    "malloc'ed buffer -- what a Rust caller's Vec is -- staged through the library's pinned bounce ring by the "
+                                    "host pool (staged_slices copies); profiles/r05_host_path.jsonl has the A/B against the runtime's own path"})
+                del cm2, host, pageable
             except Exception as ex:          # e.g. not enough pinnable host memory: the headline does not depend on it
                 e2e = {"error": repr(ex)}
 
@@ -490,6 +554,12 @@ def main():
         # exchange_exposed_ms: from the end of the local column hash to the arrival of the leaf digests (wire + leaf-digest time)
         ph = torch.tensor([tm.encode_ms, tm.hash_ms, tm.merkle_ms, tm.exchange_exposed_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+        # (d) per rank: min / max over ranks of each phase of the instrumented commit
+        mine = [tm.encode_ms, tm.hash_ms, tm.exchange_wire_ms, max(0.0, tm.merkle_ms - tm.exchange_wire_ms)]
+        lo, hi = over_ranks(mine, dist.ReduceOp.MIN), over_ranks(mine, dist.ReduceOp.MAX)
+        scaling_extra["per_rank_ms"] = {k: [round(lo[i], 3), round(hi[i], 3)] for i, k in enumerate(("encode", "hash", "exchange_exposed", "finish_tree"))}
+        scaling_extra["per_rank_ms"]["what"] = "[min, max] over ranks, one instrumented commit in sequence: exchange_exposed = end of the local hash -> " \
+                                               "end of the collectives on the stream; finish_tree = leaf digests + Merkle tree"
         shard_ms = {"local_encode": round(float(ph[0]), 3), "local_hash": round(float(ph[1]), 3),
                     "exchange_tail_plus_merkle": round(float(ph[2]), 3), "exchange_exposed_ms": round(float(ph[3]), 3),
                     "async_tail": not args.no_async_tail,
@@ -507,7 +577,8 @@ def main():
                                    (world, ("RCCL inside the library" + ("" if args.no_async_tail else "; two LcCommit objects filled alternately, "
                                             "commit k's exchange + leaf digests + tree on its own stream while commit k + 1 encodes "
                                             "(LCPC_COMMIT_ASYNC_TAIL)")) if args.exchange == "native" else "torch.distributed all-gather")) if distributed else "none",
-                      "input": "device-resident (HBM)",
+                      "input": "device-resident (HBM); Field::random over ChaCha20Rng::from_seed([%d; 32]), stream 0, drawn on the device "
+                               "(lcpc_random_coeffs_device; SURVEY.md 8d)" % INPUT_SEED,
                       "coeffs": "borrowed: LcCommit.coeffs aliases the caller's HBM buffer (LCPC_COMMIT_BORROW_COEFFS)" if borrow
                                 else "copied into the LcCommit (as LcCommit::commit does, lcpc-2d/src/lib.rs:636-645)"},
            "roofline": roofline}
@@ -518,6 +589,8 @@ def main():
         out["e2e_host"] = e2e
     if shard_ms is not None:
         out["shard_ms"] = shard_ms
+    if scaling_extra:
+        out.update(scaling_extra)
     if distributed:
         out["ranks_seen"] = ranks_seen
         out["check"] = check
@@ -536,23 +609,31 @@ def main():
             avail = host_memory_available()
             need = lambda l: 10 * (32 << l)            # coeffs + the oracle's coeffs copy + comm (2x) + slack
             lg = args.log_len if (avail is None or avail > need(args.log_len) + (8 << 30)) else args.log_len - 1
-        v, secs, root_cpu, cpu_coeffs = cpu_commit(O, np, lg, n_per_row, n_cols, threads)
-        # the same sample through the HIP path: the baseline doubles as a full-size parity check
-        dev_sample = torch.from_numpy(cpu_coeffs.view(np.int64)).to(dev)
-        root_gpu = LcCommit.commit_device(dev_sample.data_ptr(), 1 << lg, enc, stream, sync=True).get_root()
+        # THE timed vector, drawn again on the host by the oracle's serial generator (the first 2^lg elements of the same stream)
+        t_gen = time.perf_counter()
+        cpu_coeffs = O.random_elems(3, 1 << lg, INPUT_SEED)
+        t_gen = time.perf_counter() - t_gen
+        same = bool((torch.from_numpy(cpu_coeffs.view(np.int64)) == coeffs[:1 << lg].cpu()).all())
+        if not same:
+            raise SystemExit("bench.py: the device-drawn coefficients differ from the oracle's Field::random stream")
+        v, secs, root_cpu = cpu_commit(O, cpu_coeffs, n_per_row, n_cols, threads)
+        # the HIP root of the same data: at the full length it is the root the timed loop itself produced
+        root_gpu = LcCommit.commit_device(coeffs.data_ptr(), 1 << lg, enc, stream, sync=True, into=cm).get_root()
         if root_gpu != root_cpu:
-            raise SystemExit("bench.py: HIP root != oracle root on the CPU-baseline sample (2^%d): %s vs %s" % (lg, root_gpu.hex(), root_cpu.hex()))
-        del dev_sample, cpu_coeffs
+            raise SystemExit("bench.py: HIP root != oracle root on the timed coefficients (2^%d): %s vs %s" % (lg, root_gpu.hex(), root_cpu.hex()))
         lg1 = max(lg - 4, 17)
-        v1, secs1, _, _ = cpu_commit(O, np, lg1, n_per_row, n_cols, 1)
+        v1, secs1, _ = cpu_commit(O, cpu_coeffs[:1 << lg1], n_per_row, n_cols, 1)
+        del cpu_coeffs
         out["cpu_baseline"] = {"value": v, "unit": "field-elements/s", "cores": threads, "kind": "port",
                                "host_hw_threads": os.cpu_count(),
-                               "root_equals_hip_root": True,
+                               "root_equals_hip_root": True, "coeffs_equal_timed_coeffs": True,
+                               "root": root_cpu.hex(),
                                "one_thread": {"value": v1, "cores": 1, "sample": "2^%d coeffs (%d rows), %.1f s wall" % (lg1, (1 << lg1) // n_per_row, secs1)},
                                "sample": "oracle C port (OpenMP, one thread per usable core: affinity mask capped by the cgroup CPU "
                                          "quota), Ligero Ft255 commit of 2^%d coeffs with the headline row "
-                                         "shape (%d x %d -> %d), %.1f s wall; the same coefficients committed through the HIP "
-                                         "path give the same root" % (lg, (1 << lg) // n_per_row, n_per_row, n_cols, secs)}
+                                         "shape (%d x %d -> %d), %.1f s wall (+ %.1f s drawing them); the coefficients are the TIMED vector%s, "
+                                         "checked element for element against the device copy, and the HIP commit of it gives the same root"
+                                         % (lg, (1 << lg) // n_per_row, n_per_row, n_cols, secs, t_gen, "" if lg == args.log_len else "'s first 2^%d elements" % lg)}
     if rank == 0:
         print(json.dumps(out))
     if distributed:

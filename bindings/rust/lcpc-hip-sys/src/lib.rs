@@ -98,6 +98,7 @@ pub struct lcpc_timings {
     pub merkle_launches: u32,
     pub exchange_exposed_ms: f32,
     pub staged_slices: u32,
+    pub exchange_wire_ms: f32,
 }
 
 pub type lcpc_write_fn = Option<unsafe extern "C" fn(user: *mut c_void, data: *const u8, len: u64) -> c_int>;
@@ -126,6 +127,14 @@ extern "C" {
         n_rows: *mut u64,
         n_per_row: *mut u64,
         n_cols: *mut u64,
+    ) -> c_int;
+    pub fn lcpc_random_coeffs_device(
+        ctx: *mut lcpc_ctx,
+        seed: *const u8,
+        stream_id: u64,
+        n: u64,
+        out_dev: *mut u64,
+        stream: *mut c_void,
     ) -> c_int;
     pub fn lcpc_encode_rows(ctx: *mut lcpc_ctx, rows_host: *mut u64, n_rows: u64) -> c_int;
 
@@ -304,6 +313,8 @@ extern "C" {
     ) -> c_int;
 
     // ---- measurement hooks ----
+    pub fn lcpc_shard_exchange_probe(cm: *mut lcpc_commit_t, stream: *mut c_void, bytes_in: *mut u64) -> c_int;
+    pub fn lcpc_comm_rccl_version(version: *mut c_int) -> c_int;
     pub fn lcpc_set_timing(cm: *mut lcpc_commit_t, enable: c_int) -> c_int;
     pub fn lcpc_get_timings(cm: *mut lcpc_commit_t, out: *mut lcpc_timings) -> c_int;
 }
@@ -321,6 +332,6 @@ mod tests {
     #[test]
     fn struct_layouts() {
         assert_eq!(std::mem::size_of::<lcpc_params>(), 72);
-        assert_eq!(std::mem::size_of::<lcpc_timings>(), 36);
+        assert_eq!(std::mem::size_of::<lcpc_timings>(), 40);
     }
 }

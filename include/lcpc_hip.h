@@ -33,7 +33,7 @@ extern "C" {
 
 /* 5: the four column-range phases of ABI 3 (lcpc_commit_shard_encode_device, lcpc_commit_shard_hash_device,
  * lcpc_commit_finish_cols_device, lcpc_commit_finish_merkle_device) are gone -- slicing the exchange was measured neutral to
- * negative (profiles/r04_shard_slices.jsonl) and nothing called them; lcpc_timings.staged_slices.
+ * negative (profiles/r04_shard_slices.jsonl) and nothing called them; lcpc_timings.staged_slices / .exchange_wire_ms; lcpc_random_coeffs_device, lcpc_shard_exchange_probe, lcpc_comm_rccl_version.
  * 4: lcpc_shard_nodes_field (row sharding for Ft191, whose elements straddle BLAKE3 chunks), LCPC_COMMIT_ASYNC_TAIL.
  * 3: the column-range phases of the sharded commit (lcpc_commit_shard_encode_device, lcpc_commit_shard_hash_device,
  * lcpc_commit_finish_cols_device, lcpc_commit_finish_merkle_device), lcpc_timings.exchange_exposed_ms; the LcCommit bincode
@@ -125,6 +125,12 @@ int  lcpc_static_get_dims_ml(const lcpc_params *params, uint32_t n_vars, uint64_
 /* encode (ligero lib.rs:162-164, brakedown lib.rs:150-153), batched: `rows` holds n_rows rows of
  * n_cols elements each, first n_per_row = message, rest zero on entry; encoded in place. */
 int  lcpc_encode_rows(lcpc_ctx *ctx, uint64_t *rows_host, uint64_t n_rows);
+/* lcpc_test_fields::random_coeffs (lcpc-test-fields/src/lib.rs:75-97) with a FIXED generator, on the device: n elements of the
+ * encoder's field by ff's `Field::random` rule (L x next_u64 as limbs, top limb masked to NUM_BITS, accepted iff < p; the limbs
+ * are the Montgomery representation) drawn from ChaCha20Rng::from_seed(seed) after set_stream(stream_id) -- element for element
+ * the vector the same rule gives on a host (SURVEY.md 8d "Synthetic inputs": seed 32 x 0x00, stream 0).  out_dev: n * L u64 on
+ * the encoder's device.  Synchronises `stream` (a utility for tests and benches, not a commit-path call). */
+int  lcpc_random_coeffs_device(lcpc_ctx *ctx, const uint8_t seed[32], uint64_t stream_id, uint64_t n, uint64_t *out_dev, void *stream);
 
 /* ---- LcCommit (lcpc-2d/src/lib.rs:172-184, 270-312) ---- */
 /* An empty LcCommit bound to `enc` (no device memory yet); every commit entry point below fills it.  Filling it
@@ -309,7 +315,16 @@ typedef struct {
    * the source was pageable memory (0: the source was pinned / registered and was copied from directly).  Set with or without
    * lcpc_set_timing. */
   uint32_t staged_slices;
+  /* lcpc_commit_sharded_device only: from the end of the local column hash to the end of the exchange's collectives on the
+   * stream that carries them (the wire alone; exchange_exposed_ms - exchange_wire_ms = the leaf digests). */
+  float exchange_wire_ms;
 } lcpc_timings;
+/* the exchange of this object's last lcpc_commit_sharded_device ALONE, once more, on `stream` (the same collectives on the same
+ * buffers; the finished commitment is not touched): bench.py times 20 of them to MEASURE the wire instead of assuming it.
+ * bytes_in: what this rank receives from the others per exchange.  Enqueues only.  A collective: every rank, the same order. */
+int  lcpc_shard_exchange_probe(lcpc_commit_t *cm, void *stream, uint64_t *bytes_in);
+/* ncclGetVersion of the communicator library the native exchange uses (0: it exports none); LCPC_ERR_NO_RCCL without one */
+int  lcpc_comm_rccl_version(int *version);
 int  lcpc_set_timing(lcpc_commit_t *cm, int enable);
 int  lcpc_get_timings(lcpc_commit_t *cm, lcpc_timings *out);
 

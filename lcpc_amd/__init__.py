@@ -115,6 +115,20 @@ class _Encoding:
         self._check(_lib.lib().lcpc_encode_rows(self._h, _ptr(rows), n))
         return rows
 
+    def random_coeffs_device(self, n, seed=0, stream_id=0, out_ptr=None, stream=0):
+        """lcpc_test_fields::random_coeffs (lcpc-test-fields/src/lib.rs:75-97) with a fixed generator, on the device: n elements by
+        Field::random from ChaCha20Rng::from_seed([seed; 32]), stream `stream_id` (lcpc_random_coeffs_device) -- element for
+        element the vector the same rule gives on a host.  Returns a torch int64 tensor [n, L] on the encoder's device, or
+        fills `out_ptr` (a device address with room for n * L u64) and returns None."""
+        key = (C.c_uint8 * 32)(*([seed & 0xFF] * 32))
+        t = None
+        if out_ptr is None:
+            import torch
+            t = torch.empty((n, self.L), dtype=torch.int64, device=torch.device("cuda", self.params.device))
+            out_ptr = t.data_ptr()
+        self._check(_lib.lib().lcpc_random_coeffs_device(self._h, key, stream_id, n, C.c_void_p(out_ptr), C.c_void_p(stream)))
+        return t
+
     def __del__(self):
         try:
             _lib.lib().lcpc_ctx_destroy(self._h)      # commitments made with it keep the tables alive (refcount)

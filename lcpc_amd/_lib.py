@@ -22,7 +22,7 @@ class LcpcParams(C.Structure):
 class LcpcTimings(C.Structure):
     _fields_ = [("encode_ms", C.c_float), ("hash_ms", C.c_float), ("merkle_ms", C.c_float), ("total_ms", C.c_float),
                 ("encode_launches", C.c_uint32), ("hash_launches", C.c_uint32), ("merkle_launches", C.c_uint32),
-                ("exchange_exposed_ms", C.c_float), ("staged_slices", C.c_uint32)]
+                ("exchange_exposed_ms", C.c_float), ("staged_slices", C.c_uint32), ("exchange_wire_ms", C.c_float)]
 
 
 # every symbol include/lcpc_hip.h declares: name -> (restype, argtypes)
@@ -43,6 +43,7 @@ SYMBOLS = {
     "lcpc_field_limbs": (_u32, [_vp]),
     "lcpc_static_get_dims": (_i32, [C.POINTER(LcpcParams), _vp, _vp, _vp]),
     "lcpc_static_get_dims_ml": (_i32, [_vp, _u32, _vp, _vp, _vp]),
+    "lcpc_random_coeffs_device": (_i32, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "lcpc_encode_rows": (_i32, [_vp, _vp, _u64]),
     "lcpc_commit_create": (_i32, [_vp, C.POINTER(_vp)]),
     "lcpc_commit_destroy": (None, [_vp]),
@@ -84,6 +85,8 @@ SYMBOLS = {
     "lcpc_field_sum_device": (_i32, [_vp, _vp, _u32, _u64, _vp, _vp]),
     "lcpc_prove_sharded_bytes": (_u64, [_vp, _u64]),
     "lcpc_prove_sharded": (_i32, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, ALLGATHER_FN, _vp, _vp, _vp, _vp]),
+    "lcpc_shard_exchange_probe": (_i32, [_vp, _vp, C.POINTER(_u64)]),
+    "lcpc_comm_rccl_version": (_i32, [C.POINTER(_i32)]),
     "lcpc_set_timing": (_i32, [_vp, _i32]),
     "lcpc_get_timings": (_i32, [_vp, C.POINTER(LcpcTimings)]),
 }

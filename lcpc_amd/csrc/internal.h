@@ -171,8 +171,8 @@ struct lcpc_commit_s {
   uint64_t h_pin_cap = 0;
   // timing
   bool timing = false;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // start | encoded | hashed | done; [4] (ev_xw): the commit's stream has
-                                   // the leaf digests (sharded commit: behind the exchange)
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start | encoded | hashed | done; [4]: the commit's stream
+                                   // has the leaf digests (sharded commit: behind the exchange); [5]: the exchange's collectives are done
   hipStream_t s_prove = nullptr;   // sharded prove: its device steps and the native exchange, ordered behind the commit by ev_done
   hipEvent_t ev_done = nullptr;    // recorded on the commit's stream when a sharded commit has been enqueued completely
   // native sharded commit (shard.cpp): the exchange stream of an async tail and its hand-over event

@@ -76,6 +76,7 @@ struct Rccl {
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
   bool ok = false;
 };
 Rccl& rccl() {
@@ -113,6 +114,7 @@ Rccl& rccl() {
     x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.h, "ncclGroupStart"));
     x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.h, "ncclGroupEnd"));
     x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.h, "ncclGetErrorString"));
+    x.GetVersion = reinterpret_cast<decltype(x.GetVersion)>(dlsym(x.h, "ncclGetVersion"));      // (optional)
     x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather && x.Broadcast && x.GroupStart && x.GroupEnd;
     return x;
   }();
@@ -523,6 +525,60 @@ int lcpc_comm_destroy(lcpc_ctx* c) {
   return 0;
 }
 
+// What crosses the wire in the native exchange: node 0 of every rank (one all-gather of one slot each; slot = one chaining value
+// per column) plus the few second / third nodes some ranks own (one broadcast each: at the headline only the last rank has one),
+// instead of padding every rank to the largest node count.  Layout of d_gather, contiguous:
+// [ this rank's nodes: my_slots ][ gathered: G slots of node 0, then the extra nodes in rank order ]
+struct XchgPlan {
+  uint32_t G = 1, me = 0, my_slots = 1, extras = 0;
+  uint32_t n_nodes_of[256];
+  uint64_t slot_bytes = 0;
+  uint64_t tot_slots() const { return (uint64_t)my_slots + G + extras; }
+  uint64_t bytes_in() const { return (uint64_t)(G - 1 + extras - (my_slots - 1)) * slot_bytes; }   // what this rank RECEIVES from others
+};
+static int xchg_plan(const lcpc_ctx* c, uint64_t n_rows_total, XchgPlan* p) {
+  p->G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
+  p->me = p->G > 1 ? c->prm.shard_rank : 0;
+  if (p->G > 256) return LCPC_ERR_ARG;
+  const uint64_t nch = leaf_chunks(c, n_rows_total);
+  p->extras = 0; p->my_slots = 1;
+  for (uint32_t r = 0; r < p->G; r++) {
+    uint64_t first[64];
+    uint32_t lg[64];
+    uint64_t c0, c1;
+    shard_chunk_range(elem_bytes(c), nch, p->G, r, &c0, &c1);
+    p->n_nodes_of[r] = (uint32_t)shard_nodes(c0, c1, first, lg);
+    if (p->n_nodes_of[r] > 1) p->extras += p->n_nodes_of[r] - 1;
+    if (r == p->me && p->n_nodes_of[r] > 1) p->my_slots = p->n_nodes_of[r];
+  }
+  p->slot_bytes = c->n_cols * 32;
+  return 0;
+}
+// the collectives of one exchange, enqueued on sx (the ONE exchange step of the path)
+static int xchg_enqueue(lcpc_commit_t* m, const XchgPlan& p, hipStream_t sx) {
+  lcpc_ctx* c = m->enc;
+  uint8_t* send = m->d_gather;
+  uint8_t* recv = send + p.slot_bytes * p.my_slots;
+  // Collectives of one communicator must be submitted in the same order on every rank.  This lock only keeps the exchanges of
+  // two commitments of ONE process from interleaving; it cannot order submissions ACROSS ranks -- one encoder's sharded
+  // commits / proves must be issued in the same program order on every rank (one driving thread per communicator).
+  std::lock_guard<std::mutex> xg(c->xchg_mu);
+  HIPCHK(m, xchg_order_before(c, sx));
+  int nrc = rccl().GroupStart();
+  if (nrc == 0) nrc = rccl().AllGather(send, recv, (size_t)p.slot_bytes, NCCL_UINT8, c->comm, sx);
+  uint32_t x = p.G;
+  for (uint32_t r = 0; r < p.G && nrc == 0; r++)
+    for (uint32_t k = 1; k < p.n_nodes_of[r] && nrc == 0; k++, x++) {
+      uint8_t* dst = recv + p.slot_bytes * x;
+      nrc = rccl().Broadcast(r == p.me ? send + p.slot_bytes * k : dst, dst, (size_t)p.slot_bytes, NCCL_UINT8, (int)r, c->comm, sx);
+    }
+  const int erc = rccl().GroupEnd();
+  if (nrc == 0) nrc = erc;
+  if (nrc != 0) return fail_nccl(&m->err, nrc, "ncclAllGather / ncclBroadcast");
+  HIPCHK(m, xchg_order_after(c, sx));
+  return 0;
+}
+
 // One commit on a row shard with the exchange inside: encode and the local column hash on `stream`; the collectives (node 0 of
 // every rank by ncclAllGather, the few second / third nodes by one ncclBroadcast each, grouped), the leaf digests and the Merkle
 // tree follow
@@ -538,28 +594,12 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
   std::lock_guard<std::mutex> g(m->mu);
   HIPCHK(m, hipSetDevice(c->prm.device));
   hipStream_t st = (hipStream_t)stream;
-  const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
-  const uint32_t me = G > 1 ? c->prm.shard_rank : 0;
-  const uint64_t nch = leaf_chunks(c, n_rows_total);
-  // one slot = one chaining value per column.  What crosses the wire: node 0 of every rank (one all-gather of one slot each) plus
-  // the few second / third nodes some ranks own (one broadcast each: at the headline only the last rank has one), instead of
-  // padding every rank to the largest node count.  Contiguous: [ this rank's nodes ][ gathered: G slots of node 0, then the
-  // extra nodes in rank order ]
-  uint32_t n_nodes_of[256], extras = 0, my_slots = 1;
-  if (G > 256) return LCPC_ERR_ARG;
-  for (uint32_t r = 0; r < G; r++) {
-    uint64_t first[64];
-    uint32_t lg[64];
-    uint64_t c0, c1;
-    shard_chunk_range(elem_bytes(c), nch, G, r, &c0, &c1);
-    n_nodes_of[r] = (uint32_t)shard_nodes(c0, c1, first, lg);
-    if (n_nodes_of[r] > 1) extras += n_nodes_of[r] - 1;
-    if (r == me && n_nodes_of[r] > 1) my_slots = n_nodes_of[r];
-  }
-  const uint64_t tot_slots = (uint64_t)my_slots + G + extras;
-  // (the refill order of shard_encode_phase comes first: the buffer below may still be read by the previous fill's exchange)
-  int rc = order_after_commit(m, st);
+  XchgPlan xp;
+  int rc = xchg_plan(c, n_rows_total, &xp);
   if (rc) return rc;
+  const uint64_t tot_slots = xp.tot_slots();
+  // (the refill order of shard_encode_phase comes first: the buffer below may still be read by the previous fill's exchange)
+  if ((rc = order_after_commit(m, st))) return rc;
   if (tot_slots * c->n_cols * 32 > m->gather_cap && m->ev_done) HIPCHK(m, hipEventSynchronize(m->ev_done));
   if ((rc = ensure_dev(&m->err, &m->d_gather, &m->gather_cap, tot_slots * c->n_cols * 32))) return rc;
   const bool async_tail = (flags & LCPC_COMMIT_ASYNC_TAIL) != 0;
@@ -573,41 +613,57 @@ int lcpc_commit_sharded_device(lcpc_commit_t* m, const uint64_t* coeffs_local, u
     if (!m->ev_hashed) HIPCHK(m, hipEventCreateWithFlags(&m->ev_hashed, hipEventDisableTiming));
     sx = m->s_xchg;
   }
-  const uint64_t slot_bytes = c->n_cols * 32;
   uint8_t* send = m->d_gather;
-  uint8_t* recv = send + slot_bytes * my_slots;
+  uint8_t* recv = send + xp.slot_bytes * xp.my_slots;
   if ((rc = shard_hash_cols(m, st, send))) return rc;
   if (sx != st) {
     HIPCHK(m, hipEventRecord(m->ev_hashed, st));
     HIPCHK(m, hipStreamWaitEvent(sx, m->ev_hashed, 0));
   }
   if (m->timing) HIPCHK(m, hipEventRecord(m->ev[2], st));
-  {
-    // Collectives of one communicator must be submitted in the same order on every rank.  This lock only keeps the exchanges of
-    // two commitments of ONE process from interleaving; it cannot order submissions ACROSS ranks -- one encoder's sharded
-    // commits / proves must be issued in the same program order on every rank (one driving thread per communicator).
-    std::lock_guard<std::mutex> xg(c->xchg_mu);
-    HIPCHK(m, xchg_order_before(c, sx));
-    int nrc = rccl().GroupStart();
-    if (nrc == 0) nrc = rccl().AllGather(send, recv, (size_t)slot_bytes, NCCL_UINT8, c->comm, sx);
-    uint32_t x = G;
-    for (uint32_t r = 0; r < G && nrc == 0; r++)
-      for (uint32_t k = 1; k < n_nodes_of[r] && nrc == 0; k++, x++) {
-        uint8_t* dst = recv + slot_bytes * x;
-        nrc = rccl().Broadcast(r == me ? send + slot_bytes * k : dst, dst, (size_t)slot_bytes, NCCL_UINT8, (int)r, c->comm, sx);
-      }
-    const int erc = rccl().GroupEnd();
-    if (nrc == 0) nrc = erc;
-    if (nrc != 0) return fail_nccl(&m->err, nrc, "ncclAllGather / ncclBroadcast");
-    HIPCHK(m, xchg_order_after(c, sx));
-  }
+  if ((rc = xchg_enqueue(m, xp, sx))) return rc;
+  if (m->timing) HIPCHK(m, hipEventRecord(m->ev[5], sx));      // the wire is done
   if ((rc = shard_finish_cols(m, recv, 0, sx))) return rc;
   if (m->timing) HIPCHK(m, hipEventRecord(m->ev[4], sx));
   if ((rc = shard_merkle_phase(m, sx, root))) return rc;      // (async tail: `st` is not held up, it is free for the next commit's encode)
   unstart.armed = false;
-  if (m->timing) (void)hipEventElapsedTime(&m->last.exchange_exposed_ms, m->ev[2], m->ev[4]);
+  if (m->timing) {
+    (void)hipEventElapsedTime(&m->last.exchange_exposed_ms, m->ev[2], m->ev[4]);
+    (void)hipEventElapsedTime(&m->last.exchange_wire_ms, m->ev[2], m->ev[5]);
+  }
   return 0;
   LCPC_CATCH(m)
+}
+
+// measurement hook: the exchange of the last lcpc_commit_sharded_device of this object ALONE, once more, on `stream` -- the same
+// collectives on the same buffers (the node values this rank sent are still in place; what arrives overwrites the gathered
+// area, which the finished commit no longer reads).  Enqueues only.  A collective: every rank calls it, in the same order.
+int lcpc_shard_exchange_probe(lcpc_commit_t* m, void* stream, uint64_t* bytes_in) {
+  if (!m) return LCPC_ERR_ARG;
+  lcpc_ctx* c = m->enc;
+  if (!c->comm) return LCPC_ERR_STATE;
+  LCPC_TRY
+  std::lock_guard<std::mutex> g(m->mu);
+  if (!m->committed || !m->d_gather) return LCPC_ERR_STATE;
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  XchgPlan xp;
+  int rc = xchg_plan(c, m->n_rows, &xp);
+  if (rc) return rc;
+  if (xp.tot_slots() * xp.slot_bytes > m->gather_cap) return LCPC_ERR_STATE;
+  if (bytes_in) *bytes_in = xp.bytes_in();
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = order_after_commit(m, st))) return rc;           // behind the commit (and its async tail) that owns the buffer
+  return xchg_enqueue(m, xp, st);
+  LCPC_CATCH(m)
+}
+
+// NCCL_VERSION_CODE of the loaded communicator library (ncclGetVersion), 0 if it has none; LCPC_ERR_NO_RCCL without a library
+int lcpc_comm_rccl_version(int* version) {
+  if (!version) return LCPC_ERR_ARG;
+  if (!rccl().ok) return LCPC_ERR_NO_RCCL;
+  *version = 0;
+  if (rccl().GetVersion) (void)rccl().GetVersion(version);
+  return 0;
 }
 
 uint64_t lcpc_prove_sharded_bytes(const lcpc_ctx* c, uint64_t n_rows_total) {

@@ -179,6 +179,20 @@ class HipShardEngine:
             self.cm._refresh()
         return bytes(root) if want_root else None
 
+    def exchange_probe(self):
+        """lcpc_shard_exchange_probe: the exchange of the last commit_native alone, once more, enqueued on the current stream;
+        returns the bytes this rank receives per exchange"""
+        st = torch.cuda.current_stream().cuda_stream
+        b = C.c_uint64()
+        self.cm._check(_lib.lib().lcpc_shard_exchange_probe(self.cm._h, C.c_void_p(st), C.byref(b)))
+        return b.value
+
+    @staticmethod
+    def rccl_version():
+        """ncclGetVersion of the communicator library the native exchange loaded (0: none exported), None without a library"""
+        v = C.c_int()
+        return v.value if _lib.lib().lcpc_comm_rccl_version(C.byref(v)) == 0 else None
+
     def prove_native(self, outer_tensor, tr):
         import numpy as np
         t = np.ascontiguousarray(outer_tensor, np.uint64).reshape(-1, self.enc.L)

@@ -64,6 +64,21 @@ def test_bench_native_exchange_across_processes(tmp_path, n):
     assert "RCCL inside the library" in out["config"]["sharding"] and "LCPC_COMMIT_ASYNC_TAIL" in out["config"]["sharding"]
     assert out["check"]["sharded_root_equals_unsharded_root"] is True
     assert out["shard_ms"]["async_tail"] is True and out["min_ms_per_step"] is None and out["value"] > 0
+    # one run tells the whole scaling story: the serial figure beside the pipelined one, the wire measured on the real
+    # payload, per-rank phase times, the communicator library's version, and the async-tail roots looked at
+    assert out["serial_ms_per_step"] > 0 and out["serial_min_ms_per_step"] > 0 and out["serial_value"] > 0
+    assert out["serial_min_ms_per_step"] <= out["serial_ms_per_step"] * 1.001
+    pr = out["exchange_probe"]
+    n_cols = out["config"]["n_cols"]
+    assert pr["reps"] == 20 and pr["ms"] > 0 and pr["GBps_in"] > 0
+    assert pr["bytes_in"] % (n_cols * 32) == 0 and n_cols * 32 * (n - 1) <= pr["bytes_in"] <= n_cols * 32 * (n + 1)
+    per = out["per_rank_ms"]
+    for k in ("encode", "hash", "exchange_exposed", "finish_tree"):
+        lo, hi = per[k]
+        assert 0 <= lo <= hi
+    assert per["encode"][1] > 0
+    assert "rccl_version" in out and "async_tail_roots_checked" in out
+    assert "ChaCha20Rng" in out["config"]["input"]
 
 
 @pytest.mark.gpu
@@ -95,6 +110,12 @@ def test_bench_n1_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample", "root_equals_hip_root"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == out["unit"] and cb["root_equals_hip_root"] is True
+    # the inputs are SURVEY 8(d)'s (named in config.input) and the baseline leg committed the timed vector itself
+    assert "ChaCha20Rng::from_seed([0; 32])" in cfg["input"] and cb["coeffs_equal_timed_coeffs"] is True
+    # the host-pointer entry from pinned AND from pageable memory, same root as the device-resident commit
+    e2e = out["e2e_host"]
+    assert e2e["root_matches_device_commit"] is True and e2e["staged_slices"] == 0
+    assert e2e["pageable"]["root_matches_device_commit"] is True and e2e["pageable"]["staged_slices"] > 0 and e2e["pageable"]["vs_pinned"] > 0
 
 
 @pytest.mark.gpu

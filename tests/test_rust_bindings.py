@@ -99,7 +99,7 @@ def rust_functions():
 
 def test_extern_block_equals_header():
     c, r = header_functions(), rust_functions()
-    assert len(c) == 55, sorted(c)
+    assert len(c) == 58, sorted(c)
     assert sorted(c) == sorted(r), "symbols differ: only in header %s, only in lib.rs %s" % (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
     for name in sorted(c):
         ca, cr = c[name]
