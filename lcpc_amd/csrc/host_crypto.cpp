@@ -49,7 +49,7 @@ static void keccak_f1600_scalar(uint64_t a[25]) {
 // Keccak-f[1600] on AVX-512VL: one 64-bit lane per XMM register (32 registers: the 25 lanes, 5 column parities and two
 // temporaries fit without spilling, which the 16 general-purpose registers of the scalar form cannot offer), 3-input
 // logic (vpternlogq: theta's XOR3, chi's a ^ (~b & c) in one instruction) and native rotates (vprolq).  105-110 instructions
-// per round, no shuffles: pi is bookkeeping done by the generator (tools/gen_keccak_x25.py -> keccak_x25_gen.h), which also
+// per round, no shuffles: pi is bookkeeping done by the generator (gen/gen_keccak_x25.py -> keccak_x25_gen.h, made by the Makefile), which also
 // allocates the registers and emits the whole permutation as one asm statement (left to the compiler, the intrinsic
 // form is spilled 4-9 times per round).  The serial STROBE absorb of prove / verify (lcpc-2d/src/lib.rs:1045-1047) runs
 // at the speed of this permutation; timings in DESIGN.md section 6a.

@@ -44,7 +44,7 @@ def test_product_never_imports_oracle():
     needs nor dlopen()s it."""
     import ast
     import subprocess
-    allowed_mods = {"ctypes", "os", "subprocess", "numpy", "torch", "lcpc_amd", ""}
+    allowed_mods = {"ctypes", "os", "sys", "subprocess", "numpy", "torch", "lcpc_amd", ""}     # (sys: the build-time generators under csrc/gen)
     for top in ("lcpc_amd", "include"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
             for f in files:
@@ -234,3 +234,19 @@ def test_shard_node_layout_matches_python():
                     lg = (C.c_uint32 * 64)()
                     assert L.lcpc_shard_nodes_field(field, n_chunks, world, rank, C.byref(n), first, lg) == 0
                     assert [(first[i], lg[i]) for i in range(n.value)] == aligned_nodes(b, e)
+
+
+def test_generated_sources_are_deterministic_and_current():
+    """keccak_x25_gen.h, field_r29_gen.h and field_ln_gen.h are build products of lcpc_amd/csrc/Makefile (git-ignored, 13 000 lines):
+    each generator is a pure function of its own text -- two runs give the same bytes -- and the header the library was built
+    from is what the generator prints now (a stale header would mean the .so does not match the tree)."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "lcpc_amd", "csrc")
+    tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "lcpc_amd/csrc"], capture_output=True, text=True).stdout
+    for gen, hdr in (("gen_keccak_x25.py", "keccak_x25_gen.h"), ("gen_r29_asm.py", "field_r29_gen.h"), ("gen_ln_asm.py", "field_ln_gen.h")):
+        a = subprocess.run([sys.executable, os.path.join(csrc, "gen", gen)], capture_output=True, check=True).stdout
+        b = subprocess.run([sys.executable, os.path.join(csrc, "gen", gen)], capture_output=True, check=True, env=dict(os.environ, PYTHONHASHSEED="12345")).stdout
+        assert a == b and len(a) > 1000, gen
+        assert open(os.path.join(csrc, hdr), "rb").read() == a, "%s is stale: rebuild (make -C lcpc_amd/csrc)" % hdr
+        assert hdr not in tracked, "%s must not be tracked" % hdr

@@ -6,7 +6,7 @@
 #define LCPC_AVX512VL __attribute__((target("avx512f,avx512vl")))
 #include "keccak_x25_gen.h"
 #include "host_crypto.h"
-#ifdef KECCAK_VARIANTS          // python tools/gen_keccak_x25.py --variants > /tmp/keccak_variants_gen.h; g++ -DKECCAK_VARIANTS -I/tmp ...
+#ifdef KECCAK_VARIANTS          // python lcpc_amd/csrc/gen/gen_keccak_x25.py --variants > /tmp/keccak_variants_gen.h; g++ -DKECCAK_VARIANTS -I/tmp ...
 #include "keccak_variants_gen.h"
 #endif
 LCPC_AVX512VL void keccak_x25(uint64_t a[25]) {
