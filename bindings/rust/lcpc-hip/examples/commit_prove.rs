@@ -34,13 +34,13 @@ fn main() {
     let mut tr = HipTranscript::new(b"example");
     tr.append_message(b"polycommit", root.as_ref());
     let t0 = Instant::now();
-    let proof: LcEvalProof<Blake3, HipLigeroEncoding<Ft255>> = comm.prove(&outer, &mut tr).expect("prove");
+    let proof: LcEvalProof<Blake3, HipLigeroEncoding<Ft255>> = comm.prove(&outer, &enc, &mut tr).expect("prove");
     println!("prove: {:?}, {} bytes", t0.elapsed(), bincode::serialize(&proof).unwrap().len());
 
     // the reference's own verify, generic over LcEncoding: merlin's transcript on this side
     let mut vtr = merlin::Transcript::new(b"example");
     vtr.append_message(b"polycommit", root.as_ref());
-    let eval = proof.verify(&root, &outer, &inner, &enc, &mut vtr).expect("verify");
+    let eval = proof.verify(root.as_ref(), &outer, &inner, &enc, &mut vtr).expect("verify");
     let direct = coeffs.iter().rev().fold(Ft255::zero(), |acc, c| acc * x + c); // Horner
     assert_eq!(eval, direct);
     println!("verified: p(x) = {:?}", eval);

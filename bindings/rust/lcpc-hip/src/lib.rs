@@ -28,7 +28,7 @@ pub use lcpc_hip_sys as sys;
 use blake3::Hasher as Blake3;
 use digest::Output;
 use ff::PrimeField;
-use lcpc_2d::{def_labels, FieldHash, LcEncoding, LcEvalProof, ProverError, SizedField, VerifierError};
+use lcpc_2d::{def_labels, FieldHash, LcEncoding, LcEvalProof, LcRoot, ProverError, SizedField, VerifierError};
 use lcpc_brakedown_pc::codespec::{SdigCode1, SdigCode2, SdigCode3, SdigCode4, SdigCode5, SdigCode6, SdigSpecification};
 use serde::{Deserialize, Serialize};
 use std::ffi::CStr;
@@ -649,12 +649,32 @@ where
         }
     }
 
-    /// `comm.get_root()` (lcpc-2d lib.rs:276-281) as the raw `Output<D>` that `verify` takes
-    pub fn get_root(&self) -> Output<Blake3> {
+    /// `comm.get_root()` (lcpc-2d lib.rs:276-281): the reference's own `LcRoot`, whose fields are private -- built through its
+    /// bincode form (lib.rs:373-398: an 8-byte length and the 32 digest bytes, `lcpc_root_bincode`).  `root.as_ref()` is the
+    /// `&Output<D>` that `verify` takes, `root.into_raw()` the digest, exactly as with the reference's commitment.
+    pub fn get_root(&self) -> LcRoot<Blake3, E> {
+        let raw = self.get_root_raw();
+        let mut wire = [0u8; 40];
+        unsafe { sys::lcpc_root_bincode(raw.as_ptr(), wire.as_mut_ptr()) };
+        bincode::deserialize(&wire).expect("lcpc_root_bincode writes the bincode layout of LcRoot")
+    }
+
+    /// the Merkle root as the raw digest (what `get_root().into_raw()` gives, without the detour)
+    pub fn get_root_raw(&self) -> Output<Blake3> {
         let mut r = [0u8; 32];
         let rc = unsafe { sys::lcpc_get_root(self.cm, r.as_mut_ptr()) };
         assert_eq!(rc, 0, "get_root on an empty commitment");
         Output::<Blake3>::clone_from_slice(&r)
+    }
+
+    /// `check_comm` (lcpc-2d lib.rs:673-688): the commitment's fields and `enc` belong together -- here: `enc` is (a clone of)
+    /// the encoder the device buffers were filled under
+    fn check_comm(&self, enc: &E) -> Result<(), ProverError<HipError>> {
+        if enc.raw_ctx() == self.enc.raw_ctx() {
+            Ok(())
+        } else {
+            Err(ProverError::Commit)
+        }
     }
 
     fn dims(&self) -> (usize, usize, usize) {
@@ -676,16 +696,19 @@ where
         self.dims().2
     }
 
-    /// `comm.prove(&outer_tensor, &enc, &mut tr)` (lcpc-2d lib.rs:304-311 -> 1004-1093): the proof is the reference's own
-    /// type, obtained through its bincode form (lib.rs:597-609)
-    pub fn prove(&self, outer_tensor: &[E::F], tr: &mut HipTranscript) -> Result<LcEvalProof<Blake3, E>, ProverError<HipError>> {
+    /// `comm.prove(&outer_tensor, &enc, &mut tr)` (lcpc-2d lib.rs:304-311 -> 1004-1093), argument for argument: the proof is the
+    /// reference's own type, obtained through its bincode form (lib.rs:597-609).  `enc` must be the encoder the commitment was
+    /// made with -- the reference's `check_comm(comm, enc)` (lib.rs:1015) -- else `ProverError::Commit`.
+    pub fn prove(&self, outer_tensor: &[E::F], enc: &E, tr: &mut HipTranscript) -> Result<LcEvalProof<Blake3, E>, ProverError<HipError>> {
+        self.check_comm(enc)?;
         let bytes = self.prove_bytes(outer_tensor, tr, false)?;
         Ok(bincode::deserialize(&bytes).expect("lcpc_prove returns the bincode layout of LcEvalProof"))
     }
 
     /// the same on a row-sharded commitment, the three all-gathers on RCCL (`lcpc_prove_sharded_rccl`); every rank returns the
     /// unsharded proof byte for byte
-    pub fn prove_sharded(&self, outer_tensor: &[E::F], tr: &mut HipTranscript) -> Result<LcEvalProof<Blake3, E>, ProverError<HipError>> {
+    pub fn prove_sharded(&self, outer_tensor: &[E::F], enc: &E, tr: &mut HipTranscript) -> Result<LcEvalProof<Blake3, E>, ProverError<HipError>> {
+        self.check_comm(enc)?;
         let bytes = self.prove_bytes(outer_tensor, tr, true)?;
         Ok(bincode::deserialize(&bytes).expect("lcpc_prove_sharded_rccl returns the bincode layout of LcEvalProof"))
     }
@@ -722,8 +745,16 @@ where
     /// (lcpc-2d lib.rs:186-268), streamed to `w` in pieces of at most 64 MiB
     pub fn serialize_into<W: std::io::Write>(&self, w: &mut W) -> Result<(), HipError> {
         unsafe extern "C" fn sink<W: std::io::Write>(user: *mut c_void, data: *const u8, len: u64) -> c_int {
-            let w = &mut *(user as *mut W);
-            w.write_all(std::slice::from_raw_parts(data, len as usize)).is_err() as c_int
+            // a panic in `W::write_all` must not unwind through the C++ frames of the library (undefined behaviour): it becomes
+            // the callback's failure code, and the library returns LCPC_ERR_ARG to `serialize_into`
+            let r = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| {
+                let w = &mut *(user as *mut W);
+                w.write_all(std::slice::from_raw_parts(data, len as usize)).is_err()
+            }));
+            match r {
+                Ok(failed) => failed as c_int,
+                Err(_) => 1,
+            }
         }
         match unsafe { sys::lcpc_commit_bincode_write(self.cm, Some(sink::<W>), w as *mut W as *mut c_void) } {
             0 => Ok(()),
@@ -735,8 +766,15 @@ where
     /// rebuilt from `comm` on the device and must agree with the stream's `hashes`
     pub fn deserialize_from<R: std::io::Read>(enc: &'a E, r: &mut R) -> Result<Self, ProverError<HipError>> {
         unsafe extern "C" fn source<R: std::io::Read>(user: *mut c_void, data: *mut u8, len: u64) -> c_int {
-            let r = &mut *(user as *mut R);
-            r.read_exact(std::slice::from_raw_parts_mut(data, len as usize)).is_err() as c_int
+            // (no unwinding across the C frames: see `serialize_into`)
+            let res = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| {
+                let r = &mut *(user as *mut R);
+                r.read_exact(std::slice::from_raw_parts_mut(data, len as usize)).is_err()
+            }));
+            match res {
+                Ok(failed) => failed as c_int,
+                Err(_) => 1,
+            }
         }
         let me = Self::empty(enc).map_err(ProverError::Encode)?;
         match unsafe { sys::lcpc_commit_from_bincode(me.cm, Some(source::<R>), r as *mut R as *mut c_void, std::ptr::null_mut()) } {
@@ -817,8 +855,9 @@ mod tests {
 
         let comm = HipCommit::commit(&coeffs, &enc).unwrap();
         let ref_comm = LigeroCommit::<Blake3, Ft255>::commit(&coeffs, &ref_enc).unwrap();
-        let root = comm.get_root();
-        assert_eq!(&root, ref_comm.get_root().as_ref());
+        let root = comm.get_root(); // an LcRoot<Blake3, _>, as the reference's
+        assert_eq!(root.as_ref(), ref_comm.get_root().as_ref());
+        assert_eq!(bincode::serialize(&root).unwrap(), bincode::serialize(&ref_comm.get_root()).unwrap());
 
         let x = Ft255::random(&mut rng);
         let (nr, np, _) = enc.get_dims(len);
@@ -838,10 +877,18 @@ mod tests {
         let pf: lcpc_ligero_pc::LigeroEvalProof<Blake3, Ft255> = bincode::deserialize(&pf_bytes).unwrap();
         let mut vtr = Transcript::new(b"test transcript");
         vtr.append_message(b"polycommit", root.as_ref());
-        let ev = pf.verify(&root, &outer, &inner, &ref_enc, &mut vtr).unwrap();
+        let ev = pf.verify(root.as_ref(), &outer, &inner, &ref_enc, &mut vtr).unwrap();
         // ... and the library's verifier: same evaluation
         let mut htr = HipTranscript::new(b"test transcript");
         htr.append_message(b"polycommit", root.as_ref());
-        assert_eq!(ev, verify_on_device(&pf_bytes, &root, &outer, &inner, &enc, &mut htr).unwrap());
+        assert_eq!(ev, verify_on_device(&pf_bytes, root.as_ref(), &outer, &inner, &enc, &mut htr).unwrap());
+        // and the typed form, argument for argument the reference's call: the same proof
+        let mut tr2 = HipTranscript::new(b"test transcript");
+        tr2.append_message(b"polycommit", root.as_ref());
+        let pf2 = comm.prove(&outer, &enc, &mut tr2).unwrap();
+        assert_eq!(bincode::serialize(&pf2).unwrap(), pf_bytes);
+        // check_comm: another encoder than the commitment's is refused as the reference refuses inconsistent fields
+        let other = HipLigeroEncoding::<Ft255>::new(len);
+        assert!(matches!(comm.prove(&outer, &other, &mut tr2), Err(ProverError::Commit)));
     }
 }

@@ -245,3 +245,107 @@ def test_rust_sources_are_lexically_balanced():
     ws = open(os.path.join(base, "Cargo.toml")).read()
     assert '"lcpc-hip-sys"' in ws and '"lcpc-hip"' in ws
     assert 'path = "../lcpc-hip-sys"' in open(os.path.join(base, "lcpc-hip", "Cargo.toml")).read()
+
+
+# ---- the wrapper crate against the reference's own signatures -------------------------------------------------------------------
+# Which reference item each public function of lcpc-hip stands in for, and how the reference's type names read on this side
+# (the only differences a caller sees: the digest is fixed to BLAKE3, the transcript is the library's -- merlin's STROBE state is
+# private and cannot be handed across -- and the encoder's error type is HipError).
+MIRRORS = {
+    # reference item                       (impl block in lcpc-hip/src/lib.rs, fn name)
+    "LcCommit::commit": ("HipCommit", "commit"),
+    "LcCommit::prove": ("HipCommit", "prove"),
+    "LcCommit::get_root": ("HipCommit", "get_root"),
+    "LcCommit::get_n_rows": ("HipCommit", "get_n_rows"),
+    "LcCommit::get_n_per_row": ("HipCommit", "get_n_per_row"),
+    "LcCommit::get_n_cols": ("HipCommit", "get_n_cols"),
+    "LcEvalProof::verify": (None, "verify_on_device"),           # free function: `self` becomes the proof's bincode bytes
+    "LigeroEncodingRho::new": ("HipLigeroEncodingRho", "new"),
+    "LigeroEncodingRho::new_ml": ("HipLigeroEncodingRho", "new_ml"),
+    "LigeroEncodingRho::new_from_dims": ("HipLigeroEncodingRho", "new_from_dims"),
+    "SdigEncodingS::new": ("HipSdigEncodingS", "new"),
+    "SdigEncodingS::new_ml": ("HipSdigEncodingS", "new_ml"),
+    "SdigEncodingS::new_from_dims": ("HipSdigEncodingS", "new_from_dims"),
+}
+TYPE_MAP = [(r"\bFldT<E>", "E::F"), (r"\bErrT<E>", "HipError"), (r"\bTranscript\b", "HipTranscript"), (r"\bD\b", "Blake3"),
+            (r"\bProverResult<(.*), HipError>$", r"Result<\1, ProverError<HipError>>"),
+            (r"\bVerifierResult<(.*), HipError>$", r"Result<\1, VerifierError<HipError>>")]
+
+
+def norm_type(t, ours=False):
+    t = " ".join(t.split())
+    if ours:
+        t = re.sub(r"&'a ", "&", t)                  # HipCommit<'a, E> borrows its encoder for its lifetime
+    else:
+        for pat, rep in TYPE_MAP:
+            t = re.sub(pat, rep, t)
+    return t.replace(" ", "")
+
+
+def crate_functions():
+    """(impl type or None, fn name) -> {"args": [[name, type]], "ret": type} for every `pub fn` of lcpc-hip/src/lib.rs"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_reference_api", os.path.join(ROOT, "tests", "golden", "make_reference_api.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    src = strip_rs(open(HI).read())
+    src = src.split("#[cfg(test)]")[0]
+    out = {}
+    spans = []
+    for m in re.finditer(r"impl(?:<[^{]*?>)?\s+(\w+)(?:<[^{]*?>)?\s*(?:where[^{]*)?\{", src):
+        if " for " in m.group(0):
+            continue
+        (start, body), = M.block_of(src[m.start():], r"impl(?:<[^{]*?>)?\s+%s\b[^{;]*?\{" % m.group(1))[:1]
+        spans.append((m.start(), m.start() + len(body)))
+        for f in re.finditer(r"pub\s+(?:unsafe\s+)?fn\s+(\w+)\s*(<[^(]*?>)?\s*\((.*?)\)\s*(?:->\s*([^{;]+?))?\s*(?:where[^{;]*)?\{", body, flags=re.S):
+            a = []
+            for x in M.split_args(f.group(3)):
+                a.append(["self", x] if x in ("&self", "self", "&mut self") else [x.split(":", 1)[0].strip(), " ".join(x.split(":", 1)[1].split())])
+            out.setdefault((m.group(1), f.group(1)), {"args": a, "ret": " ".join(f.group(4).split()) if f.group(4) else None})
+    for f in re.finditer(r"\npub\s+fn\s+(\w+)\s*(<[^(]*?>)?\s*\((.*?)\)\s*(?:->\s*([^{;]+?))?\s*(?:where[^{;]*)?\{", src, flags=re.S):
+        a = [[x.split(":", 1)[0].strip(), " ".join(x.split(":", 1)[1].split())] for x in M.split_args(f.group(3))]
+        out[(None, f.group(1))] = {"args": a, "ret": " ".join(f.group(4).split()) if f.group(4) else None}
+    return out, M
+
+
+def test_wrapper_signatures_equal_reference():
+    """every public function of lcpc-hip that stands in for a reference item takes the reference's arguments -- same names, same
+    order, same types after the three documented substitutions -- and returns the reference's type (lcpc-2d/src/lib.rs:270-312,
+    518-527; lcpc-ligero-pc/src/lib.rs:121-148; lcpc-brakedown-pc/src/lib.rs:103-137).  The reference side is the committed
+    table tests/golden/reference_api.json (made by tests/golden/make_reference_api.py); where /root/reference is present the
+    table itself is re-derived and must be current."""
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_api.json")))
+    ours, M = crate_functions()
+    if os.path.isdir(M.REF):
+        assert M.build() == ref, "tests/golden/reference_api.json is stale: python tests/golden/make_reference_api.py"
+    for item, key in MIRRORS.items():
+        assert key in ours, "lcpc-hip has no %s::%s" % key
+        r, o = ref[item], ours[key]
+        ra = [a for a in r["args"]]
+        oa = [a for a in o["args"]]
+        if item == "LcEvalProof::verify":
+            assert oa[0] == ["proof_bytes", "&[u8]"]               # `&self` of the proof
+            ra, oa = ra[1:], oa[1:]
+        assert [a[0] for a in ra] == [a[0] for a in oa], "%s: argument names %s vs %s" % (item, [a[0] for a in ra], [a[0] for a in oa])
+        for (n, rt), (_, ot) in zip(ra, oa):
+            assert norm_type(rt) == norm_type(ot, True), "%s, argument %s: reference %s, crate %s" % (item, n, rt, ot)
+        assert norm_type(r["ret"]) == norm_type(o["ret"], True), "%s returns %s, the crate's %s" % (item, r["ret"], o["ret"])
+    # the trait the encoders implement: method names and arities of LcEncoding (the trait's own signatures are the compiler's to check)
+    src = strip_rs(open(HI).read())
+    for enc in ("HipLigeroEncodingRho", "HipSdigEncodingS"):
+        blk = re.search(r"impl<[^{]*?>\s+LcEncoding\s+for\s+%s\b.*?\n\}" % enc, src, flags=re.S).group(0)
+        for name in ("encode", "get_dims", "dims_ok", "get_n_col_opens", "get_n_degree_tests"):
+            m = re.search(r"fn\s+%s\s*(?:<[^(]*?>)?\s*\((.*?)\)" % name, blk, flags=re.S)
+            assert m, "%s: LcEncoding::%s missing" % (enc, name)
+            assert len(M.split_args(m.group(1))) == len(ref["LcEncoding::" + name]["args"]), (enc, name)
+
+
+def test_ci_script_and_readme_state_the_pin():
+    """bindings/rust/ci.sh holds the three commands whose first green run pins the oracle to the real crates; the README says so
+    and says that the crates have never been compiled here"""
+    sh = open(os.path.join(ROOT, "bindings", "rust", "ci.sh")).read()
+    for needle in ("cargo test -p lcpc-hip", "--example commit_prove", "oracle/repin", "compare.py"):
+        assert needle in sh, needle
+    rd = open(os.path.join(ROOT, "bindings", "rust", "README.md")).read().lower()
+    assert "never been compiled" in rd and "ci.sh" in rd and "partial" in rd
