@@ -6,6 +6,7 @@ Per case: G threads, each with its own sharded encoder (rank r of G), ONE commun
  1. lcpc_commit_sharded_device in sequence on the rank's stream -> every rank's root and whole `hashes` == the oracle's;
  2. the same with LCPC_COMMIT_ASYNC_TAIL on two commitments per rank, filled alternately with two polynomials and no host
     synchronisation, then a refill of each -> roots / hashes of the LAST polynomial committed into each;
+ 2b. lcpc_shard_exchange_probe (bench.py's wire probe) between commits: the commitment and the next commit are unaffected;
  3. lcpc_prove_sharded_rccl on every rank -> the oracle prover's bytes, identical on every rank;
 for Ligero and Brakedown, the four fields (Ft191's shards cut at rows = 84 mod 128), node layouts with one, two and three nodes
 per rank and ranks that own nothing.
@@ -98,6 +99,14 @@ def run_case(kind, fid, n_rows, n_per_row, n_cols, G):
             st.synchronize()
             a.cm._refresh(); b.cm._refresh()
             assert (a.cm.hashes() == ocs[1].hashes()).all() and (b.cm.hashes() == ocs[0].hashes()).all(), "rank %d: async hashes" % g
+            # 2b. the measurement hook: the exchange of a's last commit alone, twice more (collective: every rank, same order).  What
+            #     arrives lands in the gathered area only: the finished commitment is untouched, and so is the next commit
+            n_in = a.exchange_probe()
+            assert n_in == a.exchange_probe()
+            torch.cuda.current_stream().synchronize()
+            assert n_in % (n_cols * 32) == 0 and (G - 1) * n_cols * 32 <= n_in + n_cols * 32 * 2, "rank %d: probe bytes %d" % (g, n_in)
+            assert (a.cm.hashes() == ocs[1].hashes()).all(), "rank %d: hashes after the probe" % g
+            assert a.commit_native(loc[1], n_rows, want_root=True) == ocs[1].get_root(), "rank %d: commit after the probe" % g
             # 3. sharded prove on both commitments (three all-gathers each; same order on every rank)
             for eng, k in ((a, 1), (b, 0)):
                 data, _ = eng.prove_native(outer, mk_transcript(Transcript, ocs[k].get_root(), n_open))

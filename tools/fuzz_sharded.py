@@ -2,9 +2,7 @@
 """tools/fuzz_sharded.py [n_cases] -- random row-sharded commits (G shard contexts on one GPU, emulated all-gather, as in
 tests/test_gpu_sharded.py): encoding (Ligero; every fifth case Brakedown, whose shards fall on both sides of the row-major /
 position-major threshold), field, shape, row count and shard count drawn at random; every rank's root and full hashes array
-must equal the unsharded oracle commitment.  Every other case runs the four-step form of the commit (encode | per column
-slice: hash, gather, leaf digests | tree) with 1 .. 5 random, unaligned slices in random order.  One-off soak, not part of the
-test suite."""
+must equal the unsharded oracle commitment.  One-off soak, not part of the test suite."""
 import os
 import random
 import sys
@@ -28,13 +26,6 @@ for case in range(n_cases):
     n_per_row = rnd.randrange(1, n_cols)
     n_rows = rnd.randrange(1, max(2, min(700, (1 << 21) // n_cols)))
     G = rnd.choice([2, 3, 4, 5, 8])
-    def rand_slices(nc):
-        if case % 2 == 0:
-            return None
-        cuts = sorted(set([0, nc] + [rnd.randrange(0, nc + 1) for _ in range(rnd.randrange(0, 5))]))
-        sl = list(zip(cuts[:-1], cuts[1:]))
-        rnd.shuffle(sl)
-        return sl
     if case % 5 == 4:
         n_per_row = rnd.randrange(200, 3000)
         n_rows = rnd.randrange(1, 260)
@@ -43,7 +34,7 @@ for case in range(n_cases):
         _, _, n_cols = oenc.get_dims(n_per_row)
         coeffs = O.random_elems(fid, n_rows * n_per_row, rnd.randrange(1 << 30))
         dev = torch.from_numpy(coeffs.view(np.int64)).cuda().reshape(n_rows, n_per_row, L)
-        roots, engines = T.run_sharded(lambda sh: SdigEncoding(fid, None, seed, code, 0, sh, _dims=(n_per_row, n_cols)), G, dev, n_rows, rand_slices(n_cols))
+        roots, engines = T.run_sharded(lambda sh: SdigEncoding(fid, None, seed, code, 0, sh, _dims=(n_per_row, n_cols)), G, dev, n_rows)
         oc = O.Commit.commit(coeffs, oenc, n_threads=4)
         assert all(r == oc.get_root() for r in roots), (case, "sdig", fid, n_rows, n_per_row, G, seed, code)
         for eng in engines:
@@ -51,7 +42,7 @@ for case in range(n_cases):
         continue
     coeffs = O.random_elems(fid, n_rows * n_per_row, rnd.randrange(1 << 30))
     dev = torch.from_numpy(coeffs.view(np.int64)).cuda().reshape(n_rows, n_per_row, L)
-    roots, engines = T.run_sharded(lambda sh: LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=sh), G, dev, n_rows, rand_slices(n_cols))
+    roots, engines = T.run_sharded(lambda sh: LigeroEncoding.new_from_dims(fid, n_per_row, n_cols, shard=sh), G, dev, n_rows)
     oc = O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=4)
     assert all(r == oc.get_root() for r in roots), (case, fid, n_rows, n_per_row, n_cols, G)
     for eng in engines:
