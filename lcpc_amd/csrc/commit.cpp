@@ -401,10 +401,18 @@ int lcpc_commit_device(lcpc_commit_t* m, const uint64_t* coeffs_dev, uint64_t n_
 // upload_host does the staging itself: slices of the source are copied into a ring of pinned bounce buffers by the host pool
 // (streaming stores: the DMA engine is the only reader) while the previous slices cross the bus; every H2D is a true async copy.
 // The caller's memory is never registered (hipHostRegister would pin pages we do not own, and costs more than the copy).
+// true: the runtime knows this memory and copies from it without staging -- hipHostMalloc'ed or registered by its owner, managed,
+// or (a caller's mistake the runtime still handles, which the host pool's memcpy would not) device memory
 static bool host_ptr_is_pinned(const void* p) {
   hipPointerAttribute_t a{};
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // unknown to the runtime = pageable
-  return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeManaged;                           // hipHostMalloc'ed or registered by its owner
+  return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeDevice;
+}
+
+static bool host_ptr_is_device(const void* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice;
 }
 
 static void stream_copy(uint8_t* dst, const uint8_t* src, size_t n) {
@@ -482,7 +490,8 @@ int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uin
   const uint64_t padded = n_rows * c->n_per_row;
   const size_t total_bytes = (size_t)n_coeffs * eb;
   // pageable source (a Rust Vec, malloc, numpy): staged through pinned bounce buffers by the host pool; small ones are not worth the ring
-  const bool pinned = c->sw_host_stage == 0 || (c->sw_host_stage < 0 && (total_bytes < ((size_t)4 << 20) || host_ptr_is_pinned(coeffs)));
+  const bool pinned = c->sw_host_stage == 0 || (c->sw_host_stage < 0 && (total_bytes < ((size_t)4 << 20) || host_ptr_is_pinned(coeffs))) ||
+                      (c->sw_host_stage > 0 && host_ptr_is_device(coeffs));
   // Small inputs, Brakedown (whole-matrix transposes) and timing runs: one copy, then the resident path.
   if (c->prm.encoding != LCPC_ENC_LIGERO || total_bytes < ((size_t)64 << 20) || n_rows < 16 || m->timing) {
     {

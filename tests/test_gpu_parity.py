@@ -434,6 +434,31 @@ def test_commit_host_pipelined_vs_oracle(oracle, source, stage):
     assert (c.timings().staged_slices > 0) == expect_staged
 
 
+def test_commit_host_entry_given_device_memory(oracle):
+    """a caller's mistake the library must survive: lcpc_commit (the HOST-pointer entry) handed a device address.  The runtime
+    copies device-to-device under the host-to-device label; the library must not send such a pointer through its bounce ring
+    (the host pool's memcpy would fault on it), with or without LCPC_HOST_STAGE=1."""
+    import ctypes as C
+    import os
+    import torch
+    O = oracle
+    n = (1 << 21) + 3                                   # 64 MiB + : the batched path
+    coeffs = O.random_elems(3, n, 57)
+    dev = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    want = O.Commit.commit(coeffs, O.Encoding.ligero(3, n), n_threads=8).get_root()
+    for stage in (None, "1"):
+        if stage:
+            os.environ["LCPC_HOST_STAGE"] = stage
+        try:
+            enc = LigeroEncoding.new(3, n)
+        finally:
+            os.environ.pop("LCPC_HOST_STAGE", None)
+        c = LcCommit(enc)
+        root = (C.c_uint8 * 32)()
+        c._check(lcpc_amd._lib.lib().lcpc_commit(c._h, C.c_void_p(dev.data_ptr()), n, root))
+        assert bytes(root) == want and c.timings().staged_slices == 0
+
+
 @pytest.mark.parametrize("kind,fid,n", [("sdig", 3, (1 << 19) + 77), ("ligero", 0, (1 << 21) - 3), ("ligero", 3, (1 << 18) + 1)])
 def test_commit_host_single_upload_staged(oracle, kind, fid, n):
     """the one-copy form of lcpc_commit (Brakedown, commitments below 64 MiB or 16 rows) from pageable memory of >= 4 MiB also goes
