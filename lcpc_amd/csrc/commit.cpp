@@ -396,11 +396,13 @@ int lcpc_commit_device(lcpc_commit_t* m, const uint64_t* coeffs_dev, uint64_t n_
 
 // ---- host memory -> HBM ---------------------------------------------------------------------------------------------
 // LcCommit::commit(&coeffs, &enc) (lcpc-2d/src/lib.rs:299-301, 636-645) takes a slice of ordinary -- pageable -- memory.
-// hipMemcpyAsync from such a pointer is neither asynchronous nor fast: the runtime stages it through its own pinned buffer on
-// the calling thread (one core's memcpy rate, the call returns when the data has left), so the row-batch overlap below is lost.
-// upload_host does the staging itself: slices of the source are copied into a ring of pinned bounce buffers by the host pool
-// (streaming stores: the DMA engine is the only reader) while the previous slices cross the bus; every H2D is a true async copy.
-// The caller's memory is never registered (hipHostRegister would pin pages we do not own, and costs more than the copy).
+// What hipMemcpyAsync does with such a pointer is the runtime's business: ROCm 7 on the MI355X boxes locks the caller's pages in
+// place and stays asynchronous (measured, profiles/r05_host_path.jsonl: 40.6 ms for the 2 GiB headline on pages it has locked
+// before, 44.4 ms on a buffer it has never seen, 40.7 from pinned memory); older stacks stage through one pinned buffer on the
+// calling thread and lose the row-batch overlap below.  upload_host does not depend on either: slices of the source are copied
+// into the encoder's own ring of pinned bounce buffers by the host pool (streaming stores: the DMA engine is the only reader)
+// while the previous slices cross the bus, and every H2D is a true async copy from memory the library owns -- 41.2 ms whatever
+// the pages' history.  The caller's memory is never registered or locked by this library.
 // true: the runtime knows this memory and copies from it without staging -- hipHostMalloc'ed or registered by its owner, managed,
 // or (a caller's mistake the runtime still handles, which the host pool's memcpy would not) device memory
 static bool host_ptr_is_pinned(const void* p) {

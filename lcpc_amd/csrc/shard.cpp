@@ -273,7 +273,7 @@ static int shard_encode_phase(lcpc_commit_t* m, const uint64_t* coeffs_local, ui
   m->n_rows = n_rows_total; m->row_begin = rb; m->n_rows_local = re - rb;
   m->chunk_begin = cb; m->chunk_end = ce; m->n_chunks = nch;
   m->launches[0] = m->launches[1] = m->launches[2] = 0;
-  m->last.exchange_exposed_ms = 0.f;
+  m->last.exchange_exposed_ms = 0.f; m->last.exchange_wire_ms = 0.f;
   m->shard_encoded = false;
   const bool fused = c->prm.encoding == LCPC_ENC_LIGERO || m->n_rows_local >= SDIG_T_MIN_ROWS;
   const bool borrow = (flags & LCPC_COMMIT_BORROW_COEFFS) != 0 && m->n_rows_local > 0;   // local rows are always whole rows
