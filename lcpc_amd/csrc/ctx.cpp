@@ -20,6 +20,7 @@ void ctx_ref(lcpc_ctx* c) { c->refs.fetch_add(1); }
 static void ctx_free(lcpc_ctx* c) {
   (void)hipSetDevice(c->prm.device);
   comm_release(c);
+  dev_free(c->d_wq_w);
   dev_free(c->d_pack[0]); dev_free(c->d_pack[1]); dev_free(c->d_pack[2]); dev_free(c->d_roots29s); dev_free(c->d_roots29cs); dev_free(c->d_rootsls); dev_free(c->d_rootslcs);
   dev_free(c->d_rootsl); dev_free(c->d_rootslc); dev_free(c->d_qpl); dev_free(c->d_roots); dev_free(c->d_roots29); dev_free(c->d_roots29c); dev_free(c->d_qp29); dev_free(c->d_r2);
   dev_free(c->ws.d_tmp); dev_free(c->ws.d_t); dev_free(c->ws.d_mid); dev_free(c->d_scratch);
@@ -54,6 +55,34 @@ uint64_t ntt_mid_rows(const lcpc_ctx* c, uint64_t n_rows) {
   if (fit >= n_rows) return n_rows;
   const uint64_t batches = (n_rows + fit - 1) / fit;       // equal batches
   return (n_rows + batches - 1) / batches;
+}
+
+// The nine shifted multiples W_j = balanced(w 2^(29 j) mod p), j < 9, of a field element w (Montgomery form in), as the 81 words
+// t = 9 k + j = limb k of W_j (limbs 0..7 in [0, 2^29), limb 8 signed) that field_wmul_gen.h's wmul_u takes as scalar operands.
+static void wmul_table(const FieldDesc& f, const uint64_t* w_mont, uint32_t out[96]) {
+  uint64_t v[MAXL];
+  h_canon(f, v, w_mont);
+  memset(out, 0, 96 * 4);
+  for (int j = 0; j < 9; j++) {
+    // v > (p - 1) / 2 -> v - p, as a 320-bit two's complement number
+    uint64_t m[5] = {v[0], v[1], v[2], v[3], 0};
+    bool big = false;
+    for (int i = 3; i >= 0; i--) {
+      const uint64_t h = (f.p[i] >> 1) | (i < 3 ? f.p[i + 1] << 63 : 0);
+      if (v[i] != h) { big = v[i] > h; break; }
+    }
+    if (big) {
+      unsigned __int128 br = 0;
+      for (int i = 0; i < 5; i++) { const unsigned __int128 d = (unsigned __int128)m[i] - (i < 4 ? f.p[i] : 0) - (uint64_t)br; m[i] = (uint64_t)d; br = (d >> 64) & 1; }
+    }
+    for (int k = 0; k < 9; k++) {
+      const int b = 29 * k, wd = b / 64, sh = b % 64;
+      uint64_t x = m[wd] >> sh;
+      if (sh > 35) x |= m[wd + 1] << (64 - sh);
+      out[9 * k + j] = k < 8 ? (uint32_t)(x & ((1u << 29) - 1)) : (uint32_t)x;
+    }
+    for (int s = 0; s < 29; s++) h_add(f, v, v, v);         // (h_add works on fully reduced values of either form)
+  }
 }
 
 // ---- NTT pass plan (DESIGN.md "K1") ----------------------------------------------------------------
@@ -141,10 +170,13 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
         const bool first = i == 0;
         NttPassArgs a{};
         a.roots29c = j.canon_out ? c->d_roots29c : nullptr;
-        a.mont_prefix = (j.canon_out && !first) ? 4u : 0u;              // the last pass ends with a radix-4 round (10 stages)
+        // (canonical output: the last pass has a uniform round and converts what is left of block 0 before it -- no Montgomery-form
+        // prefix reaches the store; a first pass of 8 or 10 stages has one too, and then the last pass sees canonical values only)
+        a.mont_prefix = 0u;
+        a.blk0_gone = (!first && j.canon_out && c->passes[0].s % 2 == 0 && c->passes[0].s >= 8) ? 1u : 0u;
         a.dst = j.dst + r0 * c->n_cols * c->NL;
         a.src = first ? j.src + r0 * j.src_stride * c->NL : a.dst;
-        a.roots = c->d_roots; a.roots29 = c->d_roots29; a.qp29 = c->d_qp29;
+        a.roots = c->d_roots; a.roots29 = c->d_roots29; a.qp29 = c->d_qp29; a.wq_w = c->d_wq_w;
         a.src_stride = first ? j.src_stride : c->n_cols;
         a.dst_stride = c->n_cols;
         a.n_valid = first ? j.n_valid : c->n_cols;
@@ -173,11 +205,12 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       NttPassArgs a{};
       a.dst = j.dst;
       a.src = first ? j.src : j.dst;
-      a.roots = c->d_roots; a.qp29 = c->d_qp29;
+      a.roots = c->d_roots; a.qp29 = c->d_qp29; a.wq_w = c->d_wq_w;
       a.roots29 = sub ? c->d_roots29s : c->d_roots29;
       a.roots29c = j.canon_out ? (sub ? c->d_roots29cs : c->d_roots29c) : nullptr;
       a.canon_row_mask = sub ? (1u << s0) - 1 : 0u;
-      a.mont_prefix = (j.canon_out && i == 2) ? 4u : 0u;
+      a.mont_prefix = 0u;                                     // (as in the two-pass branch: pass 1 -- 10 stages -- has the uniform round)
+      a.blk0_gone = (i == 2 && j.canon_out) ? 1u : 0u;
       a.src_stride = first ? j.src_stride : ((uint64_t)1 << 20);
       a.dst_stride = first ? c->n_cols : ((uint64_t)1 << 20);
       a.n_valid = first ? j.n_valid : ((uint64_t)1 << 20);
@@ -503,6 +536,14 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       }
       if ((rc = dev_alloc(err, &c->d_qp29, tab.size() * 4))) return rc;
       HIPCHK(c, hipMemcpy(c->d_qp29, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+      // w^(n/4) = ROOT_OF_UNITY^(2^(S - 2)): the primitive 4th root the last two stages of every transform multiply by
+      uint64_t i4[MAXL];
+      memcpy(i4, f->rou, 8 * f->L);
+      for (unsigned i = 0; i + 2 < f->S; i++) h_mul(*f, i4, i4, i4);
+      uint32_t wt[96];
+      wmul_table(*f, i4, wt);
+      if ((rc = dev_alloc(err, &c->d_wq_w, sizeof wt))) return rc;
+      HIPCHK(c, hipMemcpy(c->d_wq_w, wt, sizeof wt, hipMemcpyHostToDevice));
       c->comm_canon = true;
     }
     if ((rc = dev_alloc(err, &c->d_r2, 8 * f->L))) return rc;

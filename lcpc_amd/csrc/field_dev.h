@@ -356,6 +356,7 @@ LCPC_DEV void fe_from29(u32 out[8], const u32 l[9]) {
   }
 }
 #include "field_r29_gen.h"   // r29_columns(): the 153-mad Comba/Montgomery chain as generated asm blocks
+#include "field_wmul_gen.h"  // wmul_u(): x * w mod p for a WAVE-UNIFORM w given as its nine shifted multiples (scalar operands)
 
 // r = a * b29 * 2^-261 mod p, fully reduced, packed.  a: packed element < p; b29: 9 limbs < 2^29.
 LCPC_DEV Fe<8> fe_mul_r29(const Fe<8>& a, const Fe29& b) {
@@ -480,6 +481,17 @@ LCPC_DEV void clamp_apply(L9& a, const Row9& nt) {
 LCPC_DEV L9 mul(const L9& a, const Fe29& w) {
   L9 r;
   r29_mul1s(a.v, w.v, r.v);       // one asm statement (field_r29_gen.h)
+  return r;
+}
+// a * w mod p for a wave-uniform w: wt = the 81 words t = 9 k + j of its shifted multiples W_j = balanced(w 2^(29 j) mod p), limb k
+// (host: ctx.cpp wmul_table).  a: limbs of a difference of two normalised values (sum |limb| < 9 * 2^29).  Result: normalised,
+// in (-2p, 2.7p).  119 instructions against mul()'s 188 (tools/lab, profiles/r05_ubench_wmul.jsonl: 1.6-1.8 x per second).
+LCPC_DEV L9 mul_u(const L9& a, const u32* wt) {
+  u32 np2[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) np2[j] = 0u - 2u * (u32)P29::limb(j);        // the limbs of -2p (the quotient counts units of 2p)
+  L9 r;
+  wmul_u(a.v, np2, wt, r.v);
   return r;
 }
 // exact: normalised |value| < 16p -> packed, fully reduced

@@ -91,6 +91,7 @@ struct lcpc_ctx {
   uint32_t* d_pack[3] = {nullptr, nullptr, nullptr};   // Ft255 two- / three-pass plans: lane-order twiddle packs of the specialised kernel (ntt_l9s.hip)
   lcpc::NttPackInfo pack_info[3]{};
   bool l9s = false;
+  uint32_t* d_wq_w = nullptr;      // Ft255: the shifted multiples of the primitive 4th root w^(n/4) (the same element for every n), 96 words
   bool l9s3 = false;               // 2^21 .. 2^26 columns: first-pass kernel over the whole rows, then the 2^20-point two-pass plan per block
   uint32_t* d_roots29s = nullptr;  // l9s3: the 2^20-point twiddle tables (every 2^(log_n - 20)-th entry of d_roots29 / d_roots29c)
   uint32_t* d_roots29cs = nullptr;

@@ -28,6 +28,10 @@ struct NttPassArgs {
   uint32_t canon_row_mask = 0; // canonical output (roots29c != null) applies to the rows r with (r & canon_row_mask) == 0 only: the
                            // three-pass plan runs its last two passes on n_rows << s0 sub-rows of 2^20 elements, of which only every
                            // 2^s0-th still holds never-multiplied elements (ntt_l9s.hip)
+  uint32_t blk0_gone = 0;  // shape-specialised kernel, canonical output: an earlier pass converted the last never-multiplied elements
+                           // (the round before its uniform round): this pass sees canonical values only
+  const uint32_t* wq_w = nullptr;  // shape-specialised last pass (ntt_l9s.hip): the shifted multiples of w^(n/4) (81 words, ctx.cpp wmul_table), the
+                           // one wave-uniform twiddle of the transform (stages k-2, k-1); null: the Montgomery-form table entry
   uint32_t tile_group = 0; // shape-specialised first pass (ntt_l9s.hip, ntt_lns.hip): 2^tile_group neighbouring tiles of a row are
                            // consecutive workgroups of one XCD (short strided runs then meet in that L2); needs
                            // tiles_per_row >= 8 << tile_group
@@ -39,6 +43,7 @@ hipError_t launch_ntt_pass(int nl, int log_tile, const NttPassArgs& a, hipStream
 struct NttPackInfo {
   uint32_t round_off[8];    // word offset of round slot r inside a class block
   uint32_t class_words;     // words per tile class
+  uint32_t u_off;           // passes with a uniform round (ntt_l9s.hip Shape::RU): word offset of its 4 x 3 shifted-multiples tables
 };
 bool ntt_l9s_supported(uint32_t log_n, uint32_t n_passes, int log_tile);
 // three passes for 2^21 .. 2^26 columns: s0 = log_n - 20 stages with the first-pass kernel on the whole rows (element stride 2^20),

@@ -47,7 +47,12 @@ template <int S, int LBT> struct Shape {
   static constexpr int NR4 = S / 2;
   static constexpr u32 period2 = 1u << (S - 1 + LBT);                     // radix-2 round: all 512 pairs differ
   static constexpr u32 period4(int r) { return 1u << (S - U0 - 2 * r - 2 + LBT); }
+  // the radix-4 round whose twiddle period is 4 (quads q and q + 4 share their twiddles): with the lanes dealt so that wave w holds
+  // the quads q = w mod 4, every lane of a wave multiplies by the SAME three twiddles -- the shifted-multiples multiply with scalar
+  // operands (l9::mul_u, 119 instructions against 188).  S + LBT == 10: round 3 of an even S >= 8; -1: the pass has none.
+  static constexpr int RU = (U0 == 0 && S >= 8) ? 3 : -1;
 };
+constexpr u32 U_SLOT = 96;                                  // words per shifted-multiples table (81 used)
 
 // MID: the intermediate between the two passes is not the packed comm buffer but a.mid, which holds every element as the
 // LDS tile holds it -- 9 signed 29-bit limbs, normalised, |value| < 4p (invariant I of field_dev.h) -- laid out per row as
@@ -62,6 +67,11 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
   static_assert(LT == 10, "1024-element tiles: one radix-4 quad (two radix-2 pairs) per thread and round");
   static_assert(FIRST || (LTJ == 0 && S % 2 == 0), "the last pass works on contiguous tiles and ends with the trivial stages k-2, k-1");
   using SH = Shape<S, LBT>;
+  constexpr int RU = SH::RU;
+  // a pass with a uniform round reads its tile with a lane stride of 16 elements there (64-way bank conflicts on the uint4
+  // planes): the tile is kept XOR-swizzled -- element e at slot e ^ ((e >> 4) & 15), a permutation inside every aligned block
+  // of 16 -- which leaves the consecutive accesses of the other rounds conflict-free and spreads that round's over all banks
+  auto SWZ = [](u32 e) -> u32 { if constexpr (RU >= 0) return e ^ ((e >> 4) & 15u); else return e; };
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* nqp = lds + (size_t)Lds9<LT>::T * 9;                  // NEGATED q*p rows (l9::clamp_apply)
   const u32 k = a.log_n;
@@ -103,8 +113,20 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     // the tile as the first pass left it: [limbs 0-3][limbs 4-7][limb 8] planes, the LDS layout itself
     const uint4* t4 = reinterpret_cast<const uint4*>(a.mid + (row << k) * 9 + (size_t)tile * (9 * T));
     uint4* l4 = reinterpret_cast<uint4*>(lds);
+    if constexpr (RU >= 0) {
+      // (the swizzled tile: planes 0 and 1 move whole uint4s, the limb-8 plane word by word -- (e + j) -> SWZ(e) ^ j for e = 0 mod 4)
+#pragma unroll
+      for (u32 i = tid; i < 2 * T; i += 256) l4[(i & ~(T - 1)) | SWZ(i & (T - 1))] = t4[i];
+#pragma unroll
+      for (u32 i = tid; i < T / 4; i += 256) {
+        const uint4 v = t4[2 * T + i];
+        const u32 b = 8 * T + SWZ(4 * i);
+        lds[b] = v.x; lds[b ^ 1u] = v.y; lds[b ^ 2u] = v.z; lds[b ^ 3u] = v.w;
+      }
+    } else {
 #pragma unroll
     for (u32 i = tid; i < 9 * T / 4; i += 256) l4[i] = t4[i];
+    }
   } else {
 #pragma unroll
   for (u32 e = tid; e < T; e += 256) {
@@ -116,12 +138,14 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     } else {
       v = fe_load<NL>(src + (size_t)g * NL);                 // < 2^256 (the first pass's store), not necessarily < p
     }
-    lds9_put<LT>(lds, e, l9::from_packed(v));
+    lds9_put<LT>(lds, SWZ(e), l9::from_packed(v));
   }
   }
   __syncthreads();
   const u32* cls_pack = pack + (size_t)(FIRST ? tile : 0u) * pi.class_words;
-  const bool blk0_tile = FIRST || tile == 0;                 // tiles that hold elements of "block 0" (never multiplied so far)
+  // tiles that hold elements of "block 0" (never multiplied so far).  a.blk0_gone: an earlier pass had a uniform round and
+  // converted what was left of block 0 before it (below): nothing is in Montgomery form any more
+  const bool blk0_tile = (FIRST || tile == 0) && a.blk0_gone == 0;
   const bool zero_hi = FIRST && a.n_valid <= (1ull << (k - 1));
 
   if constexpr (SH::U0 == 1) {
@@ -133,15 +157,15 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     for (u32 pp = 0; pp < 2; pp++) {
       const u32 e1 = tid + 256u * pp;                        // slots with the top stage bit clear are [0, half)
       const Fe29 w = pk_load<2>(blk, SH::period2, canon ? 1u : 0u, e1);
-      const L9 x = lds9_get<LT>(lds, e1);
+      const L9 x = lds9_get<LT>(lds, SWZ(e1));
       if (zero_hi) {
-        lds9_put<LT>(lds, e1 + half, l9::mul(x, w));         // (x, 0) -> (x, x w)
+        lds9_put<LT>(lds, SWZ(e1 + half), l9::mul(x, w));         // (x, 0) -> (x, x w)
       } else {
-        const L9 y = lds9_get<LT>(lds, e1 + half);
+        const L9 y = lds9_get<LT>(lds, SWZ(e1 + half));
         L9 sum = l9::add(x, y);                              // [0, 2p)
         l9::normalize(sum);
-        lds9_put<LT>(lds, e1, sum);
-        lds9_put<LT>(lds, e1 + half, l9::mul(l9::sub(x, y), w));
+        lds9_put<LT>(lds, SWZ(e1), sum);
+        lds9_put<LT>(lds, SWZ(e1 + half), l9::mul(l9::sub(x, y), w));
       }
     }
     __syncthreads();
@@ -160,60 +184,99 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     const u32 period = one << (hb - 1 + LBT);                // quads q and q + period share their twiddles
     const u32 jl = q & (period - 1);
     const u32* blk = cls_pack + pi.round_off[SH::U0 + r];
+    if constexpr (RU >= 0) {
+      if (r == RU) {
+        // ---- the uniform round: wave w takes the quads q = w mod 4, whose twiddles are the three of pack slot (w): scalar operands.
+        //      Block 0 is gone (converted in round RU - 1), so every lane multiplies by the same plain constants.
+        const u32 wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const u32 qu = ((tid & 63u) << 2) | wv;
+        const u32 lpu = qu & ((1u << LBT) - 1), ju = qu >> LBT;
+        const u32 iu = ((ju >> (hb - 1)) << (hb + 1)) | (ju & ((1u << (hb - 1)) - 1));
+        const u32 eu = (iu << LBT) | lpu;
+        const u32* wu = cls_pack + pi.u_off + wv * (3 * U_SLOT);
+        const L9 x0 = lds9_get<LT>(lds, SWZ(eu)), x1 = lds9_get<LT>(lds, SWZ(eu + dq));
+        const L9 x2 = lds9_get<LT>(lds, SWZ(eu + 2 * dq)), x3 = lds9_get<LT>(lds, SWZ(eu + 3 * dq));
+        const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);
+        L9 c0 = l9::add(b0, b1);
+        l9::clamp_apply(c0, l9::clamp_row(nqp, l9::clamp_q(c0.v[8])));
+        lds9_put<LT>(lds, SWZ(eu), c0);
+        L9 d1 = l9::sub(b0, b1);
+        l9::normalize(d1);                                                                 // mul_u wants sum |limb| < 9 * 2^29
+        lds9_put<LT>(lds, SWZ(eu + dq), l9::mul_u(d1, wu + 2 * U_SLOT));
+        const L9 b2 = l9::mul_u(l9::sub(x0, x2), wu);
+        const L9 b3 = l9::mul_u(l9::sub(x1, x3), wu + U_SLOT);                            // (-2p, 2.7p)
+        L9 c2 = l9::add(b2, b3);
+        l9::normalize(c2);
+        lds9_put<LT>(lds, SWZ(eu + 2 * dq), c2);
+        lds9_put<LT>(lds, SWZ(eu + 3 * dq), l9::mul_u(l9::sub(b2, b3), wu + 2 * U_SLOT));
+        __syncthreads();
+        continue;
+      }
+    }
     if (u == 0 && zero_hi) {
       // zero-padded first round (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x w); inputs < p; everything
       // is block 0, so with canonical output the multiplies leaving it (w0, w1, and w2 for c1) take the converting set
       const u32 vb = canon ? 3u : 0u;
       const Fe29 w0 = pk_load<6>(blk, period, vb + 0, jl), w2c = pk_load<6>(blk, period, vb + 2, jl), w2 = pk_load<6>(blk, period, 2, jl);
       if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
-        const L9 x0 = lds9_get<LT>(lds, e0);
-        lds9_put<LT>(lds, e0 + dq, l9::mul(x0, w2c));
+        const L9 x0 = lds9_get<LT>(lds, SWZ(e0));
+        lds9_put<LT>(lds, SWZ(e0 + dq), l9::mul(x0, w2c));
         const L9 b2 = l9::mul(x0, w0);
-        lds9_put<LT>(lds, e0 + 2 * dq, b2);
-        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(b2, w2));
+        lds9_put<LT>(lds, SWZ(e0 + 2 * dq), b2);
+        lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(b2, w2));
       } else {
         const Fe29 w1 = pk_load<6>(blk, period, vb + 1, jl);
-        const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
+        const L9 x0 = lds9_get<LT>(lds, SWZ(e0)), x1 = lds9_get<LT>(lds, SWZ(e0 + dq));
         L9 c0 = l9::add(x0, x1);                                                           // [0, 2p)
         l9::normalize(c0);
-        lds9_put<LT>(lds, e0, c0);
-        lds9_put<LT>(lds, e0 + dq, l9::mul(l9::sub(x0, x1), w2c));
+        lds9_put<LT>(lds, SWZ(e0), c0);
+        lds9_put<LT>(lds, SWZ(e0 + dq), l9::mul(l9::sub(x0, x1), w2c));
         const L9 b2 = l9::mul(x0, w0), b3 = l9::mul(x1, w1);                               // (-1.2p, 0.2p]
         L9 c2 = l9::add(b2, b3);
         l9::normalize(c2);
-        lds9_put<LT>(lds, e0 + 2 * dq, c2);
-        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2));
+        lds9_put<LT>(lds, SWZ(e0 + 2 * dq), c2);
+        lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(l9::sub(b2, b3), w2));
       }
       __syncthreads();
       continue;
     }
-    const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
-    const L9 x2 = lds9_get<LT>(lds, e0 + 2 * dq), x3 = lds9_get<LT>(lds, e0 + 3 * dq);     // I: normalised, |value| < 4p
+    const L9 x0 = lds9_get<LT>(lds, SWZ(e0)), x1 = lds9_get<LT>(lds, SWZ(e0 + dq));
+    const L9 x2 = lds9_get<LT>(lds, SWZ(e0 + 2 * dq)), x3 = lds9_get<LT>(lds, SWZ(e0 + 3 * dq));     // I: normalised, |value| < 4p
     const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);                                   // limbs [0, 2^30), |value| < 8p
     L9 c0 = l9::add(b0, b1);                                                               // limbs [0, 2^31), |value| < 16p
     if (last_two) {
       // outputs go straight to the store path (normalised, |value| < 16p)
       l9::normalize(c0);
-      const Fe29 wq = tw_entry29(a.roots29, 1u << (k - 2));                                // wave-uniform
       L9 c1 = l9::sub(b0, b1);
       const L9 b2 = l9::sub(x0, x2);
-      const L9 b3 = l9::mul(l9::sub(x1, x3), wq);
+      // w^(n/4) is the one twiddle every lane shares: its multiply takes the shifted-multiples form (scalar operands)
+      const L9 b3 = a.wq_w != nullptr ? l9::mul_u(l9::sub(x1, x3), a.wq_w) : l9::mul(l9::sub(x1, x3), tw_entry29(a.roots29, 1u << (k - 2)));
       L9 c2 = l9::add(b2, b3);
       L9 c3 = l9::sub(b2, b3);
       l9::normalize(c1); l9::normalize(c2); l9::normalize(c3);
-      lds9_put<LT>(lds, e0, c0);
-      lds9_put<LT>(lds, e0 + dq, c1);
-      lds9_put<LT>(lds, e0 + 2 * dq, c2);
-      lds9_put<LT>(lds, e0 + 3 * dq, c3);
+      lds9_put<LT>(lds, SWZ(e0), c0);
+      lds9_put<LT>(lds, SWZ(e0 + dq), c1);
+      lds9_put<LT>(lds, SWZ(e0 + 2 * dq), c2);
+      lds9_put<LT>(lds, SWZ(e0 + 3 * dq), c3);
     } else {
       // clamp the pure sum at once: c0 leaves the registers before the multiplier chains start (holding it and its
       // q*p row across them spills at 128 VGPRs: +1 GB of scratch writes per pass, profiles/r02b)
       l9::clamp_apply(c0, l9::clamp_row(nqp, l9::clamp_q(c0.v[8])));                       // [0, p + 2^239)
-      lds9_put<LT>(lds, e0, c0);
+      lds9_put<LT>(lds, SWZ(e0), c0);
       // block 0 of stages (u, u + 1) = the quads whose elements all lie below n / 2^(t + 2): here exactly q < period in the
       // tiles that hold block 0.  Their three multiplies that leave block 0 take the converting set; c0 stays a pure sum;
       // c3's inputs b2, b3 are already canonical
-      const bool blk0c = canon && blk0_tile && q < period;
+      const bool blk0c = canon && blk0_tile && q < period && (RU < 0 || r < RU);
+      if constexpr (RU >= 1) {
+        if (r == RU - 1 && blk0c) {
+          // the last round before the uniform one: c0, the pure sum that would carry block 0 on, is converted as well (a multiply
+          // by 2^5 = 2^261 R^-1: 16 lanes of one wave per block-0 tile), so that the uniform round sees canonical values only
+          Fe29 k32;
+#pragma unroll
+          for (int i = 0; i < 9; i++) k32.v[i] = i == 0 ? 32u : 0u;
+          lds9_put<LT>(lds, SWZ(e0), l9::mul(c0, k32));
+        }
+      }
       const u32 vb = blk0c ? 3u : 0u;
       const Fe29 w0 = pk_load<6>(blk, period, vb + 0, jl), w1 = pk_load<6>(blk, period, vb + 1, jl);
       const Fe29 w2 = pk_load<6>(blk, period, 2, jl);
@@ -221,13 +284,13 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       L9 c1;
       if (blk0c) c1 = l9::mul(d1, pk_load<6>(blk, period, 5, jl));
       else c1 = l9::mul(d1, w2);
-      lds9_put<LT>(lds, e0 + dq, c1);                                                      // normalised, (-1.2p, 0.2p]
+      lds9_put<LT>(lds, SWZ(e0 + dq), c1);                                                      // normalised, (-1.2p, 0.2p]
       const L9 b2 = l9::mul(l9::sub(x0, x2), w0);                                          // in: |value| < 8p
       const L9 b3 = l9::mul(l9::sub(x1, x3), w1);
       L9 c2 = l9::add(b2, b3);                                                             // (-2.4p, 0.4p]
       l9::normalize(c2);
-      lds9_put<LT>(lds, e0 + 2 * dq, c2);
-      lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2));
+      lds9_put<LT>(lds, SWZ(e0 + 2 * dq), c2);
+      lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(l9::sub(b2, b3), w2));
     }
     __syncthreads();
   }
@@ -241,7 +304,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     for (u32 e = tid; e < T; e += 256) {
       const u32 e2 = (tile << LTJ) | (e & ((1u << LBT) - 1));
       u32* t = mrow + (size_t)(e >> LBT) * (9 * T);
-      const L9 x = lds9_get<LT>(lds, e);
+      const L9 x = lds9_get<LT>(lds, SWZ(e));
       *reinterpret_cast<uint4*>(t + (size_t)e2 * 4) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
       *reinterpret_cast<uint4*>(t + (size_t)(T + e2) * 4) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
       t[(size_t)8 * T + e2] = x.v[8];
@@ -252,7 +315,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
 #pragma unroll
   for (u32 e = tid; e < T; e += 256) {
     const u32 g = gindex(e);
-    L9 x = lds9_get<LT>(lds, e);                                        // normalised, |value| < 16p
+    L9 x = lds9_get<LT>(lds, SWZ(e));                                        // normalised, |value| < 16p
     l9::clamp_apply(x, l9::clamp_row(nqp, l9::clamp_q(x.v[8])));        // [0, p + 2^239) < 2^256
     u32 w[8];
     fe_from29(w, x.v);
@@ -313,12 +376,69 @@ __global__ void __launch_bounds__(256) ntt_pack_kernel(NttPassArgs a, NttPackInf
   }
 }
 
+// the uniform round's constants: per class, for jl = 0..3 and the round's three twiddles w0, w1, w2 (plain: block 0 is gone by then),
+// the nine shifted multiples W_j = balanced(w 2^(29 j) mod p) as 81 words t = 9 k + j (limb k of W_j; l9::mul_u / field_wmul_gen.h).
+// The table entry is w 2^261 mod p as limbs: fe_mul_r29(2^(29 j), entry) = w 2^(29 j), fully reduced.
+template <int S, int LBT>
+__global__ void __launch_bounds__(64) ntt_upack_kernel(NttPassArgs a, NttPackInfo pi, u32 n_classes, bool first, u32* pack) {
+  using SH = Shape<S, LBT>;
+  constexpr int r = SH::RU;
+  const u32 k = a.log_n, t0 = a.t0;
+  const u32 lb = first ? k - S : 0u;
+  const u32 id = blockIdx.x * 64 + threadIdx.x;
+  if (id >= n_classes * 12) return;
+  const u32 cls = id / 12, jl = (id % 12) / 3, v = id % 3;
+  constexpr u32 u = SH::U0 + 2 * r, hb = S - u - 1;
+  const u32 t = t0 + u;
+  const u32 lo = first ? (cls << LBT) : 0u;
+  const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
+  const u32 lp = jl & ((1u << LBT) - 1), j = jl >> LBT;
+  const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+  const u32 g0 = (i0 << lb) | lo | lp;
+  const u32 g1 = g0 + (1u << (hb - 1 + lb));
+  const u32 idx = v == 0 ? (g0 & gm0) << t : (v == 1 ? (g1 & gm0) << t : (g0 & gm1) << (t + 1));
+  const Fe29 w = tw_entry29(a.roots29, idx);
+  u32* out = pack + (size_t)cls * pi.class_words + pi.u_off + (jl * 3 + v) * U_SLOT;
+  for (u32 jj = 0; jj < 9; jj++) {
+    Fe<8> sh = fe_zero<8>();
+    sh.v[(29 * jj) / 32] = 1u << ((29 * jj) % 32);
+    const Fe<8> val = fe_mul_r29(sh, w);                     // w 2^(29 jj) mod p, in [0, p)
+    u32 m[9];
+#pragma unroll
+    for (int z = 0; z < 8; z++) m[z] = val.v[z];
+    m[8] = 0;
+    bool big = false, decided = false;                       // val > (p - 1) / 2 -> val - p (288-bit two's complement)
+#pragma unroll
+    for (int z = 7; z >= 0; z--) {
+      const u32 hz = (Mod<8>::P[z] >> 1) | (z < 7 ? (Mod<8>::P[z + 1] & 1u) << 31 : 0u);
+      if (!decided && val.v[z] != hz) { big = val.v[z] > hz; decided = true; }
+    }
+    if (big) {
+      u64 br = 0;
+#pragma unroll
+      for (int z = 0; z < 9; z++) {
+        const u64 d = (u64)m[z] - (z < 8 ? Mod<8>::P[z] : 0u) - br;
+        m[z] = (u32)d;
+        br = (d >> 32) & 1u;
+      }
+    }
+    for (u32 kk = 0; kk < 9; kk++) {
+      const u32 b = 29 * kk, wd = b / 32, shb = b % 32;
+      u64 x = (u64)m[wd] >> shb;
+      if (wd + 1 < 9) x |= (u64)m[wd + 1] << (32 - shb);
+      out[9 * kk + jj] = kk < 8 ? (u32)(x & P29::M) : (u32)x;  // limb 8: bits 232 .. 263, sign-extended (m[8] is 0 or ~0)
+    }
+  }
+  for (u32 z = 81; z < U_SLOT; z++) out[z] = 0;
+}
+
 template <int S, int LBT> NttPackInfo pack_info_t() {
   using SH = Shape<S, LBT>;
   NttPackInfo pi{};
   u32 off = 0, slot = 0;
   if (SH::U0) { pi.round_off[slot++] = off; off += 2 * SH::period2 * 9; off = (off + 3) & ~3u; }
   for (int r = 0; r < SH::NR4; r++) { pi.round_off[slot++] = off; off += 6 * SH::period4(r) * 9; off = (off + 3) & ~3u; }
+  if (SH::RU >= 0) { pi.u_off = off; off += 4 * 3 * U_SLOT; }
   pi.class_words = off;
   return pi;
 }
@@ -371,8 +491,10 @@ NttPackInfo ntt_l9s_pack_info(uint32_t s, bool first) {
 
 hipError_t launch_ntt_l9s_pack(const NttPassArgs& a, bool first, const NttPackInfo& pi, uint32_t n_classes, uint32_t* pack, hipStream_t st) {
   const unsigned grid = 2048;
+  const unsigned ugrid = (n_classes * 12 + 63) / 64;
   if (!first) {
     hipLaunchKernelGGL((ntt_pack_kernel<10, 0>), dim3(64), dim3(256), 0, st, a, pi, n_classes, false, pack);
+    hipLaunchKernelGGL((ntt_upack_kernel<10, 0>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, false, pack);
     return hipGetLastError();
   }
   switch (a.s) {
@@ -381,6 +503,8 @@ hipError_t launch_ntt_l9s_pack(const NttPassArgs& a, bool first, const NttPackIn
 #undef X
     default: return hipErrorInvalidValue;
   }
+  if (a.s == 8) hipLaunchKernelGGL((ntt_upack_kernel<8, 2>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, true, pack);
+  if (a.s == 10) hipLaunchKernelGGL((ntt_upack_kernel<10, 0>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, true, pack);
   return hipGetLastError();
 }
 

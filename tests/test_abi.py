@@ -237,14 +237,15 @@ def test_shard_node_layout_matches_python():
 
 
 def test_generated_sources_are_deterministic_and_current():
-    """keccak_x25_gen.h, field_r29_gen.h and field_ln_gen.h are build products of lcpc_amd/csrc/Makefile (git-ignored, 13 000 lines):
+    """keccak_x25_gen.h, field_r29_gen.h, field_ln_gen.h and field_wmul_gen.h are build products of lcpc_amd/csrc/Makefile (git-ignored, 13 000 lines):
     each generator is a pure function of its own text -- two runs give the same bytes -- and the header the library was built
     from is what the generator prints now (a stale header would mean the .so does not match the tree)."""
     import subprocess
     import sys
     csrc = os.path.join(ROOT, "lcpc_amd", "csrc")
     tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "lcpc_amd/csrc"], capture_output=True, text=True).stdout
-    for gen, hdr in (("gen_keccak_x25.py", "keccak_x25_gen.h"), ("gen_r29_asm.py", "field_r29_gen.h"), ("gen_ln_asm.py", "field_ln_gen.h")):
+    for gen, hdr in (("gen_keccak_x25.py", "keccak_x25_gen.h"), ("gen_r29_asm.py", "field_r29_gen.h"), ("gen_ln_asm.py", "field_ln_gen.h"),
+                     ("gen_wmul_asm.py", "field_wmul_gen.h")):
         a = subprocess.run([sys.executable, os.path.join(csrc, "gen", gen)], capture_output=True, check=True).stdout
         b = subprocess.run([sys.executable, os.path.join(csrc, "gen", gen)], capture_output=True, check=True, env=dict(os.environ, PYTHONHASHSEED="12345")).stdout
         assert a == b and len(a) > 1000, gen
