@@ -171,9 +171,9 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
         NttPassArgs a{};
         a.roots29c = j.canon_out ? c->d_roots29c : nullptr;
         // (canonical output: the last pass has a uniform round and converts what is left of block 0 before it -- no Montgomery-form
-        // prefix reaches the store; a first pass of 8 or 10 stages has one too, and then the last pass sees canonical values only)
+        // prefix reaches the store; a first pass of 8 to 10 stages has one too, and then the last pass sees canonical values only)
         a.mont_prefix = 0u;
-        a.blk0_gone = (!first && j.canon_out && c->passes[0].s % 2 == 0 && c->passes[0].s >= 8) ? 1u : 0u;
+        a.blk0_gone = (!first && j.canon_out && c->passes[0].s >= 8) ? 1u : 0u;
         a.dst = j.dst + r0 * c->n_cols * c->NL;
         a.src = first ? j.src + r0 * j.src_stride * c->NL : a.dst;
         a.roots = c->d_roots; a.roots29 = c->d_roots29; a.qp29 = c->d_qp29; a.wq_w = c->d_wq_w;

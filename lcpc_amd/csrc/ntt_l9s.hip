@@ -49,8 +49,11 @@ template <int S, int LBT> struct Shape {
   static constexpr u32 period4(int r) { return 1u << (S - U0 - 2 * r - 2 + LBT); }
   // the radix-4 round whose twiddle period is 4 (quads q and q + 4 share their twiddles): with the lanes dealt so that wave w holds
   // the quads q = w mod 4, every lane of a wave multiplies by the SAME three twiddles -- the shifted-multiples multiply with scalar
-  // operands (l9::mul_u, 119 instructions against 188).  S + LBT == 10: round 3 of an even S >= 8; -1: the pass has none.
-  static constexpr int RU = (U0 == 0 && S >= 8) ? 3 : -1;
+  // operands (l9::mul_u, 119 instructions against 188).  The same deal serves periods 2 and 1.  S + LBT == 10: the period
+  // is 2^(8 - U0 - 2 r), i.e. <= 4 from round 3 on: RU = 3 where the pass has four radix-4 rounds (S >= 8), -1: none.  NRU: how
+  // many rounds from RU on (a last pass ends with the trivial stages k-2, k-1, which have their own form).
+  static constexpr int RU = NR4 >= 4 ? 3 : -1;
+  static constexpr int NRU = RU < 0 ? 0 : NR4 - RU;
 };
 constexpr u32 U_SLOT = 96;                                  // words per shifted-multiples table (81 used)
 
@@ -185,15 +188,15 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     const u32 jl = q & (period - 1);
     const u32* blk = cls_pack + pi.round_off[SH::U0 + r];
     if constexpr (RU >= 0) {
-      if (r == RU) {
-        // ---- the uniform round: wave w takes the quads q = w mod 4, whose twiddles are the three of pack slot (w): scalar operands.
+      if (r >= RU && !last_two) {
+        // ---- a uniform round: wave w takes the quads q = w mod 4, whose twiddles are the three of pack slot (w): scalar operands.
         //      Block 0 is gone (converted in round RU - 1), so every lane multiplies by the same plain constants.
         const u32 wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const u32 qu = ((tid & 63u) << 2) | wv;
         const u32 lpu = qu & ((1u << LBT) - 1), ju = qu >> LBT;
         const u32 iu = ((ju >> (hb - 1)) << (hb + 1)) | (ju & ((1u << (hb - 1)) - 1));
         const u32 eu = (iu << LBT) | lpu;
-        const u32* wu = cls_pack + pi.u_off + wv * (3 * U_SLOT);
+        const u32* wu = cls_pack + pi.u_off + ((r - RU) * 4 + wv) * (3 * U_SLOT);
         const L9 x0 = lds9_get<LT>(lds, SWZ(eu)), x1 = lds9_get<LT>(lds, SWZ(eu + dq));
         const L9 x2 = lds9_get<LT>(lds, SWZ(eu + 2 * dq)), x3 = lds9_get<LT>(lds, SWZ(eu + 3 * dq));
         const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);
@@ -382,14 +385,16 @@ __global__ void __launch_bounds__(256) ntt_pack_kernel(NttPassArgs a, NttPackInf
 template <int S, int LBT>
 __global__ void __launch_bounds__(64) ntt_upack_kernel(NttPassArgs a, NttPackInfo pi, u32 n_classes, bool first, u32* pack) {
   using SH = Shape<S, LBT>;
-  constexpr int r = SH::RU;
   const u32 k = a.log_n, t0 = a.t0;
   const u32 lb = first ? k - S : 0u;
   const u32 id = blockIdx.x * 64 + threadIdx.x;
-  if (id >= n_classes * 12) return;
-  const u32 cls = id / 12, jl = (id % 12) / 3, v = id % 3;
-  constexpr u32 u = SH::U0 + 2 * r, hb = S - u - 1;
+  if (id >= n_classes * SH::NRU * 12) return;
+  const u32 cls = id / (SH::NRU * 12), ru = (id / 12) % SH::NRU, jl0 = (id % 12) / 3, v = id % 3;
+  const u32 r = SH::RU + ru;
+  const u32 u = SH::U0 + 2 * r, hb = S - u - 1;
   const u32 t = t0 + u;
+  if (t + 2 == k) return;                                    // (a last pass's final round: w^(n/4), not packed)
+  const u32 jl = jl0 & (SH::period4(r) - 1);                 // periods 2 and 1: the four slots repeat
   const u32 lo = first ? (cls << LBT) : 0u;
   const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
   const u32 lp = jl & ((1u << LBT) - 1), j = jl >> LBT;
@@ -398,7 +403,7 @@ __global__ void __launch_bounds__(64) ntt_upack_kernel(NttPassArgs a, NttPackInf
   const u32 g1 = g0 + (1u << (hb - 1 + lb));
   const u32 idx = v == 0 ? (g0 & gm0) << t : (v == 1 ? (g1 & gm0) << t : (g0 & gm1) << (t + 1));
   const Fe29 w = tw_entry29(a.roots29, idx);
-  u32* out = pack + (size_t)cls * pi.class_words + pi.u_off + (jl * 3 + v) * U_SLOT;
+  u32* out = pack + (size_t)cls * pi.class_words + pi.u_off + ((ru * 4 + jl0) * 3 + v) * U_SLOT;
   for (u32 jj = 0; jj < 9; jj++) {
     Fe<8> sh = fe_zero<8>();
     sh.v[(29 * jj) / 32] = 1u << ((29 * jj) % 32);
@@ -438,7 +443,7 @@ template <int S, int LBT> NttPackInfo pack_info_t() {
   u32 off = 0, slot = 0;
   if (SH::U0) { pi.round_off[slot++] = off; off += 2 * SH::period2 * 9; off = (off + 3) & ~3u; }
   for (int r = 0; r < SH::NR4; r++) { pi.round_off[slot++] = off; off += 6 * SH::period4(r) * 9; off = (off + 3) & ~3u; }
-  if (SH::RU >= 0) { pi.u_off = off; off += 4 * 3 * U_SLOT; }
+  if (SH::RU >= 0) { pi.u_off = off; off += SH::NRU * 4 * 3 * U_SLOT; }
   pi.class_words = off;
   return pi;
 }
@@ -491,7 +496,7 @@ NttPackInfo ntt_l9s_pack_info(uint32_t s, bool first) {
 
 hipError_t launch_ntt_l9s_pack(const NttPassArgs& a, bool first, const NttPackInfo& pi, uint32_t n_classes, uint32_t* pack, hipStream_t st) {
   const unsigned grid = 2048;
-  const unsigned ugrid = (n_classes * 12 + 63) / 64;
+  const unsigned ugrid = (n_classes * 2 * 12 + 63) / 64;      // (<= 2 uniform rounds per pass)
   if (!first) {
     hipLaunchKernelGGL((ntt_pack_kernel<10, 0>), dim3(64), dim3(256), 0, st, a, pi, n_classes, false, pack);
     hipLaunchKernelGGL((ntt_upack_kernel<10, 0>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, false, pack);
@@ -504,6 +509,7 @@ hipError_t launch_ntt_l9s_pack(const NttPassArgs& a, bool first, const NttPackIn
     default: return hipErrorInvalidValue;
   }
   if (a.s == 8) hipLaunchKernelGGL((ntt_upack_kernel<8, 2>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, true, pack);
+  if (a.s == 9) hipLaunchKernelGGL((ntt_upack_kernel<9, 1>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, true, pack);
   if (a.s == 10) hipLaunchKernelGGL((ntt_upack_kernel<10, 0>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, true, pack);
   return hipGetLastError();
 }
