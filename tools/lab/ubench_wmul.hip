@@ -1,7 +1,7 @@
 // tools/ubench_wmul.hip -- LAB: what a WAVE-UNIFORM twiddle would buy the Ft255 row NTT (LABNOTES Part 0, "shifted multiples").
 //   A  today's multiply: l9::mul = r29_mul1s, 153 mads + 35, per-LANE twiddle (36 B per lane and multiply, coalesced)
 //   B  x * w as sum_j x_j * W_j with the nine precomputed W_j = balanced(w 2^(29 j) mod p) of a wave-uniform w (81 dwords by
-//      scalar loads inside the statement) + one 32-bit quotient: 90 mads + 26  (tools/gen_wmul_asm.py)
+//      scalar loads inside the statement) + one 32-bit quotient: 90 mads + 26  (lcpc_amd/csrc/gen/gen_wmul_asm.py)
 // Each thread runs a dependent chain x <- x * w_i of ITERS multiplies (one accumulator chain per wave and multiply, as in K1s);
 // occupancy by __launch_bounds__.  Results of B are checked on the host (r == x * prod w_i mod p, done by the caller script with
 // Python integers from the dumped values).
