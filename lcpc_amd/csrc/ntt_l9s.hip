@@ -26,8 +26,16 @@ namespace lcpc {
 namespace {
 
 // pack block of one (class, round): [NV variants][2 chunks of 16 B][period] uint4, then [NV][period] u32 (limb 8).
-// radix-4 rounds: variants 0 w0, 1 w1, 2 w2 (plain table, w^i * 2^261) and 3, 4, 5 the same from the converting table
+// radix-4 rounds: variants 0 w0, 1 w3, 2 w2 (plain table, w^i * 2^261) and 3, 4, 5 the same from the converting table
 // (w^i * 2^5); the radix-2 round: 0 w, 1 converting w.
+//
+// The radix-4 butterfly of stages (t, t + 1) on x0 .. x3 (quarter-block apart), radix-2 DIF regrouped:
+//   b0 = x0 + x2, b1 = x1 + x3, b2 = (x0 - x2) w0, b3 = (x1 - x3) w1;  c0 = b0 + b1, c1 = (b0 - b1) w2, c2 = b2 + b3, c3 = (b2 - b3) w2
+// with w0 = w^e, w1 = w^(e + n/4) = I w0 (I = w^(n/4), the field's fixed primitive 4th root of unity) and w2 = w0^2.  Hence
+//   t = (x1 - x3) I;  c2 = ((x0 - x2) + t) w0;  c3 = ((x0 - x2) - t) w3,  w3 = w0 w2 = w^(3 e):
+// I is ONE constant for every lane of every transform, so its multiply takes the shifted-multiples form with scalar operands
+// (l9::mul_u on a.wq_w: 119 instructions) and a generic round does three lane-varying Montgomery multiplies (188 each) instead
+// of four; c2 comes out of a multiplier normalised.  Exact arithmetic mod p: the same fully reduced bits.
 template <u32 NV> LCPC_DEV Fe29 pk_load(const u32* blk, u32 period, u32 variant, u32 jl) {
   // 32-bit byte offsets from the (wave-uniform) block pointer: scalar base + vector offset addressing, no 64-bit VALU adds
   // (a class block is < 2^20 words)
@@ -218,27 +226,23 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     }
     if (u == 0 && zero_hi) {
       // zero-padded first round (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x w); inputs < p; everything
-      // is block 0, so with canonical output the multiplies leaving it (w0, w1, and w2 for c1) take the converting set
+      // is block 0, so with canonical output the three multiplies leaving it (w0, w3, and w2 for c1) take the converting set
       const u32 vb = canon ? 3u : 0u;
-      const Fe29 w0 = pk_load<6>(blk, period, vb + 0, jl), w2c = pk_load<6>(blk, period, vb + 2, jl), w2 = pk_load<6>(blk, period, 2, jl);
+      const Fe29 w0 = pk_load<6>(blk, period, vb + 0, jl), w3 = pk_load<6>(blk, period, vb + 1, jl), w2 = pk_load<6>(blk, period, vb + 2, jl);
       if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
         const L9 x0 = lds9_get<LT>(lds, SWZ(e0));
-        lds9_put<LT>(lds, SWZ(e0 + dq), l9::mul(x0, w2c));
-        const L9 b2 = l9::mul(x0, w0);
-        lds9_put<LT>(lds, SWZ(e0 + 2 * dq), b2);
-        lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(b2, w2));
+        lds9_put<LT>(lds, SWZ(e0 + dq), l9::mul(x0, w2));
+        lds9_put<LT>(lds, SWZ(e0 + 2 * dq), l9::mul(x0, w0));
+        lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(x0, w3));
       } else {
-        const Fe29 w1 = pk_load<6>(blk, period, vb + 1, jl);
         const L9 x0 = lds9_get<LT>(lds, SWZ(e0)), x1 = lds9_get<LT>(lds, SWZ(e0 + dq));
         L9 c0 = l9::add(x0, x1);                                                           // [0, 2p)
         l9::normalize(c0);
         lds9_put<LT>(lds, SWZ(e0), c0);
-        lds9_put<LT>(lds, SWZ(e0 + dq), l9::mul(l9::sub(x0, x1), w2c));
-        const L9 b2 = l9::mul(x0, w0), b3 = l9::mul(x1, w1);                               // (-1.2p, 0.2p]
-        L9 c2 = l9::add(b2, b3);
-        l9::normalize(c2);
-        lds9_put<LT>(lds, SWZ(e0 + 2 * dq), c2);
-        lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(l9::sub(b2, b3), w2));
+        lds9_put<LT>(lds, SWZ(e0 + dq), l9::mul(l9::sub(x0, x1), w2));
+        const L9 t = l9::mul_u(x1, a.wq_w);                                                // x1 I (plain constant: t keeps x1's form); (-2p, 2.7p)
+        lds9_put<LT>(lds, SWZ(e0 + 2 * dq), l9::mul(l9::add(x0, t), w0));                  // in: limbs (-2^29, 2^30), |value| < 3.7p
+        lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(l9::sub(x0, t), w3));
       }
       __syncthreads();
       continue;
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       L9 c1 = l9::sub(b0, b1);
       const L9 b2 = l9::sub(x0, x2);
       // w^(n/4) is the one twiddle every lane shares: its multiply takes the shifted-multiples form (scalar operands)
-      const L9 b3 = a.wq_w != nullptr ? l9::mul_u(l9::sub(x1, x3), a.wq_w) : l9::mul(l9::sub(x1, x3), tw_entry29(a.roots29, 1u << (k - 2)));
+      const L9 b3 = l9::mul_u(l9::sub(x1, x3), a.wq_w);
       L9 c2 = l9::add(b2, b3);
       L9 c3 = l9::sub(b2, b3);
       l9::normalize(c1); l9::normalize(c2); l9::normalize(c3);
@@ -267,8 +271,8 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       l9::clamp_apply(c0, l9::clamp_row(nqp, l9::clamp_q(c0.v[8])));                       // [0, p + 2^239)
       lds9_put<LT>(lds, SWZ(e0), c0);
       // block 0 of stages (u, u + 1) = the quads whose elements all lie below n / 2^(t + 2): here exactly q < period in the
-      // tiles that hold block 0.  Their three multiplies that leave block 0 take the converting set; c0 stays a pure sum;
-      // c3's inputs b2, b3 are already canonical
+      // tiles that hold block 0.  Their three multiplies that leave block 0 (c1, c2, c3) take the converting set; c0 stays a
+      // pure sum
       const bool blk0c = canon && blk0_tile && q < period && (RU < 0 || r < RU);
       if constexpr (RU >= 1) {
         if (r == RU - 1 && blk0c) {
@@ -281,19 +285,15 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
         }
       }
       const u32 vb = blk0c ? 3u : 0u;
-      const Fe29 w0 = pk_load<6>(blk, period, vb + 0, jl), w1 = pk_load<6>(blk, period, vb + 1, jl);
-      const Fe29 w2 = pk_load<6>(blk, period, 2, jl);
+      const Fe29 w0 = pk_load<6>(blk, period, vb + 0, jl), w3 = pk_load<6>(blk, period, vb + 1, jl);
+      const Fe29 w2 = pk_load<6>(blk, period, vb + 2, jl);
       const L9 d1 = l9::sub(b0, b1);                                                       // limbs (-2^30, 2^30), |value| < 16p
-      L9 c1;
-      if (blk0c) c1 = l9::mul(d1, pk_load<6>(blk, period, 5, jl));
-      else c1 = l9::mul(d1, w2);
-      lds9_put<LT>(lds, SWZ(e0 + dq), c1);                                                      // normalised, (-1.2p, 0.2p]
-      const L9 b2 = l9::mul(l9::sub(x0, x2), w0);                                          // in: |value| < 8p
-      const L9 b3 = l9::mul(l9::sub(x1, x3), w1);
-      L9 c2 = l9::add(b2, b3);                                                             // (-2.4p, 0.4p]
-      l9::normalize(c2);
-      lds9_put<LT>(lds, SWZ(e0 + 2 * dq), c2);
-      lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(l9::sub(b2, b3), w2));
+      lds9_put<LT>(lds, SWZ(e0 + dq), l9::mul(d1, w2));                                    // normalised, (-1.2p, 0.2p]
+      // t = (x1 - x3) I by the plain constant: in block 0 it stays in the form of its inputs and the two products below convert
+      const L9 t = l9::mul_u(l9::sub(x1, x3), a.wq_w);                                     // normalised, (-2p, 2.7p)
+      const L9 e2 = l9::sub(x0, x2);                                                       // limbs (-2^29, 2^29), |value| < 8p
+      lds9_put<LT>(lds, SWZ(e0 + 2 * dq), l9::mul(l9::add(e2, t), w0));                    // in: limbs (-2^29, 2^30), |value| < 10.7p
+      lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(l9::sub(e2, t), w3));
     }
     __syncthreads();
   }
@@ -364,17 +364,33 @@ __global__ void __launch_bounds__(256) ntt_pack_kernel(NttPassArgs a, NttPackInf
     const u32 r = slot - SH::U0, u = SH::U0 + 2 * r, hb = S - u - 1, period = 1u << (hb - 1 + LBT);
     const u32 t = t0 + u;
     if (jl >= period || t + 2 == k) continue;                // (stages k-2, k-1: one wave-uniform twiddle, not packed)
-    const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
+    const u32 gm0 = (1u << (k - t - 1)) - 1;
     const u32 lp = jl & ((1u << LBT) - 1), j = jl >> LBT;
     const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
     const u32 g0 = (i0 << lb) | lo | lp;                     // (last pass: the tile's high bits do not reach these twiddles)
-    const u32 g1 = g0 + (1u << (hb - 1 + lb));
-    const u32 idx[3] = {(g0 & gm0) << t, (g1 & gm0) << t, (g0 & gm1) << (t + 1)};
+    // w0 = w^e, w3 = w^(3 e), w2 = w^(2 e) with e = (g0 & gm0) << t < n / 4 (g0 has the quarter bit clear; the pass kernel's
+    // w1 = w^(e + n/4) = I w0 is never read).  The tables hold w^i for i < n / 2 and w^(n/2) = -1: past that, the negated entry
+    const u32 e1x = (g0 & gm0) << t, half_n = 1u << (k - 1);
+    const u32 idx[3] = {e1x, 3 * e1x, 2 * e1x};
     for (u32 v = 0; v < 6; v++) {
-      const u32* e = (v < 3 ? a.roots29 : a.roots29c) + (size_t)idx[v % 3] * 12;
+      const u32 ix = idx[v % 3];
+      const u32* e = (v < 3 ? a.roots29 : a.roots29c) + (size_t)(ix & (half_n - 1)) * 12;
+      u32 m[9];
+      if (ix >= half_n) {                                    // p - entry, limb-wise with borrow (entry in (0, p))
+        int32_t br = 0;
+#pragma unroll
+        for (int z = 0; z < 9; z++) {
+          const int32_t d = (int32_t)P29::limb(z) - (int32_t)e[z] - br;
+          br = d < 0 ? 1 : 0;
+          m[z] = z < 8 ? (u32)d & P29::M : (u32)d;
+        }
+      } else {
+#pragma unroll
+        for (int z = 0; z < 9; z++) m[z] = e[z];
+      }
       for (u32 c = 0; c < 2; c++)
-        for (u32 w = 0; w < 4; w++) blk[((size_t)(v * 2 + c) * period + jl) * 4 + w] = e[c * 4 + w];
-      blk[(size_t)6 * 2 * period * 4 + (size_t)v * period + jl] = e[8];
+        for (u32 w = 0; w < 4; w++) blk[((size_t)(v * 2 + c) * period + jl) * 4 + w] = m[c * 4 + w];
+      blk[(size_t)6 * 2 * period * 4 + (size_t)v * period + jl] = m[8];
     }
   }
 }
