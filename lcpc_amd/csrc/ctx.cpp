@@ -57,32 +57,48 @@ uint64_t ntt_mid_rows(const lcpc_ctx* c, uint64_t n_rows) {
   return (n_rows + batches - 1) / batches;
 }
 
-// The nine shifted multiples W_j = balanced(w 2^(29 j) mod p), j < 9, of a field element w (Montgomery form in), as the 81 words
-// t = 9 k + j = limb k of W_j (limbs 0..7 in [0, 2^29), limb 8 signed) that field_wmul_gen.h's wmul_u takes as scalar operands.
-static void wmul_table(const FieldDesc& f, const uint64_t* w_mont, uint32_t out[96]) {
+// The N shifted multiples W_j = balanced(w 2^(W j) mod p), j < N, of a field element w (Montgomery form in), as the N^2 words
+// t = N k + j = limb k of W_j (limbs 0..N-2 in [0, 2^W), the top limb signed) that field_wmul_gen.h's wmul_u* take as scalar operands
+// (Ft255: N = 9, W = 29; field_ln.h's forms for the other fields).
+static void wmul_table(const FieldDesc& f, const uint64_t* w_mont, int N, int W, uint32_t out[96]) {
   uint64_t v[MAXL];
   h_canon(f, v, w_mont);
   memset(out, 0, 96 * 4);
-  for (int j = 0; j < 9; j++) {
+  for (int j = 0; j < N; j++) {
     // v > (p - 1) / 2 -> v - p, as a 320-bit two's complement number
-    uint64_t m[5] = {v[0], v[1], v[2], v[3], 0};
+    uint64_t m[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < f.L; i++) m[i] = v[i];
     bool big = false;
-    for (int i = 3; i >= 0; i--) {
-      const uint64_t h = (f.p[i] >> 1) | (i < 3 ? f.p[i + 1] << 63 : 0);
+    for (int i = f.L - 1; i >= 0; i--) {
+      const uint64_t h = (f.p[i] >> 1) | (i + 1 < f.L ? f.p[i + 1] << 63 : 0);
       if (v[i] != h) { big = v[i] > h; break; }
     }
     if (big) {
       unsigned __int128 br = 0;
-      for (int i = 0; i < 5; i++) { const unsigned __int128 d = (unsigned __int128)m[i] - (i < 4 ? f.p[i] : 0) - (uint64_t)br; m[i] = (uint64_t)d; br = (d >> 64) & 1; }
+      for (int i = 0; i < 5; i++) { const unsigned __int128 d = (unsigned __int128)m[i] - (i < f.L ? f.p[i] : 0) - (uint64_t)br; m[i] = (uint64_t)d; br = (d >> 64) & 1; }
     }
-    for (int k = 0; k < 9; k++) {
-      const int b = 29 * k, wd = b / 64, sh = b % 64;
+    for (int k = 0; k < N; k++) {
+      const int b = W * k, wd = b / 64, sh = b % 64;
       uint64_t x = m[wd] >> sh;
-      if (sh > 35) x |= m[wd + 1] << (64 - sh);
-      out[9 * k + j] = k < 8 ? (uint32_t)(x & ((1u << 29) - 1)) : (uint32_t)x;
+      if (sh && wd + 1 < 5) x |= m[wd + 1] << (64 - sh);
+      out[N * k + j] = k < N - 1 ? (uint32_t)(x & (((uint64_t)1 << W) - 1)) : (uint32_t)x;
     }
-    for (int s = 0; s < 29; s++) h_add(f, v, v, v);         // (h_add works on fully reduced values of either form)
+    for (int s = 0; s < W; s++) h_add(f, v, v, v);          // (h_add works on fully reduced values of either form)
   }
+}
+// w^(n/4) = ROOT_OF_UNITY^(2^(S - 2)): the primitive 4th root I of the field -- the last two stages of every transform multiply by it,
+// and so does every radix-4 butterfly of the limb kernels (w1 = I w0: ntt_l9s.hip) -- as its shifted multiples on the device
+static int build_wq_w(lcpc_ctx* c, int N, int W) {
+  const FieldDesc* f = c->f;
+  uint64_t i4[MAXL];
+  memcpy(i4, f->rou, 8 * f->L);
+  for (unsigned i = 0; i + 2 < f->S; i++) h_mul(*f, i4, i4, i4);
+  uint32_t wt[96];
+  wmul_table(*f, i4, N, W, wt);
+  int rc = dev_alloc(&c->err, &c->d_wq_w, sizeof wt);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpy(c->d_wq_w, wt, sizeof wt, hipMemcpyHostToDevice));
+  return 0;
 }
 
 // ---- NTT pass plan (DESIGN.md "K1") ----------------------------------------------------------------
@@ -233,7 +249,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       NttPassArgs a{};
       a.dst = j.dst;
       a.src = first ? j.src : j.dst;
-      a.roots = c->d_roots; a.qp29 = c->d_qpl;
+      a.roots = c->d_roots; a.qp29 = c->d_qpl; a.wq_w = c->d_wq_w;
       a.roots29 = sub ? c->d_rootsls : c->d_rootsl;
       a.roots29c = j.canon_out ? (sub ? c->d_rootslcs : c->d_rootslc) : nullptr;
       a.canon_row_mask = sub ? (1u << s0) - 1 : 0u;
@@ -259,7 +275,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       NttPassArgs a{};
       a.src = first ? j.src : j.dst;
       a.dst = j.dst;
-      a.roots = c->d_roots; a.roots29 = c->d_rootsl; a.qp29 = c->d_qpl;
+      a.roots = c->d_roots; a.roots29 = c->d_rootsl; a.qp29 = c->d_qpl; a.wq_w = c->d_wq_w;
       a.roots29c = j.canon_out ? c->d_rootslc : nullptr;
       a.mont_prefix = (j.canon_out && !first) ? 4u : 0u;       // the last pass ends with a radix-4 round (10 stages)
       a.src_stride = first ? j.src_stride : c->n_cols;
@@ -288,6 +304,7 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.roots = c->d_roots;
       a.roots29 = c->d_roots29;
       a.qp29 = c->d_qp29;
+      a.wq_w = c->d_wq_w;
       a.src_stride = first ? j.src_stride : c->n_cols;
       a.dst_stride = c->n_cols;
       a.n_valid = first ? j.n_valid : c->n_cols;
@@ -536,14 +553,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       }
       if ((rc = dev_alloc(err, &c->d_qp29, tab.size() * 4))) return rc;
       HIPCHK(c, hipMemcpy(c->d_qp29, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
-      // w^(n/4) = ROOT_OF_UNITY^(2^(S - 2)): the primitive 4th root the last two stages of every transform multiply by
-      uint64_t i4[MAXL];
-      memcpy(i4, f->rou, 8 * f->L);
-      for (unsigned i = 0; i + 2 < f->S; i++) h_mul(*f, i4, i4, i4);
-      uint32_t wt[96];
-      wmul_table(*f, i4, wt);
-      if ((rc = dev_alloc(err, &c->d_wq_w, sizeof wt))) return rc;
-      HIPCHK(c, hipMemcpy(c->d_wq_w, wt, sizeof wt, hipMemcpyHostToDevice));
+      if ((rc = build_wq_w(c, 9, 29))) return rc;
       c->comm_canon = true;
     }
     if ((rc = dev_alloc(err, &c->d_r2, 8 * f->L))) return rc;
@@ -663,6 +673,7 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
         if (he == hipSuccess) he = hipDeviceSynchronize();
         dev_free(d_rp); dev_free(d_rpc);
         if (he != hipSuccess) return fail_hip(err, he, "ntt_lns tables");
+        if (!c->d_wq_w && (rc_ = build_wq_w(c, N, W))) return rc_;
         if (lns3) {
           const size_t n_sub = (size_t)1 << 19;
           if ((rc_ = dev_alloc(err, &c->d_rootsls, n_sub * stride * 4)) || (rc_ = dev_alloc(err, &c->d_rootslcs, n_sub * stride * 4))) return rc_;
@@ -688,8 +699,8 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
       const int brc = build();
       if (brc == LCPC_ERR_NOMEM) {
         for (auto& pk : c->d_pack) { dev_free(pk); pk = nullptr; }
-        dev_free(c->d_rootsl); dev_free(c->d_rootslc); dev_free(c->d_qpl); dev_free(c->d_rootsls); dev_free(c->d_rootslcs);
-        c->d_rootsl = c->d_rootslc = c->d_qpl = c->d_rootsls = c->d_rootslcs = nullptr;
+        dev_free(c->d_rootsl); dev_free(c->d_rootslc); dev_free(c->d_qpl); dev_free(c->d_rootsls); dev_free(c->d_rootslcs); dev_free(c->d_wq_w);
+        c->d_rootsl = c->d_rootslc = c->d_qpl = c->d_rootsls = c->d_rootslcs = c->d_wq_w = nullptr;
         c->passes = general_plan;
         (void)hipGetLastError();
         err->clear();

@@ -151,6 +151,18 @@ template <class FT> LCPC_DEV LN<FT::N> mul(const LN<FT::N>& a, const LN<FT::N>& 
   else ln_mul1s_ft191(a.v, w.v, r.v);
   return r;
 }
+// a * w mod p for a wave-uniform w given as its N shifted multiples W_j = balanced(w 2^(W j) mod p) (N^2 words t = N k + j, host:
+// ctx.cpp wmul_table; field_wmul_gen.h).  a: limbs of a normalised value or of a difference of two (sum |limb| < N 2^W).  Result:
+// normalised, in (-2.5p, 1.6p) (gen_wmul_asm.py wmul_bounds).  Ft127: 50 instructions against mul()'s 64, Ft191: 80 against 118.
+// Ft63 has no such form: at 3 limbs the Montgomery multiply (22 instructions) is the shorter one (28).
+template <class FT> constexpr bool has_mul_u = FT::N >= 5;
+template <class FT> LCPC_DEV LN<FT::N> mul_u(const LN<FT::N>& a, const u32* wt) {
+  static_assert(has_mul_u<FT>, "no shifted-multiples multiply for this field");
+  LN<FT::N> r;
+  if constexpr (FT::FID == FT127) wmul_u_ft127(a.v, wt, r.v);
+  else wmul_u_ft191(a.v, wt, r.v);
+  return r;
+}
 // ---- carry-free lazy dot product (Brakedown SpMM for Ft127 / Ft191): field_dev.h's lazy29_* for N limbs of W bits ------
 // acc += x * v with x, v as N unsigned W-bit limbs (x: a packed element < p split by from_packed; v: a matrix value in the
 // R'-Montgomery form, v R' mod p): N^2 v_mad_u64_u32 into 2N u64 columns, no carries.  A column receives <= N products

@@ -244,6 +244,13 @@ __global__ void __launch_bounds__(BS) ntt_pass_kernel(NttPassArgs a) {
 // per row), reduced explicitly at the store.  comm then holds canonical values (LcCommit.coeffs, copied from the
 // loads, stays in Montgomery form); the hash kernel reads them as they are.
 // -------------------------------------------------------------------------------------------------
+// m == ~0: -x, m == 0: x, limb-wise (per-lane choice without a select)
+__device__ __forceinline__ L9 l9_neg_if(const L9& x, u32 m) {
+  L9 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = (x.v[i] ^ m) - m;
+  return r;
+}
 template <int LT>
 __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
   constexpr int NL = 8;
@@ -295,6 +302,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
     // first round of a zero-padded row (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x * w)
     const bool zero_hi = (t == 0) && !last_two && a.n_valid <= (1ull << (k - 1));
     const bool zero_3q = zero_hi && a.n_valid <= (1ull << (k - 2));
+    const u32 half_mask = (1u << (k - 1)) - 1;                  // the tables hold w^i, i < n / 2
     for (u32 q = tid; q < T / 4; q += 256) {
       const u32 lp = q & lp_mask;
       const u32 j = (q >> lbt) & (i_mask >> 2);
@@ -302,33 +310,29 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
       const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
       const u32 e0 = (((hp << s) | i0) << lbt) | lp;
       const u32 dq = 1u << (hb - 1 + lbt);
-      const u32 g0 = gindex(e0), g1 = gindex(e0 + dq);
+      const u32 g0 = gindex(e0);
       if (zero_hi) {
         // inputs straight from the loads: value < p.  Everything is block 0 here, so with canonical output the
         // multiplies out of block 0 (w0, w1, and w2 for c1) take the converting table
         const u32* tc = canon ? a.roots29c : a.roots29;
-        const Tw<NL> w0 = tw_load29(tc, g0 & gm0);
-        const Tw<NL> w2c = tw_load29(tc, (g0 & gm1) << 1);
-        const Tw<NL> w2 = tw_load<NL>(a, (g0 & gm1) << 1);
+        const u32 ex = g0 & gm0;                               // < n / 4; w0 = w^ex, w2 = w^(2 ex), w3 = w^(3 ex) = -w^(3 ex - n/2) past n/2
+        const Tw<NL> w0 = tw_load29(tc, ex), w2 = tw_load29(tc, 2 * ex), w3 = tw_load29(tc, (3 * ex) & half_mask);
+        const u32 ng = 3 * ex > half_mask ? ~0u : 0u;
         if (zero_3q) {           // rate <= 1/4: x1 is zero too; c0 = x0 stays where it is, three multiplies
           const L9 x0 = lds9_get<LT>(lds, e0);
-          lds9_put<LT>(lds, e0 + dq, l9::mul(x0, w2c.w));
-          const L9 b2 = l9::mul(x0, w0.w);
-          lds9_put<LT>(lds, e0 + 2 * dq, b2);
-          lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(b2, w2.w));
+          lds9_put<LT>(lds, e0 + dq, l9::mul(x0, w2.w));
+          lds9_put<LT>(lds, e0 + 2 * dq, l9::mul(x0, w0.w));
+          lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9_neg_if(x0, ng), w3.w));
           continue;
         }
-        const Tw<NL> w1 = tw_load29(tc, g1 & gm0);
         const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
         L9 c0 = l9::add(x0, x1);                                                           // [0, 2p)
         l9::normalize(c0);
         lds9_put<LT>(lds, e0, c0);
-        lds9_put<LT>(lds, e0 + dq, l9::mul(l9::sub(x0, x1), w2c.w));
-        const L9 b2 = l9::mul(x0, w0.w), b3 = l9::mul(x1, w1.w);                           // (-1.2p, 0.2p]
-        L9 c2 = l9::add(b2, b3);
-        l9::normalize(c2);
-        lds9_put<LT>(lds, e0 + 2 * dq, c2);
-        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2.w));
+        lds9_put<LT>(lds, e0 + dq, l9::mul(l9::sub(x0, x1), w2.w));
+        const L9 tI = l9::mul_u(x1, a.wq_w);                                               // x1 I (ntt_l9s.hip: the true radix-4 form)
+        lds9_put<LT>(lds, e0 + 2 * dq, l9::mul(l9::add(x0, tI), w0.w));
+        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9_neg_if(l9::sub(x0, tI), ng), w3.w));
         continue;
       }
       const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
@@ -338,10 +342,9 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
       l9::normalize(c0);
       if (last_two) {
         // stages k-2, k-1: twiddles 1, w^(n/4), 1 -- outputs go straight to the store path (normalised, |value| < 16p)
-        const Tw<NL> wq = tw_load<NL>(a, 1u << (k - 2));
         L9 c1 = l9::sub(b0, b1);                                                           // |value| < 16p
         const L9 b2 = l9::sub(x0, x2);                                                     // limbs (-2^29, 2^29), |value| < 8p
-        const L9 b3 = l9::mul(l9::sub(x1, x3), wq.w);                                      // normalised, (-1.2p, 0.2p]
+        const L9 b3 = l9::mul_u(l9::sub(x1, x3), a.wq_w);                                  // normalised, (-2.2p, 1.5p)
         L9 c2 = l9::add(b2, b3);                                                           // |value| < 9.2p
         L9 c3 = l9::sub(b2, b3);                                                           // |value| < 9.2p
         l9::normalize(c1); l9::normalize(c2); l9::normalize(c3);
@@ -354,22 +357,18 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
         // leave block 0 take the converting table; c0 stays a pure sum; c3's inputs b2, b3 are already canonical
         const bool blk0c = canon && g0 <= gm1;
         const u32* t01 = blk0c ? a.roots29c : a.roots29;
-        const Tw<NL> w0 = tw_load29(t01, (g0 & gm0) << t);
-        const Tw<NL> w1 = tw_load29(t01, (g1 & gm0) << t);
-        const Tw<NL> w2 = tw_load<NL>(a, (g0 & gm1) << (t + 1));
+        // true radix-4 (ntt_l9s.hip): w1 = I w0, so t = (x1 - x3) I by the shifted-multiples multiply on the one constant every
+        // lane shares, c2 = ((x0 - x2) + t) w0, c3 = ((x0 - x2) - t) w^(3 ex); past n/2 the table entry is the negated twiddle
+        const u32 ex = (g0 & gm0) << t;
+        const Tw<NL> w0 = tw_load29(t01, ex), w2 = tw_load29(t01, 2 * ex), w3 = tw_load29(t01, (3 * ex) & half_mask);
+        const u32 ng = 3 * ex > half_mask ? ~0u : 0u;
         l9::clamp(c0, qp);                                                                 // [0, 1.01p)
         lds9_put<LT>(lds, e0, c0);
-        const L9 d1 = l9::sub(b0, b1);                                                     // limbs (-2^30, 2^30), |value| < 16p
-        L9 c1;
-        if (blk0c) c1 = l9::mul(d1, tw_load29(a.roots29c, (g0 & gm1) << (t + 1)).w);
-        else c1 = l9::mul(d1, w2.w);
-        lds9_put<LT>(lds, e0 + dq, c1);                                                    // normalised, (-1.2p, 0.2p]
-        const L9 b2 = l9::mul(l9::sub(x0, x2), w0.w);                                      // in: |value| < 8p
-        const L9 b3 = l9::mul(l9::sub(x1, x3), w1.w);
-        L9 c2 = l9::add(b2, b3);                                                           // (-2.4p, 0.4p]
-        l9::normalize(c2);
-        lds9_put<LT>(lds, e0 + 2 * dq, c2);
-        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9::sub(b2, b3), w2.w));
+        lds9_put<LT>(lds, e0 + dq, l9::mul(l9::sub(b0, b1), w2.w));                        // normalised, (-1.2p, 0.2p]
+        const L9 tI = l9::mul_u(l9::sub(x1, x3), a.wq_w);                                  // normalised, (-2.2p, 1.5p)
+        const L9 e2 = l9::sub(x0, x2);                                                     // limbs (-2^29, 2^29), |value| < 8p
+        lds9_put<LT>(lds, e0 + 2 * dq, l9::mul(l9::add(e2, tI), w0.w));
+        lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9_neg_if(l9::sub(e2, tI), ng), w3.w));
       }
     }
     __syncthreads();

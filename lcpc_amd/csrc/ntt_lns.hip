@@ -13,6 +13,10 @@
 //     reads comm as it is (its per-element Montgomery reduction was 16-28 % of the leaf kernel for these fields);
 //   * the first pass stores values in [0, p + 64 B) < 2^(32 NL) without the final conditional subtract, the last pass
 //     subtracts under a wave-level __any (Ft63 / Ft127: most waves; Ft191: rarely).
+// The radix-4 butterfly is K1s's true radix-4 form (ntt_l9s.hip, head comment): w1 = I w0 with I = w^(n/4) the field's fixed 4th
+// root of unity, so t = (x1 - x3) I, c2 = ((x0 - x2) + t) w0, c3 = ((x0 - x2) - t) w^(3e): three lane-varying multiplies and one by a
+// constant every lane shares -- the shifted-multiples multiply with scalar operands for Ft127 / Ft191 (ln::mul_u), the ordinary
+// one on a broadcast table entry for Ft63, whose 3-limb Montgomery multiply is the shorter of the two.
 // Exact modular arithmetic: any stage grouping gives the same fully-reduced bits as the reference's radix-2 loop.
 // The general kernel (kernels.hip ntt_pass_kernel) remains for one-pass rows, three-pass plans and as the A/B reference
 // (LCPC_NTT_GENERAL=1; tests/test_gpu_ntt_shapes.py).
@@ -63,6 +67,12 @@ template <class FT> LCPC_DEV LN<FT::N> tab_entry(const u32* tab, u32 idx) {
 #pragma unroll
   for (int k = 0; k < FT::N; k++) t.v[k] = tab[(size_t)idx * FT::STRIDE + k];
   return t;
+}
+
+// x * I, I = w^(n/4): a.wq_w = its shifted multiples (ctx.cpp build_wq_w); Ft63: the table entry w^(n/4) R' itself (wave-uniform load)
+template <class FT> LCPC_DEV LN<FT::N> mul_i(const LN<FT::N>& x, const NttPassArgs& a) {
+  if constexpr (ln::has_mul_u<FT>) return ln::mul_u<FT>(x, a.wq_w);
+  else return ln::mul<FT>(x, tab_entry<FT>(a.roots29, 1u << (a.log_n - 2)));
 }
 
 // round structure of a pass with S stages on tiles of 2^S x 2^LBT slots (as in ntt_l9s.hip)
@@ -171,28 +181,24 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
     const u32* blk = cls_pack + pi.round_off[SH::U0 + r];
     if (u == 0 && zero_hi) {
       // zero-padded first round (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x w); inputs < 4p; everything
-      // is block 0, so with canonical output the multiplies leaving it (w0, w1, and w2 for c1) take the converting set
+      // is block 0, so with canonical output the three multiplies leaving it (w0, w3, and w2 for c1) take the converting set
       const u32 vb = canon ? 3u : 0u;
-      const E w0 = planes_get<FT>(blk, 6 * period, (vb + 0) * period + jl), w2c = planes_get<FT>(blk, 6 * period, (vb + 2) * period + jl);
-      const E w2 = planes_get<FT>(blk, 6 * period, 2 * period + jl);
+      const E w0 = planes_get<FT>(blk, 6 * period, (vb + 0) * period + jl), w2 = planes_get<FT>(blk, 6 * period, (vb + 2) * period + jl);
+      const E w3 = planes_get<FT>(blk, 6 * period, (vb + 1) * period + jl);
       if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
         const E x0 = planes_get<FT>(lds, T, e0);
-        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(x0, w2c));
-        const E b2 = ln::mul<FT>(x0, w0);
-        planes_put<FT>(lds, T, e0 + 2 * dq, b2);
-        planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(b2, w2));
+        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(x0, w2));
+        planes_put<FT>(lds, T, e0 + 2 * dq, ln::mul<FT>(x0, w0));
+        planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(x0, w3));
       } else {
-        const E w1 = planes_get<FT>(blk, 6 * period, (vb + 1) * period + jl);
         const E x0 = planes_get<FT>(lds, T, e0), x1 = planes_get<FT>(lds, T, e0 + dq);
         E c0 = ln::add(x0, x1);
         ln::normalize<FT>(c0);
         planes_put<FT>(lds, T, e0, c0);
-        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(x0, x1), w2c));
-        const E b2 = ln::mul<FT>(x0, w0), b3 = ln::mul<FT>(x1, w1);                          // (-p - eps, eps]
-        E c2 = ln::add(b2, b3);
-        ln::normalize<FT>(c2);
-        planes_put<FT>(lds, T, e0 + 2 * dq, c2);
-        planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(ln::sub(b2, b3), w2));
+        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(x0, x1), w2));
+        const E t = mul_i<FT>(x1, a);                                                        // x1 I: keeps x1's form; normalised, (-2.5p, 1.6p)
+        planes_put<FT>(lds, T, e0 + 2 * dq, ln::mul<FT>(ln::add(x0, t), w0));
+        planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(ln::sub(x0, t), w3));
       }
       __syncthreads();
       continue;
@@ -206,10 +212,9 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
     planes_put<FT>(lds, T, e0, c0);
     if (last_two) {
       // outputs go straight to the store path (normalised, |value| < 16p)
-      const E wq = tab_entry<FT>(a.roots29, 1u << (k - 2));                                       // wave-uniform
       E c1 = ln::sub(b0, b1);
       const E b2 = ln::sub(x0, x2);
-      const E b3 = ln::mul<FT>(ln::sub(x1, x3), wq);
+      const E b3 = mul_i<FT>(ln::sub(x1, x3), a);                                                 // w^(n/4): the one twiddle every lane shares
       E c2 = ln::add(b2, b3);
       E c3 = ln::sub(b2, b3);
       ln::normalize<FT>(c1); ln::normalize<FT>(c2); ln::normalize<FT>(c3);
@@ -218,21 +223,17 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
       planes_put<FT>(lds, T, e0 + 3 * dq, c3);
     } else {
       // block 0 of stages (u, u + 1) = the quads whose elements all lie below n / 2^(t + 2): exactly q < period in the tiles
-      // that hold block 0.  Their three multiplies that leave block 0 take the converting set; c0 stays a pure sum; c3's
-      // inputs b2, b3 are already canonical
+      // that hold block 0.  Their three multiplies that leave block 0 (c1, c2, c3) take the converting set; c0 stays a pure sum;
+      // t = (x1 - x3) I is by a plain constant and stays in the form of its inputs
       const bool blk0c = canon && blk0_tile && q < period;
       const u32 vb = blk0c ? 3u : 0u;
-      // (c1's twiddle is fetched on its own: the one select instead of two live twiddle sets keeps Ft191 inside 96 VGPRs)
-      const E w2c1 = planes_get<FT>(blk, 6 * period, (blk0c ? 5u : 2u) * period + jl);
-      planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(b0, b1), w2c1));                        // in: |value| < 16p
-      const E w0 = planes_get<FT>(blk, 6 * period, (vb + 0) * period + jl), w1 = planes_get<FT>(blk, 6 * period, (vb + 1) * period + jl);
-      const E w2 = planes_get<FT>(blk, 6 * period, 2 * period + jl);
-      const E b2 = ln::mul<FT>(ln::sub(x0, x2), w0);                                              // in: |value| < 8p
-      const E b3 = ln::mul<FT>(ln::sub(x1, x3), w1);
-      E c2 = ln::add(b2, b3);                                                                     // (-2p - 2 eps, 2 eps]
-      ln::normalize<FT>(c2);
-      planes_put<FT>(lds, T, e0 + 2 * dq, c2);
-      planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(ln::sub(b2, b3), w2));
+      const E w2 = planes_get<FT>(blk, 6 * period, (vb + 2) * period + jl);
+      planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(b0, b1), w2));                          // in: |value| < 16p
+      const E t = mul_i<FT>(ln::sub(x1, x3), a);                                                  // normalised, (-2.5p, 1.6p)
+      const E e2 = ln::sub(x0, x2);                                                               // limbs (-2^W, 2^W), |value| < 8p
+      const E w0 = planes_get<FT>(blk, 6 * period, (vb + 0) * period + jl), w3 = planes_get<FT>(blk, 6 * period, (vb + 1) * period + jl);
+      planes_put<FT>(lds, T, e0 + 2 * dq, ln::mul<FT>(ln::add(e2, t), w0));                       // in: limbs (-2^W, 2^(W+1)), |value| < 10.5p
+      planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(ln::sub(e2, t), w3));
     }
     __syncthreads();
   }
@@ -286,13 +287,28 @@ __global__ void __launch_bounds__(256) ntt_lns_pack_kernel(NttPassArgs a, NttPac
     const u32 r = slot - SH::U0, u = SH::U0 + 2 * r, hb = S - u - 1, period = 1u << (hb - 1 + LBT);
     const u32 t = t0 + u;
     if (jl >= period || t + 2 == k) continue;                // (stages k-2, k-1: one wave-uniform twiddle, not packed)
-    const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
+    const u32 gm0 = (1u << (k - t - 1)) - 1;
     const u32 lp = jl & ((1u << LBT) - 1), j = jl >> LBT;
     const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
     const u32 g0 = (i0 << lb) | lo | lp;                     // (last pass: the tile's high bits do not reach these twiddles)
-    const u32 g1 = g0 + (1u << (hb - 1 + lb));
-    const u32 idx[3] = {(g0 & gm0) << t, (g1 & gm0) << t, (g0 & gm1) << (t + 1)};
-    for (u32 v = 0; v < 6; v++) planes_put<FT>(blk, 6 * period, v * period + jl, tab_entry<FT>(v < 3 ? a.roots29 : a.roots29c, idx[v % 3]));
+    // w0 = w^e, w3 = w^(3 e), w2 = w^(2 e), e = (g0 & gm0) << t < n / 4; the tables hold w^i for i < n / 2 and w^(n/2) = -1: past
+    // that, the negated entry (ntt_l9s.hip ntt_pack_kernel)
+    const u32 ex = (g0 & gm0) << t, half_n = 1u << (k - 1);
+    const u32 idx[3] = {ex, 3 * ex, 2 * ex};
+    for (u32 v = 0; v < 6; v++) {
+      const u32 ix = idx[v % 3];
+      LN<FT::N> m = tab_entry<FT>(v < 3 ? a.roots29 : a.roots29c, ix & (half_n - 1));
+      if (ix >= half_n) {                                    // p - entry, limb-wise with borrow (entry in (0, p))
+        int32_t br = 0;
+#pragma unroll
+        for (int z = 0; z < FT::N; z++) {
+          const int32_t d = (int32_t)FT::limb(z) - (int32_t)m.v[z] - br;
+          br = d < 0 ? 1 : 0;
+          m.v[z] = z + 1 < FT::N ? (u32)d & ((1u << FT::W) - 1) : (u32)d;
+        }
+      }
+      planes_put<FT>(blk, 6 * period, v * period + jl, m);
+    }
   }
 }
 
@@ -300,7 +316,7 @@ template <class FT, int S, int LBT> NttPackInfo pack_info_t() {
   using SH = Shape<S, LBT>;
   NttPackInfo pi{};
   u32 off = 0, slot = 0;
-  // radix-2 slot: variants (plain, converting); radix-4 slots: w0, w1, w2 plain, then the same from the converting table
+  // radix-2 slot: variants (plain, converting); radix-4 slots: w0, w3 = w0 w2, w2 plain, then the same from the converting table
   if (SH::U0) { pi.round_off[slot++] = off; off += 2 * SH::period2 * FT::N; off = (off + 3) & ~3u; }
   for (int r = 0; r < SH::NR4; r++) { pi.round_off[slot++] = off; off += 6 * SH::period4(r) * FT::N; off = (off + 3) & ~3u; }
   pi.class_words = off;
