@@ -135,16 +135,179 @@ def host_memory_available():
     return avail
 
 
-def cpu_commit(O, coeffs, n_per_row, n_cols, threads):
+def cpu_commit(O, coeffs, n_per_row, n_cols, threads, keep=False):
     """one oracle commit (C port of the reference algorithm, OpenMP over rows / 32-column blocks) of `coeffs` (Ft255 Montgomery
-    limbs on the host) with the headline row shape; returns (rate, seconds, root)."""
+    limbs on the host) with the headline row shape; returns (rate, seconds, root[, the oracle's encoding and commitment])."""
     enc = O.Encoding.ligero_from_dims(3, n_per_row, n_cols)
     t0 = time.perf_counter()
     c = O.Commit.commit(coeffs, enc, n_threads=threads)
     dt = time.perf_counter() - t0
     root = c.get_root()
+    if keep:
+        return len(coeffs) / dt, dt, root, enc, c
     del c
     return len(coeffs) / dt, dt, root
+
+
+C5_X = 0x123456789abcdef        # the evaluation point of the C5 leg (outer = powers of x^n_per_row, inner = powers of x: ligero tests.rs:120-128)
+
+
+FT255_P = 0x663c799b6e4d2900fda9df04b9575969ef73c79086595f3002a4f20000000001      # lcpc-test-fields/src/lib.rs:50-58
+
+
+def powers_mont(x, n, step=1):
+    """[x^(k step)] for k < n in Ft255 as ff_derive's Montgomery limbs (value * 2^256 mod p, 4 little-endian u64), shape (n, 4)"""
+    import numpy as np
+    base, cur, out = pow(x, step, FT255_P), 1, np.zeros((n, 4), np.uint64)
+    for k in range(n):
+        m = (cur << 256) % FT255_P
+        out[k] = [(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+        cur = cur * base % FT255_P
+    return out
+
+
+def mk_transcript(T, root, n_col_opens):
+    """the reference's test transcript (lcpc-ligero-pc/src/tests.rs:243-245)"""
+    tr = T(b"test transcript")
+    tr.append_message(b"polycommit", bytes(root))
+    tr.append_message(b"ncols", int(n_col_opens).to_bytes(8, "big"))
+    return tr
+
+
+def commit_bytes_8d(F, n_rows, n_per_row, n_cols):
+    """SURVEY.md 8(d) B_commit: read coeffs + write comm + read comm for the column hash + write / re-read the digests"""
+    np2 = 1
+    while np2 < n_cols:
+        np2 *= 2
+    return F * n_rows * n_per_row + 2 * F * n_rows * n_cols + 32 * (2 * np2 - 1) + 32 * (2 * np2 - 2)
+
+
+def time_commits(torch, LcCommit, enc, dev_coeffs, n, stream, reps=12):
+    """>= 10 back-to-back commits of a device-resident vector into ONE LcCommit object, a HIP event after each on the launch stream:
+    (mean ms, min ms, reps, the object -- holding the last commit)"""
+    c = LcCommit(enc)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.05:           # clocks up, buffers allocated
+        for _ in range(3):
+            LcCommit.commit_device(dev_coeffs.data_ptr(), n, enc, stream, sync=False, into=c)
+        torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    evs[0].record()
+    for i in range(reps):
+        LcCommit.commit_device(dev_coeffs.data_ptr(), n, enc, stream, sync=False, into=c)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(reps)]
+    return sum(ms) / reps, min(ms), reps, c
+
+
+def hip_configs(torch, lcpc_amd, coeffs, n_total, enc, cm, step, stream, device):
+    """BASELINE.json's other configs on this GPU, untimed region of an N = 1 run: C1, C2, C3 commits and C5's prove /
+    verify, each >= 10 repetitions with mean and min, on inputs that the cpu_baseline leg re-commits / re-proves with the oracle
+    (`checked` stays false until it has).  C2 / C3 commit the first 2^24 elements of the job's own vector, C5 proves the job's commitment.
+    Returns (public dict, private dict of the HIP results the oracle leg compares)."""
+    import numpy as np
+    from lcpc_amd import LcCommit, LigeroEncoding, SdigEncoding, Transcript
+    pub, priv = {}, {}
+    # ---- C1: lcpc-ligero-pc commit over ft63, 2^16 coeffs
+    n1 = 1 << 16
+    e1 = LigeroEncoding.new(lcpc_amd.FT63, n1, device=device)
+    x1 = e1.random_coeffs_device(n1, seed=INPUT_SEED)
+    mean, mn, reps, c1 = time_commits(torch, LcCommit, e1, x1, n1, stream, reps=40)
+    b = commit_bytes_8d(8, c1.n_rows, c1.n_per_row, c1.n_cols)
+    pub["C1"] = {"workload": "lcpc-ligero-pc commit, Ft63, 2^16 coeffs, rho=1/2, BLAKE3", "dims": [c1.n_rows, c1.n_per_row, c1.n_cols], "ms": round(mean, 4),
+                 "min_ms": round(mn, 4), "reps": reps, "algorithmic_GBps": round(b / (mean * 1e-3) / 1e9, 1), "checked": False}
+    priv["C1"] = (c1.get_root(), x1.cpu().numpy())
+    del c1, e1, x1
+    # ---- C2: lcpc-ligero-pc commit, 2^24 coeffs, Ft255
+    n2 = 1 << 24
+    if n_total >= n2:
+        e2 = LigeroEncoding.new(lcpc_amd.FT255, n2, device=device)
+        mean, mn, reps, c2 = time_commits(torch, LcCommit, e2, coeffs, n2, stream)
+        b = commit_bytes_8d(32, c2.n_rows, c2.n_per_row, c2.n_cols)
+        pub["C2"] = {"workload": "lcpc-ligero-pc commit, Ft255, 2^24 coeffs, rho=1/2, BLAKE3", "dims": [c2.n_rows, c2.n_per_row, c2.n_cols], "ms": round(mean, 4),
+                     "min_ms": round(mn, 4), "reps": reps, "algorithmic_GBps": round(b / (mean * 1e-3) / 1e9, 1), "checked": False,
+                     "input": "the first 2^24 elements of the job's vector"}
+        priv["C2"] = (c2.get_root(), (c2.n_per_row, c2.n_cols))
+        del c2, e2
+        # ---- C3: lcpc-brakedown-pc commit, 2^24 coeffs, Ft255 (SdigCode3, seed 0); the encoder is built outside the timed commits
+        t0 = time.perf_counter()
+        e3 = SdigEncoding.new(lcpc_amd.FT255, n2, 0, device=device)
+        t_build = time.perf_counter() - t0
+        mean, mn, reps, c3 = time_commits(torch, LcCommit, e3, coeffs, n2, stream)
+        b = commit_bytes_8d(32, c3.n_rows, c3.n_per_row, c3.n_cols)
+        pub["C3"] = {"workload": "lcpc-brakedown-pc commit, Ft255, 2^24 coeffs, SdigCode3 seed 0, BLAKE3", "dims": [c3.n_rows, c3.n_per_row, c3.n_cols],
+                     "ms": round(mean, 4), "min_ms": round(mn, 4), "reps": reps, "algorithmic_GBps": round(b / (mean * 1e-3) / 1e9, 1), "checked": False,
+                     "encoder_build_s": round(t_build, 3), "input": "the first 2^24 elements of the job's vector"}
+        priv["C3"] = (c3.get_root(), (c3.n_per_row, c3.n_cols))
+        del c3, e3
+    torch.cuda.empty_cache()
+    # ---- C5: prove + verify on the job's own commitment (the headline's 2^26): eval_outer random linear combination + column openings
+    root = step(sync=True).get_root()
+    nr, npr = cm.n_rows, cm.n_per_row
+    inner = powers_mont(C5_X, npr)
+    outer = powers_mont(C5_X, nr, npr)
+    n_open = enc.get_n_col_opens()
+    tp, tv, pf = [], [], None
+    for rep in range(11):                        # rep 0 = first use (allocations, helper threads): not counted
+        step(sync=True)                          # prove follows commit in the reference's flow (tests.rs:243-262): the GPU is at working clocks
+        t0 = time.perf_counter()
+        pf = cm.prove(outer, enc, mk_transcript(Transcript, root, n_open))
+        t1 = time.perf_counter()
+        ev = pf.verify(root, outer, inner, enc, mk_transcript(Transcript, root, n_open))
+        t2 = time.perf_counter()
+        if rep:
+            tp.append((t1 - t0) * 1e3)
+            tv.append((t2 - t1) * 1e3)
+    b = 32 * nr * npr + n_open * nr * 32
+    data = pf.to_bytes()
+    pub["C5"] = {"workload": "lcpc-2d prove + verify, Ft255, 2^%d coeffs (the job's commitment), %d column openings" % (n_total.bit_length() - 1, n_open),
+                 "prove": {"ms": round(sum(tp) / len(tp), 3), "min_ms": round(min(tp), 3), "reps": len(tp), "algorithmic_GBps": round(b / (sum(tp) / len(tp) * 1e-3) / 1e9, 1),
+                           "note": "wall time of LcCommit::prove incl. the host transcript (2 x n_per_row serial STROBE absorbs, lcpc-2d/src/lib.rs:1045-1047)"},
+                 "verify": {"ms": round(sum(tv) / len(tv), 3), "min_ms": round(min(tv), 3), "reps": len(tv)},
+                 "proof_bytes": len(data), "checked": False}
+    priv["C5"] = (data, root, outer, inner, np.asarray(ev))
+    return pub, priv
+
+
+def check_configs(O, pub, priv, cpu_coeffs, threads, oenc26, oc26):
+    """the oracle side of hip_configs: roots of C1-C3 on the same inputs, C5's proof bytes == the oracle PROVER's on the oracle's
+    commitment of the timed vector and the oracle VERIFIER accepts the HIP proof with the same evaluation.  Any difference ends the run."""
+    import numpy as np
+    if "C1" in priv:
+        root, x = priv["C1"]
+        want = O.random_elems(0, 1 << 16, INPUT_SEED)
+        if not (x.view(np.uint64).reshape(want.shape) == want).all():
+            raise SystemExit("bench.py configs: C1's device-drawn Ft63 coefficients differ from the oracle's stream")
+        if O.Commit.commit(want, O.Encoding.ligero(0, 1 << 16)).get_root() != root:
+            raise SystemExit("bench.py configs: C1 HIP root != oracle root")
+        pub["C1"]["checked"] = True
+    if "C2" in priv and len(cpu_coeffs) >= (1 << 24):
+        root, (npr, nc) = priv["C2"]
+        if O.Commit.commit(cpu_coeffs[:1 << 24], O.Encoding.ligero_from_dims(3, npr, nc), n_threads=threads).get_root() != root:
+            raise SystemExit("bench.py configs: C2 HIP root != oracle root")
+        pub["C2"]["checked"] = True
+    if "C3" in priv and len(cpu_coeffs) >= (1 << 24):
+        root, (npr, nc) = priv["C3"]
+        if O.Commit.commit(cpu_coeffs[:1 << 24], O.Encoding.sdig_from_dims(3, npr, nc, 0, 3), n_threads=threads).get_root() != root:
+            raise SystemExit("bench.py configs: C3 HIP root != oracle root")
+        pub["C3"]["checked"] = True
+    if "C5" in priv and oc26 is not None:
+        data, root, outer, inner, ev = priv["C5"]
+        if oc26.get_root() != root:
+            raise SystemExit("bench.py configs: C5 the oracle's commitment has another root")
+        n_open = oenc26.get_n_col_opens()
+        opf, _ = oc26.prove(outer, oenc26, mk_transcript(O.Transcript, root, n_open))
+        if opf != data:
+            raise SystemExit("bench.py configs: C5 HIP proof bytes != the oracle prover's")
+        rc, oev = O.verify(oenc26, root, outer, inner, data, mk_transcript(O.Transcript, root, n_open))
+        if rc != 0 or not (np.asarray(oev) == ev).all():
+            raise SystemExit("bench.py configs: C5 the oracle verifier rejects the HIP proof (rc %d) or returns another evaluation" % rc)
+        pub["C5"]["checked"] = True
+    for k, v in pub.items():
+        v["check"] = ("root == the oracle's root of the same coefficients" if k != "C5" else
+                      "proof bytes == the oracle prover's on its own commitment of the timed vector; oracle verifier accepts with the same evaluation") \
+            if v["checked"] else "NOT checked in this run (no oracle leg, or the CPU sample was shorter than the input)"
 
 
 def self_launch(args):
@@ -188,6 +351,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power-sample", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the untimed `configs` legs (C1, C2, C3, C5 of BASELINE.json, N = 1 only)")
     ap.add_argument("--lean", action="store_true", help="the timed loop and the instrumented step only (what tools/profile_round.sh wraps in "
                     "rocprofv3, so that per-kernel averages are not diluted by the secondary legs)")
     ap.add_argument("--cpu-sample-log-len", type=int, default=None, help="default: the full 2^log-len if host memory allows, else one less")
@@ -208,7 +372,7 @@ def main():
         return self_launch(args)
 
     if args.lean:
-        args.no_cpu_baseline = args.no_power_sample = args.no_e2e = True
+        args.no_cpu_baseline = args.no_power_sample = args.no_e2e = args.no_configs = True
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
     import torch
     import torch.distributed as dist
@@ -456,6 +620,18 @@ def main():
                 valu_issue = {"wave_insts_per_launch": round(sum(insts) / len(insts)), "achieved_Ginst_per_s": round(per_s / 1e9, 1),
                               "peak_Ginst_per_s": 614.4, "frac": round(per_s / 614.4e9, 3),
                               "source": "SQ_INSTS_VALU, profiles/pmc_latest.json (same stamp)"}
+                # the ceiling of THIS instruction mix (tools/isa_mix.py: disassembly classes x their measured issue cost), at the
+                # clock the board holds while the commit loops (filled in below, once rocm-smi has been sampled)
+                mix_path = os.path.join(ROOT, "profiles", "valu_mix_latest.json")
+                if os.path.exists(mix_path):
+                    mix = json.load(open(mix_path))
+                    if mix.get("kernel_stamp") == stamp:
+                        valu_issue["mix"] = {"mean_cost_cycles": mix["mean_cost_cycles"], "ubench_clock_GHz": mix["ubench_clock_GHz"],
+                                             "by_class": {k: v["by_class"] for k, v in mix["kernels"].items()},
+                                             "source": "profiles/valu_mix_latest.json (tools/isa_mix.py, same stamp): static class counts x profiles/r06_ubench_mix.txt"}
+                        valu_issue["weighted_peak_Ginst_per_s"] = mix["weighted_peak_Ginst_per_s_at_ubench_clock"]
+                        valu_issue["frac_weighted"] = round(per_s / 1e9 / mix["weighted_peak_Ginst_per_s_at_ubench_clock"], 3)
+                        valu_issue["weighted_at"] = "the microbenchmark's clock (%.2f GHz)" % mix["ubench_clock_GHz"]
             if per:         # the NTT passes are separate kernel instantiations, one launch each per commit: mean per launch
                 traffic = round(sum(per) / len(per), 3)
                 traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc, kernel stamp %s; GB per launch = 2*FETCH_SIZE + WRITE_SIZE, mean over the %d NTT passes)" % (stamp, len(per))
@@ -583,6 +759,13 @@ def main():
                                 else "copied into the LcCommit (as LcCommit::commit does, lcpc-2d/src/lib.rs:636-645)"},
            "roofline": roofline}
     roofline["power"] = power
+    if power and valu_issue and "mix" in valu_issue:
+        # one number for the remaining headroom: the mix-weighted issue peak at the clock sampled while this very commit loops
+        ghz = power["sclk_MHz"] / 1e3
+        wp = valu_issue["weighted_peak_Ginst_per_s"] * ghz / valu_issue["mix"]["ubench_clock_GHz"]
+        valu_issue["weighted_peak_Ginst_per_s"] = round(wp, 1)
+        valu_issue["frac_weighted"] = round(valu_issue["achieved_Ginst_per_s"] / wp, 3)
+        valu_issue["weighted_at"] = "the sampled clock (%.3f GHz)" % ghz
     if other_mode is not None:
         out["other_coeffs_mode"] = other_mode
     if e2e is not None:
@@ -598,6 +781,11 @@ def main():
                          "DEBUG: ranks share devices (--dist-backend %s%s)" % (args.dist_backend, "" if args.force_device is None else ", --force-device %d" % args.force_device)
     if distributed and exchange_note:
         out["exchange_fallback"] = exchange_note
+
+    cfg_pub, cfg_priv = None, {}
+    if world == 1 and not args.no_configs:
+        cfg_pub, cfg_priv = hip_configs(torch, lcpc_amd, coeffs, n_coeffs_job, enc, cm, step, stream, local_rank)
+        out["configs"] = cfg_pub
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -616,11 +804,14 @@ def main():
         same = bool((torch.from_numpy(cpu_coeffs.view(np.int64)) == coeffs[:1 << lg].cpu()).all())
         if not same:
             raise SystemExit("bench.py: the device-drawn coefficients differ from the oracle's Field::random stream")
-        v, secs, root_cpu = cpu_commit(O, cpu_coeffs, n_per_row, n_cols, threads)
+        v, secs, root_cpu, oenc26, oc26 = cpu_commit(O, cpu_coeffs, n_per_row, n_cols, threads, keep=True)
         # the HIP root of the same data: at the full length it is the root the timed loop itself produced
         root_gpu = LcCommit.commit_device(coeffs.data_ptr(), 1 << lg, enc, stream, sync=True, into=cm).get_root()
         if root_gpu != root_cpu:
             raise SystemExit("bench.py: HIP root != oracle root on the timed coefficients (2^%d): %s vs %s" % (lg, root_gpu.hex(), root_cpu.hex()))
+        if cfg_pub is not None:
+            check_configs(O, cfg_pub, cfg_priv, cpu_coeffs, threads, oenc26, oc26 if lg == args.log_len else None)
+        del oc26, oenc26
         lg1 = max(lg - 4, 17)
         v1, secs1, _ = cpu_commit(O, cpu_coeffs[:1 << lg1], n_per_row, n_cols, 1)
         del cpu_coeffs
@@ -634,6 +825,8 @@ def main():
                                          "shape (%d x %d -> %d), %.1f s wall (+ %.1f s drawing them); the coefficients are the TIMED vector%s, "
                                          "checked element for element against the device copy, and the HIP commit of it gives the same root"
                                          % (lg, (1 << lg) // n_per_row, n_per_row, n_cols, secs, t_gen, "" if lg == args.log_len else "'s first 2^%d elements" % lg)}
+    if cfg_pub is not None and args.no_cpu_baseline:
+        check_configs(None, cfg_pub, {}, [], 0, None, None)
     if rank == 0:
         print(json.dumps(out))
     if distributed:

@@ -86,7 +86,7 @@ def test_bench_n1_json_contract():
     """the N = 1 line the driver records: one JSON object carrying the metric, `roofline` (bound / achieved / peak / frac with
     frac == achieved / peak, per-launch algorithmic bytes and launch time) and `cpu_baseline` (value, cores, kind, sample, and
     the same coefficients' root through the HIP path == the CPU port's root)"""
-    r = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--log-len", "22", "--no-power-sample"])
+    r = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--log-len", "24", "--no-power-sample"])
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -96,10 +96,10 @@ def test_bench_n1_json_contract():
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True and out["vs_baseline"] is None
     assert out["unit"] == "field-elements/s" and out["data"] == "synthetic"
-    assert abs(out["value"] - (1 << 22) / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
+    assert abs(out["value"] - (1 << 24) / (out["ms_per_step"] * 1e-3)) <= 1e-6 * out["value"]
     cfg = out["config"]
-    assert "lcpc-ligero-pc commit" in cfg["workload"] and "Ft255" in cfg["workload"] and "2^22" in cfg["workload"] and "model" not in cfg
-    assert cfg["n_rows"] * cfg["n_per_row"] == 1 << 22 and cfg["n_cols"] == 2 * cfg["n_per_row"]
+    assert "lcpc-ligero-pc commit" in cfg["workload"] and "Ft255" in cfg["workload"] and "2^24" in cfg["workload"] and "model" not in cfg
+    assert cfg["n_rows"] * cfg["n_per_row"] == 1 << 24 and cfg["n_cols"] == 2 * cfg["n_per_row"]
     rf = out["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_GB_per_launch", "avg_launch_ms"):
         assert k in rf, k
@@ -116,6 +116,18 @@ def test_bench_n1_json_contract():
     e2e = out["e2e_host"]
     assert e2e["root_matches_device_commit"] is True and e2e["staged_slices"] == 0
     assert e2e["pageable"]["root_matches_device_commit"] is True and e2e["pageable"]["staged_slices"] > 0 and e2e["pageable"]["vs_pinned"] > 0
+    # BASELINE.json's other configs, timed on this box in the untimed region and checked against the oracle on the timed inputs
+    cf = out["configs"]
+    assert set(cf) == {"C1", "C2", "C3", "C5"}
+    for k in ("C1", "C2", "C3"):
+        c = cf[k]
+        assert c["checked"] is True and c["reps"] >= 10 and 0 < c["min_ms"] <= c["ms"] and c["algorithmic_GBps"] > 0, (k, c)
+    assert cf["C1"]["dims"] == [32, 2048, 4096] and cf["C2"]["dims"] == [256, 65536, 131072] and cf["C3"]["dims"] == [101, 166292, 252931]
+    assert "brakedown" in cf["C3"]["workload"] and cf["C3"]["encoder_build_s"] > 0
+    c5 = cf["C5"]
+    assert c5["checked"] is True and "oracle verifier accepts" in c5["check"]
+    for k in ("prove", "verify"):
+        assert c5[k]["reps"] >= 10 and 0 < c5[k]["min_ms"] <= c5[k]["ms"]
 
 
 @pytest.mark.gpu

@@ -96,6 +96,24 @@ KERNEL(k_dpp_ror, DECL8, asm volatile("v_mov_b32_dpp %0, %8 row_ror:1 row_mask:0
 KERNEL(k_bpermute, DECL8; u32 idx = ((threadIdx.x + 9) & 63) * 4, asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)\n"
      : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(idx)), a0^a1^a2^a3^a4^a5^a6^a7)
 
+// round 6: the forms the generated multipliers actually use -- one accumulator (a dependent chain), an SGPR multiplicand, a VOP2 with
+// a 32-bit literal (the limb mask), the plain VOP2 / VOP1 ops of the carry passes
+KERNEL(k_mad_i64_dep, u64 a0=x,
+  asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %2, %1, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %2, %1, %0\n"
+               "v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %2, %1, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %2, %1, %0\n"
+     : "+v"(a0) : "v"(x),"v"(y) : "vcc"),
+  (u32)(a0))
+KERNEL(k_mad_i64_sgpr, u64 a0=x; u32 sv = seed * 2654435761u + 12345u,
+  asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %3, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %3, %2, %0\n"
+               "v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %3, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %3, %2, %0\n"
+     : "+v"(a0) : "v"(x),"s"(sv),"v"(y) : "vcc"),
+  (u32)(a0))
+KERNEL(k_and_lit, DECL8, asm volatile("v_and_b32 %0, 0x1fffffff, %0\n v_and_b32 %1, 0x1fffffff, %1\n v_and_b32 %2, 0x1fffffff, %2\n v_and_b32 %3, 0x1fffffff, %3\n v_and_b32 %4, 0x1fffffff, %4\n v_and_b32 %5, 0x1fffffff, %5\n v_and_b32 %6, 0x1fffffff, %6\n v_and_b32 %7, 0x1fffffff, %7\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7)), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_sub_u32, DECL8, OP8("v_sub_u32"), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_ashrrev_i32, DECL8, asm volatile("v_ashrrev_i32 %0, 3, %0\n v_ashrrev_i32 %1, 3, %1\n v_ashrrev_i32 %2, 3, %2\n v_ashrrev_i32 %3, 3, %3\n v_ashrrev_i32 %4, 3, %4\n v_ashrrev_i32 %5, 3, %5\n v_ashrrev_i32 %6, 3, %6\n v_ashrrev_i32 %7, 3, %7\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7)), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_mov_b32, DECL8, asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7)), a0^a1^a2^a3^a4^a5^a6^a7)
+KERNEL(k_add_lit, DECL8, asm volatile("v_add_u32 %0, 0x12345678, %0\n v_add_u32 %1, 0x12345678, %1\n v_add_u32 %2, 0x12345678, %2\n v_add_u32 %3, 0x12345678, %3\n v_add_u32 %4, 0x12345678, %4\n v_add_u32 %5, 0x12345678, %5\n v_add_u32 %6, 0x12345678, %6\n v_add_u32 %7, 0x12345678, %7\n" : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7)), a0^a1^a2^a3^a4^a5^a6^a7)
+
 template <typename K> static double run(K kern, const char* name, int ops_per_body, int waves_per_simd, u32* d){
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
   int blocks = 256 * waves_per_simd;   // 256 CUs x (waves_per_simd) blocks of 256 threads = 4 waves => waves/SIMD
@@ -108,9 +126,19 @@ template <typename K> static double run(K kern, const char* name, int ops_per_bo
   printf("%-22s waves/SIMD=%d  %8.3f ms  %8.2f Tlane-op/s  (%.2f cyc/wave-instr/SIMD @2.4GHz)\n", name, waves_per_simd, best, rate/1e12, 2.4e9*1024*64/rate);
   return rate;
 }
-int main(){
+int main(int argc, char** argv){
   u32* d; CHECK(hipMalloc(&d, 256*8*256*4));
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p,0)); printf("device %s CUs=%d clock=%d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
+  if (argc > 1 && argv[1][0] == 'm') {      // "mix": the round-6 additions beside their round-2 neighbours, 4 waves per SIMD (the NTT kernels' occupancy)
+    const int w = 4;
+    for (int rep = 0; rep < 2; rep++) {
+      run(k_mad_i64_i32,"v_mad_i64_i32",8,w,d); run(k_mad_i64_dep,"v_mad_i64_i32 dep",8,w,d); run(k_mad_i64_sgpr,"v_mad_i64_i32 dep sgpr",8,w,d);
+      run(k_and_b32,"v_and_b32",8,w,d); run(k_and_lit,"v_and_b32 literal",8,w,d); run(k_add_u32,"v_add_u32",8,w,d); run(k_add_lit,"v_add_u32 literal",8,w,d);
+      run(k_sub_u32,"v_sub_u32",8,w,d); run(k_ashrrev_i32,"v_ashrrev_i32",8,w,d); run(k_mov_b32,"v_mov_b32",8,w,d);
+      run(k_ashrrev_i64,"v_ashrrev_i64",8,w,d); run(k_add3_u32,"v_add3_u32",8,w,d); run(k_addc_chain,"v_addc_co_u32 chain",8,w,d);
+    }
+    return 0;
+  }
   for(int w : {1,2,4}){
     run(k_mad_u64_u32,"v_mad_u64_u32",8,w,d); run(k_mad_addc,"mad_u64+addc (pairs)",4,w,d); run(k_mad_dep,"v_mad_u64_u32 dep",8,w,d);
     run(k_mul_lo_u32,"v_mul_lo_u32",8,w,d); run(k_mul_hi_u32,"v_mul_hi_u32",8,w,d);
