@@ -192,31 +192,54 @@ static uint32_t collapse_splits(const lcpc_commit_t* m) {
 size_t collapse_scratch_bytes(const lcpc_commit_t* m, uint32_t n_tensors) {
   return (size_t)collapse_splits(m) * n_tensors * m->enc->n_per_row * elem_bytes(m->enc);
 }
-static int collapse_local(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_out) {
+// one launch (+ the sum over row splits) for the column range [j0, j1) of n_tensors polynomials; d_out = the polynomials' array
+// ([n_tensors][n_per_row] elements); `a` arrives with coeffs / tensors / tensors29 / n_rows / n_per_row / n_tensors filled in.  A range
+// narrower than the whole polynomial (prove's first slice) takes only one tensor and splits its rows further, so that it still fills
+// the chip: the partials never exceed the reserved collapse_scratch_bytes(m, 2)
+static int collapse_range(lcpc_commit_t* m, CollapseArgs a, uint64_t j0, uint64_t j1, hipStream_t st, uint32_t* d_out) {
   const lcpc_ctx* c = m->enc;
-  const uint32_t n_splits = collapse_splits(m);
-  CollapseArgs a{};
-  a.coeffs = m->coeffs_view; a.tensors = d_tensors; a.n_rows = m->n_rows_local; a.n_per_row = c->n_per_row;
-  a.n_tensors = n_tensors; a.n_splits = n_splits;
+  const uint64_t len = j1 - j0;
+  uint32_t n_splits = collapse_splits(m);
+  const bool whole = len == c->n_per_row;
+  if (!whole) {
+    if (a.n_tensors != 1) return LCPC_ERR_ARG;
+    while (n_splits < 64 && ((len + 255) / 256) * n_splits < 2048 && m->n_rows_local / (n_splits * 2) >= 8) n_splits *= 2;
+    while (n_splits > 1 && (uint64_t)n_splits * len > (uint64_t)collapse_splits(m) * 2 * c->n_per_row) n_splits /= 2;
+  }
+  a.n_splits = n_splits; a.j0 = j0; a.j1 = j1;
+  if (n_splits == 1) {
+    a.out = d_out + j0 * c->NL; a.out_stride = c->n_per_row;
+    HIPCHK(m, launch_collapse(c->NL, a, st));
+    return 0;
+  }
+  const size_t part_bytes = (size_t)n_splits * a.n_tensors * len * elem_bytes(c);
+  // partials live at the end of scratch (callers reserve it; scratch_cap is a multiple of 256, part_bytes of 16)
+  uint32_t* d_part = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(m->d_scratch) + m->scratch_cap - ((part_bytes + 255) & ~(size_t)255));
+  a.out = d_part; a.out_stride = len;
+  HIPCHK(m, launch_collapse(c->NL, a, st));
+  // (whole: flat over [n_tensors][n_per_row]; a range: one tensor, its outputs start at element j0)
+  HIPCHK(m, launch_field_sum(c->NL, d_part, n_splits, (uint64_t)a.n_tensors * len, d_out + j0 * c->NL, st));
+  return 0;
+}
+static int collapse_prepare(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, CollapseArgs* a) {
+  const lcpc_ctx* c = m->enc;
+  *a = CollapseArgs{};
+  a->coeffs = m->coeffs_view; a->tensors = d_tensors; a->n_rows = m->n_rows_local; a->n_per_row = c->n_per_row;
+  a->n_tensors = n_tensors;
   if (c->NL == 8) {
     const uint64_t ne = (uint64_t)n_tensors * m->n_rows_local;
     int rc = ensure_dev(&m->err, &m->d_t29, &m->t29_cap, ne * 48);
     if (rc) return rc;
     HIPCHK(m, launch_to_r29(d_tensors, ne, m->d_t29, st));
-    a.tensors29 = m->d_t29;
+    a->tensors29 = m->d_t29;
   }
-  if (n_splits == 1) {
-    a.out = d_out;
-    HIPCHK(m, launch_collapse(c->NL, a, st));
-    return 0;
-  }
-  const size_t part_bytes = (size_t)n_splits * n_tensors * c->n_per_row * elem_bytes(c);
-  // partials live at the end of scratch (callers reserve it; scratch_cap is a multiple of 256, part_bytes of 16)
-  uint32_t* d_part = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(m->d_scratch) + m->scratch_cap - ((part_bytes + 255) & ~(size_t)255));
-  a.out = d_part;
-  HIPCHK(m, launch_collapse(c->NL, a, st));
-  HIPCHK(m, launch_field_sum(c->NL, d_part, n_splits, (uint64_t)n_tensors * c->n_per_row, d_out, st));
   return 0;
+}
+static int collapse_local(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_out) {
+  CollapseArgs a;
+  int rc = collapse_prepare(m, d_tensors, n_tensors, st, &a);
+  if (rc) return rc;
+  return collapse_range(m, a, 0, m->enc->n_per_row, st, d_out);
 }
 // scratch layout for collapse: [tensors (host entry only)] [polys (host entry only)] ... [partials at the end]
 int collapse_run(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_polys) {
@@ -254,6 +277,52 @@ int collapse_host(lcpc_commit_t* m, const uint64_t* tensors, uint32_t n_tensors,
   HIPCHK(m, hipMemcpyAsync(polys, d_p, pbytes, hipMemcpyDeviceToHost, nullptr));
   if (polys_canon) HIPCHK(m, hipMemcpyAsync(polys_canon, d_pc, pbytes, hipMemcpyDeviceToHost, nullptr));
   HIPCHK(m, hipStreamSynchronize(nullptr));
+  return 0;
+}
+
+// collapse_columns of ONE tensor for the prover, enqueued without waiting and delivered in two column ranges -- [0, cut) and
+// [cut, n_per_row), cut = *cut_out -- each followed by its device-to-host copies (Montgomery form and canonical values) and an event:
+// the transcript absorbs the first range (lib.rs:1045-1047 is serial, ~50 ns per coefficient) while the second is still being
+// computed, so that of the collapse only the first eighth stays on the prover's critical path.  The caller waits for ev[0] / ev[1]
+// (collapse_wait_slice); everything is on the null stream, so later work of this commitment queues up behind it.
+int collapse_host_sliced(lcpc_commit_t* m, const uint64_t* tensor, uint64_t* polys, uint64_t* polys_canon, uint64_t* cut_out) {
+  if (!m || !tensor || !polys || !polys_canon || !cut_out) return LCPC_ERR_ARG;
+  if (!m->committed) return LCPC_ERR_STATE;
+  const lcpc_ctx* c = m->enc;
+  std::lock_guard<std::mutex> g(m->mu);
+  HIPCHK(m, hipSetDevice(c->prm.device));
+  const size_t eb = elem_bytes(c);
+  const uint64_t np = c->n_per_row;
+  const uint64_t cut = ((np / 8) + 255) & ~(uint64_t)255;
+  if (cut == 0 || cut >= np) return LCPC_ERR_ARG;
+  const size_t tb = ((size_t)m->n_rows_local * eb + 255) & ~(size_t)255;
+  const size_t pb = ((size_t)np * eb + 255) & ~(size_t)255;
+  int rc = ensure_scratch(m, tb + 2 * pb + collapse_scratch_bytes(m, 2) + 512);
+  if (rc) return rc;
+  for (auto& e : m->ev_slice)
+    if (!e) HIPCHK(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  uint8_t* base = reinterpret_cast<uint8_t*>(m->d_scratch);
+  uint32_t* d_t = reinterpret_cast<uint32_t*>(base);
+  uint32_t* d_p = reinterpret_cast<uint32_t*>(base + tb);
+  uint32_t* d_pc = reinterpret_cast<uint32_t*>(base + tb + pb);
+  if ((rc = order_after_commit(m, nullptr))) return rc;
+  HIPCHK(m, hipMemcpyAsync(d_t, tensor, (size_t)m->n_rows_local * eb, hipMemcpyHostToDevice, nullptr));
+  CollapseArgs a;
+  if ((rc = collapse_prepare(m, d_t, 1, nullptr, &a))) return rc;
+  const uint64_t lim[3] = {0, cut, np};
+  for (int s = 0; s < 2; s++) {
+    const uint64_t j0 = lim[s], len = lim[s + 1] - lim[s];
+    if ((rc = collapse_range(m, a, j0, j0 + len, nullptr, d_p))) return rc;
+    HIPCHK(m, launch_to_canon(c->NL, d_p + j0 * c->NL, len, d_pc + j0 * c->NL, nullptr));
+    HIPCHK(m, hipMemcpyAsync(reinterpret_cast<uint8_t*>(polys_canon) + j0 * eb, reinterpret_cast<uint8_t*>(d_pc) + j0 * eb, len * eb, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(m, hipMemcpyAsync(reinterpret_cast<uint8_t*>(polys) + j0 * eb, reinterpret_cast<uint8_t*>(d_p) + j0 * eb, len * eb, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(m, hipEventRecord(m->ev_slice[s], nullptr));
+  }
+  *cut_out = cut;
+  return 0;
+}
+int collapse_wait_slice(lcpc_commit_t* m, int s) {
+  HIPCHK(m, hipEventSynchronize(m->ev_slice[s]));
   return 0;
 }
 
@@ -344,6 +413,7 @@ void lcpc_commit_destroy(lcpc_commit_t* m) {
   dev_free(m->d_t29); dev_free(m->ws.d_tmp); dev_free(m->ws.d_t); dev_free(m->ws.d_mid); dev_free(m->d_gather); dev_free(m->d_xsend); dev_free(m->d_xrecv);
   for (auto& e : m->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : m->ev_batch) if (e) (void)hipEventDestroy(e);
+  for (auto& e : m->ev_slice) if (e) (void)hipEventDestroy(e);
   if (m->h_pin) (void)hipHostFree(m->h_pin);
   if (m->h_root) (void)hipHostFree(m->h_root);
   if (m->s_prove) (void)hipStreamDestroy(m->s_prove);

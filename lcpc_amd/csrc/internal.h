@@ -182,6 +182,7 @@ struct lcpc_commit_s {
   bool shard_encoded = false;      // split phases: the encode step of a sharded commit has been enqueued, hash / finish / merkle may follow
   hipStream_t s_copy = nullptr, s_comp = nullptr;   // lcpc_commit (host pointer): H2D of row batch b+1 overlaps the NTTs of batch b
   hipEvent_t ev_batch[16] = {nullptr};
+  hipEvent_t ev_slice[2] = {nullptr, nullptr};   // prove: arrival of the two column ranges of p_random on the host (collapse_host_sliced)
   lcpc_timings last{};
   uint32_t launches[3] = {0, 0, 0};
   std::string err;
@@ -276,6 +277,8 @@ int finish_timing(lcpc_commit_t* m, hipStream_t st);
 int collapse_run(lcpc_commit_t* m, const uint32_t* d_tensors, uint32_t n_tensors, hipStream_t st, uint32_t* d_polys);
 size_t collapse_scratch_bytes(const lcpc_commit_t* m, uint32_t n_tensors);
 int collapse_host(lcpc_commit_t* m, const uint64_t* tensors, uint32_t n_tensors, uint64_t* polys, uint64_t* polys_canon);
+int collapse_host_sliced(lcpc_commit_t* m, const uint64_t* tensor, uint64_t* polys, uint64_t* polys_canon, uint64_t* cut_out);
+int collapse_wait_slice(lcpc_commit_t* m, int s);
 // open_column values / paths into device buffers (either may be null)
 int open_columns_host(lcpc_commit_t* m, const uint64_t* cols, uint32_t n, uint64_t* col_vals, size_t vals_pitch, uint8_t* paths);
 int ensure_pinned(lcpc_commit_t* m, uint64_t bytes);

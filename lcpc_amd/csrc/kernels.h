@@ -111,6 +111,9 @@ struct CollapseArgs {
   uint32_t* out;               // n_splits == 1: polys [n_tensors][n_per_row]; else partial [n_splits][n_tensors][n_per_row]
   uint64_t n_rows, n_per_row;
   uint32_t n_tensors, n_splits;
+  // column range [j0, j1) of this launch (j1 == 0: all of them) and the element stride between the output rows: a range's outputs sit
+  // at out + ((split * n_tensors + tensor) * out_stride + (j - j0)) elements (prove collapses p_random in two ranges: commit.cpp)
+  uint64_t j0 = 0, j1 = 0, out_stride = 0;
 };
 hipError_t launch_collapse(int nl, const CollapseArgs& a, hipStream_t st);
 // Ft255 tensors (Montgomery) -> the 29-bit-limb / 2^261 form used by the lazy dot-product kernels

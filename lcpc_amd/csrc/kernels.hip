@@ -858,8 +858,8 @@ hipError_t launch_merkle_tree_from(u32* hashes, u64 np2, u32 levels_done, hipStr
 // =================================================================================================
 template <int NL, int NT>
 __global__ void __launch_bounds__(256) collapse_kernel(CollapseArgs a) {
-  const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (j >= a.n_per_row) return;
+  const u64 j = a.j0 + (u64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.j1) return;
   const u32 z = blockIdx.y;
   const u64 rows_per = (a.n_rows + a.n_splits - 1) / a.n_splits;
   const u64 r0 = (u64)z * rows_per;
@@ -885,14 +885,14 @@ __global__ void __launch_bounds__(256) collapse_kernel(CollapseArgs a) {
     for (int t = 0; t < NT; t++) acc[t] = fe_add<NL>(acc[t], wide_reduce<NL>(w[t]));
   }
 #pragma unroll
-  for (int t = 0; t < NT; t++) fe_store<NL>(a.out + (((u64)z * NT + t) * a.n_per_row + j) * NL, acc[t]);
+  for (int t = 0; t < NT; t++) fe_store<NL>(a.out + (((u64)z * NT + t) * a.out_stride + (j - a.j0)) * NL, acc[t]);
 }
 // Ft255: carry-free lazy dot products (lazy29_mac); the tensor entry is wave-uniform, so its nine 29-bit limbs
 // (pre-converted to the 2^261 form, a.tensors29) are scalar operands of the 81 v_mad_u64_u32 per term.
 template <int NT>
 __global__ void __launch_bounds__(256) collapse29_kernel(CollapseArgs a) {
-  const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (j >= a.n_per_row) return;
+  const u64 j = a.j0 + (u64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.j1) return;
   const u32 z = blockIdx.y;
   const u64 rows_per = (a.n_rows + a.n_splits - 1) / a.n_splits;
   const u64 r0 = (u64)z * rows_per;
@@ -929,7 +929,7 @@ __global__ void __launch_bounds__(256) collapse29_kernel(CollapseArgs a) {
     for (int t = 0; t < NT; t++) acc[t] = fe_add<8>(acc[t], lazy29_reduce(w[t]));
   }
 #pragma unroll
-  for (int t = 0; t < NT; t++) fe_store<8>(a.out + (((u64)z * NT + t) * a.n_per_row + j) * 8, acc[t]);
+  for (int t = 0; t < NT; t++) fe_store<8>(a.out + (((u64)z * NT + t) * a.out_stride + (j - a.j0)) * 8, acc[t]);
 }
 // tensors (Montgomery, R = 2^256) -> 9 x 29-bit limbs of t * 2^261 mod p, 12-word stride
 __global__ void __launch_bounds__(256) to_r29_kernel(const u32* in, u64 n, u32* out) {
@@ -951,7 +951,7 @@ hipError_t launch_to_r29(const u32* in, u64 n, u32* out, hipStream_t st) {
 
 template <int NL>
 static hipError_t launch_collapse_t(const CollapseArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)((a.n_per_row + 255) / 256), a.n_splits);
+  dim3 grid((unsigned)((a.j1 - a.j0 + 255) / 256), a.n_splits);
   switch (a.n_tensors) {
     case 1: hipLaunchKernelGGL((collapse_kernel<NL, 1>), grid, dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL((collapse_kernel<NL, 2>), grid, dim3(256), 0, st, a); break;
@@ -959,9 +959,13 @@ static hipError_t launch_collapse_t(const CollapseArgs& a, hipStream_t st) {
   }
   return hipGetLastError();
 }
-hipError_t launch_collapse(int nl, const CollapseArgs& a, hipStream_t st) {
+hipError_t launch_collapse(int nl, const CollapseArgs& a_in, hipStream_t st) {
+  CollapseArgs a = a_in;
+  if (a.j1 == 0) { a.j0 = 0; a.j1 = a.n_per_row; }            // the whole polynomial
+  if (a.out_stride == 0) a.out_stride = a.n_per_row;
+  if (a.j1 > a.n_per_row || a.j0 >= a.j1) return hipErrorInvalidValue;
   if (nl == 8 && a.tensors29 != nullptr) {
-    dim3 grid((unsigned)((a.n_per_row + 255) / 256), a.n_splits);
+    dim3 grid((unsigned)((a.j1 - a.j0 + 255) / 256), a.n_splits);
     switch (a.n_tensors) {
       case 1: hipLaunchKernelGGL(collapse29_kernel<1>, grid, dim3(256), 0, st, a); break;
       case 2: hipLaunchKernelGGL(collapse29_kernel<2>, grid, dim3(256), 0, st, a); break;

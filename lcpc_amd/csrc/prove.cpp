@@ -140,24 +140,34 @@ int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_t
     double t0 = now_ms();
     if (filler.joinable()) filler.join();                                     // the arena is about to be overwritten
     if (eval_rc) return eval_rc;
-    int rc = collapse(tensors, nt, polys, canon);
+    // unsharded, one tensor, a polynomial long enough to matter: p_random arrives in two column ranges and the absorb of the first
+    // (serial STROBE, ~50 ns per coefficient) hides the computation of the second (commit.cpp collapse_host_sliced)
+    const bool sliced = xchg == nullptr && nt == 1 && np >= 32768;
+    uint64_t cut = np;
+    int rc = sliced ? collapse_host_sliced(m, tensors, polys, canon, &cut) : collapse(tensors, nt, polys, canon);
     if (rc) return rc;
+    if (sliced && (rc = collapse_wait_slice(m, 0))) return rc;
     t_collapse += now_ms() - t0;
     if (eval_here) have_eval = true;
     if (nt == 2 && n_deg > 1) p_eval_canon.assign(canon + np * L, canon + 2 * np * L);
     // the helper copies this round's polynomial(s) into the proof (and thereby faults the fresh pages in) meanwhile
     filler = std::thread([=, &out, &eval_rc, &p_eval_canon, &collapse] {
       if (eval_beside) {
-        eval_rc = collapse(tensors + nr * L, 1, polys + np * L, canon + np * L);
+        eval_rc = collapse(tensors + nr * L, 1, polys + np * L, canon + np * L);   // (queues up behind p_random's second range)
         if (eval_rc) return;
         if (n_deg > 1) p_eval_canon.assign(canon + np * L, canon + 2 * np * L);
       }
+      if (sliced && (eval_rc = collapse_wait_slice(m, 1))) return;              // all of p_random is on the host before it is copied
       memcpy(out.p + off_rand0 + i * (8 + pbytes), polys, pbytes);
       if (eval_here) memcpy(out.p + off_eval, polys + np * L, pbytes);
       if (i + 1 == n_deg) memset(out.p + head, 0, total - head);              // touch the column area before the copies land in it
     });
     t0 = now_ms();
-    absorb_canon(tr, LBL_PR, f, canon, np);
+    absorb_canon(tr, LBL_PR, f, canon, cut);
+    if (sliced) {
+      if ((rc = collapse_wait_slice(m, 1))) return rc;
+      absorb_canon(tr, LBL_PR, f, canon + cut * L, np - cut);
+    }
     t_absorb += now_ms() - t0;
   }
   tp[1] = now_ms();
