@@ -507,11 +507,14 @@ static void stream_copy(uint8_t* dst, const uint8_t* src, size_t n) {
 }
 
 // bytes of src (host) -> dst (device) on stream st.  Pinned sources: one async copy.  Pageable sources: through the encoder's bounce ring.
-// `total`: bytes of the whole upload this call is a part of (sizes the ring once).  Under c->stage_mu when !pinned.
+// `total`: bytes of the whole upload this call is a part of (sizes the ring once).  The ring is shared by every commitment of the
+// encoder: c->stage_mu is held per call (one row batch), so two commitments uploading at once interleave batch by batch; a buffer
+// is reused only after the copy that last read it has completed (ev_stage), whichever stream that copy was on.
 static int upload_host(lcpc_commit_t* m, void* dst, const void* src, size_t bytes, size_t total, hipStream_t st, bool pinned) {
   lcpc_ctx* c = m->enc;
   if (bytes == 0) return 0;
   if (pinned) { HIPCHK(m, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return 0; }
+  std::lock_guard<std::mutex> sg(c->stage_mu);
   // Slice = what one H2D command moves.  Measured at 2^26 Ft255 (2 GiB; tools/bench_host_path.py, profiles/r05_host_path.jsonl): 8 MiB
   // slices 44.4 ms, 16: 42.3, 32: 41.6-42.0, 64: 41.2 (pinned source 40.7; the runtime's own pageable path 40.6 on pages it has
   // locked before, 44.4 on fresh ones) -- every copy command costs ~15 us of bus idle time, a slice's latency is paid once.
@@ -533,7 +536,13 @@ static int upload_host(lcpc_commit_t* m, void* dst, const void* src, size_t byte
     if (!c->h_stage[k]) {
       // first use: pinning 64 MiB costs ~6 ms -- paid here, buffer by buffer, while the slices already enqueued cross the bus
       // (all four up front put 24 ms in front of an encoder's first pageable commit)
-      HIPCHK(m, hipHostMalloc(reinterpret_cast<void**>(&c->h_stage[k]), slice, hipHostMallocDefault));
+      if (hipHostMalloc(reinterpret_cast<void**>(&c->h_stage[k]), slice, hipHostMallocDefault) != hipSuccess) {
+        // no pinned memory to be had (ulimit -l, a full host): this slice takes the runtime's own pageable path -- slower, not an error
+        (void)hipGetLastError();
+        c->h_stage[k] = nullptr;
+        HIPCHK(m, hipMemcpyAsync(d + off, s + off, len, hipMemcpyHostToDevice, st));
+        continue;
+      }
       if (!c->ev_stage[k]) HIPCHK(m, hipEventCreateWithFlags(&c->ev_stage[k], hipEventDisableTiming));
     }
     HIPCHK(m, hipEventSynchronize(c->ev_stage[k]));                 // the copy that last read this buffer has left it (a fresh event is complete)
@@ -566,11 +575,7 @@ int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uin
                       (c->sw_host_stage > 0 && host_ptr_is_device(coeffs));
   // Small inputs, Brakedown (whole-matrix transposes) and timing runs: one copy, then the resident path.
   if (c->prm.encoding != LCPC_ENC_LIGERO || total_bytes < ((size_t)64 << 20) || n_rows < 16 || m->timing) {
-    {
-      std::unique_lock<std::mutex> sg(c->stage_mu, std::defer_lock);
-      if (!pinned) sg.lock();
-      if ((rc = upload_host(m, m->d_coeffs, coeffs, total_bytes, total_bytes, nullptr, pinned))) return rc;
-    }
+    if ((rc = upload_host(m, m->d_coeffs, coeffs, total_bytes, total_bytes, nullptr, pinned))) return rc;
     if (padded > n_coeffs)
       HIPCHK(m, hipMemsetAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + total_bytes, 0, (size_t)(padded - n_coeffs) * eb, nullptr));
     if (m->timing) HIPCHK(m, hipEventRecord(m->ev[0], nullptr));
@@ -595,8 +600,6 @@ int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uin
   if (padded > n_coeffs)
     HIPCHK(m, hipMemsetAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + total_bytes, 0, (size_t)(padded - n_coeffs) * eb, m->s_copy));
   const uint64_t rows_per = (n_rows + NB - 1) / NB;
-  std::unique_lock<std::mutex> sg(c->stage_mu, std::defer_lock);
-  if (!pinned) sg.lock();                                  // one pageable upload at a time per encoder (they share the ring and the bus)
   for (int b = 0; b < NB; b++) {
     const uint64_t r0 = (uint64_t)b * rows_per;
     if (r0 >= n_rows) break;

@@ -171,8 +171,10 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
     uint64_t rb = ws->mid_failed ? 0 : ntt_mid_rows(c, n_rows);
     if (rb) {
       std::string scratch_err;
-      // (test hook sw_test_fail_mid: an allocation no device can satisfy, so that the real failure path runs)
-      const uint64_t want = c->sw_test_fail_mid ? ((uint64_t)1 << 62) : rb * c->n_cols * 36;
+      uint64_t want = rb * c->n_cols * 36;
+#ifdef LCPC_TEST_HOOKS
+      if (c->sw_test_fail_mid) want = (uint64_t)1 << 62;      // an allocation no device can satisfy, so that the real failure path runs
+#endif
       if (ensure_dev(&scratch_err, &ws->d_mid, &ws->mid_cap, want)) {
         (void)hipGetLastError();           // HIP keeps a failed call's error until it is read: it must not surface at the next launch check
         ws->mid_failed = true; ws->mid_cap = 0; rb = 0;
@@ -599,7 +601,9 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
           a.log_n = i == 0 ? k : 20u; a.t0 = i == 2 ? 10u : 0u; a.s = ps.s; a.log_tj = ps.log_tj;
           c->pack_info[i] = ntt_l9s_pack_info(ps.s, first);
           const uint32_t n_classes = i == 0 ? 1u << (k - 10) : (i == 1 ? 1024u : 1u);
-          if (i == 0 && c->sw_test_fail_3pass) return LCPC_ERR_NOMEM;       // (test hook: the fallback below)
+#ifdef LCPC_TEST_HOOKS
+          if (i == 0 && c->sw_test_fail_3pass) return LCPC_ERR_NOMEM;       // (the fallback below)
+#endif
           if ((r = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return r;
           HIPCHK(c, launch_ntt_l9s_pack(a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
         }
@@ -689,7 +693,9 @@ static int ctx_build(lcpc_ctx* c, const lcpc_params* p) {
           a.log_n = sub ? 20u : k; a.t0 = sub ? (i == 2 ? 10u : 0u) : ps.t0; a.s = ps.s; a.log_tj = ps.log_tj;
           c->pack_info[i] = ntt_lns_pack_info(c->NL, ps.s, first);
           const uint32_t n_classes = !first ? 1u : (sub ? 1024u : 1u << (k - 10));
-          if (lns3 && i == 0 && c->sw_test_fail_3pass) return LCPC_ERR_NOMEM;   // (test hook: the fallback below)
+#ifdef LCPC_TEST_HOOKS
+          if (lns3 && i == 0 && c->sw_test_fail_3pass) return LCPC_ERR_NOMEM;   // (the fallback below)
+#endif
           if ((rc_ = dev_alloc(err, &c->d_pack[i], (size_t)n_classes * c->pack_info[i].class_words * 4))) return rc_;
           HIPCHK(c, launch_ntt_lns_pack(c->NL, a, first, c->pack_info[i], n_classes, c->d_pack[i], nullptr));
         }
@@ -789,10 +795,12 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
   if (const char* ev = getenv("LCPC_NTT_MID_MAX_MB")) c->sw_ntt_mid_max_mb = (int64_t)strtoull(ev, nullptr, 10);
   if (const char* ev = getenv("LCPC_HOST_STAGE")) c->sw_host_stage = (int32_t)strtol(ev, nullptr, 10);
   c->sw_debug_timing = getenv("LCPC_DEBUG_TIMING") != nullptr;
+#ifdef LCPC_TEST_HOOKS   // only in lib/liblcpc_hip_testhooks.so (Makefile): the product neither reads the variable nor contains the branches
   if (const char* ev = getenv("LCPC_TEST_FAIL")) {           // test hook: "3pass", "mid" (comma-separated) -- forced allocation failures
     c->sw_test_fail_3pass = strstr(ev, "3pass") != nullptr;
     c->sw_test_fail_mid = strstr(ev, "mid") != nullptr;
   }
+#endif
   int rc = 0;
   // (row shards begin where a BLAKE3 chunk boundary of the leaf message is also a row boundary: every chunk for Ft63 / Ft127 /
   // Ft255, every third chunk for Ft191 -- shard.cpp shard_chunk_range)
@@ -801,6 +809,16 @@ int lcpc_ctx_create(const lcpc_params* p, lcpc_ctx** out) {
   if (rc) { ctx_unref(c); return rc; }
   c->np2 = next_pow2(c->n_cols);
   c->path_len = (uint32_t)log2_ceil(c->n_cols);
+  if (c->sw_host_stage > 0) {
+    // LCPC_HOST_STAGE=1: every host source goes through the bounce ring -- pin its first two buffers now (~6 ms each), so that the
+    // encoder's first lcpc_commit from pageable memory does not pay for them (the other two are made as they are first used; a failure
+    // here is not an error: upload_host falls back to the runtime's own path for the slices that find no buffer)
+    c->stage_cap = (size_t)64 << 20;
+    for (unsigned k = 0; k < 2; k++) {
+      if (hipHostMalloc(reinterpret_cast<void**>(&c->h_stage[k]), c->stage_cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->h_stage[k] = nullptr; break; }
+      if (hipEventCreateWithFlags(&c->ev_stage[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(c->h_stage[k]); c->h_stage[k] = nullptr; c->ev_stage[k] = nullptr; break; }
+    }
+  }
   *out = c;
   return 0;
   } catch (...) {

@@ -71,8 +71,10 @@ struct lcpc_ctx {
   bool sw_ntt_general = false;     // LCPC_NTT_GENERAL: every Ligero row on the general kernel (K1) instead of the shape-specialised plans
   int64_t sw_ntt_mid_max_mb = -1;  // LCPC_NTT_MID_MAX_MB: -1 = the default rule of ntt_mid_rows
   bool sw_debug_timing = false;    // LCPC_DEBUG_TIMING: phase times of construction / prove / verify on stderr
-  bool sw_test_fail_3pass = false; // LCPC_TEST_FAIL=3pass (test hook): the three-pass plan's tables "do not fit" -> the general kernel's plan
-  bool sw_test_fail_mid = false;   // LCPC_TEST_FAIL=mid (test hook): the K1s limb-intermediate allocation fails -> packed intermediate
+#ifdef LCPC_TEST_HOOKS             // forced allocation failures, compiled only into lib/liblcpc_hip_testhooks.so (the tests' second build of ctx.cpp)
+  bool sw_test_fail_3pass = false; // LCPC_TEST_FAIL=3pass: the three-pass plan's tables "do not fit" -> the general kernel's plan
+  bool sw_test_fail_mid = false;   // LCPC_TEST_FAIL=mid: the K1s limb-intermediate allocation fails -> packed intermediate
+#endif
   const lcpc::FieldDesc* f = nullptr;
   int L = 0, NL = 0;
   uint64_t n_per_row = 0, n_cols = 0, np2 = 0;
@@ -127,7 +129,8 @@ struct lcpc_ctx {
   uint8_t* h_varena = nullptr;
   size_t h_varena_cap = 0;
   // lcpc_commit from PAGEABLE host memory (commit.cpp upload_host): a ring of pinned bounce buffers the host pool fills while
-  // the previous slices cross the bus.  Held (stage_mu) for the whole upload of one commit; kept between commits.
+  // the previous slices cross the bus.  stage_mu is held per upload call (one row batch of one commit); the buffers are kept between commits
+  // (up to 4 x 64 MiB of pinned host memory per encoder that has taken a pageable source; LCPC_HOST_STAGE=1 pins the first two at lcpc_ctx_create).
   std::mutex stage_mu;
   static constexpr unsigned N_STAGE = 4;
   uint8_t* h_stage[N_STAGE] = {nullptr, nullptr, nullptr, nullptr};

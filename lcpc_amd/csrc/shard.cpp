@@ -358,6 +358,9 @@ static int shard_node_table(lcpc_commit_t* m, uint32_t slots_per_rank) {
   const uint32_t G = c->prm.shard_count > 1 ? c->prm.shard_count : 1;
   const uint64_t key = (nch << 24) ^ ((uint64_t)slots_per_rank << 8) ^ G;
   if (m->d_node_tab && m->node_tab_key == key) return 0;
+  // a shape seen before: its table is still there (looked up before anything is rebuilt)
+  for (const auto& t : m->node_tabs)
+    if (t.key == key) { m->d_node_tab = t.d; m->node_tab_key = key; m->node_slot_h = t.slot; m->node_log_h = t.lg; return 0; }
   std::vector<uint32_t> slot, lgs;
   uint32_t extra = G;
   for (uint32_t r = 0; r < G; r++) {
@@ -374,10 +377,15 @@ static int shard_node_table(lcpc_commit_t* m, uint32_t slots_per_rank) {
   }
   const uint32_t nn = (uint32_t)slot.size();
   // A table that a finish step still in flight (any stream) may be reading is never freed or overwritten: a new shape gets a NEW
-  // table (a few dozen bytes), the old ones live until the object goes (an object sees one or two shapes).  The blocking copy
-  // below writes memory nothing on the device refers to yet.
-  for (const auto& t : m->node_tabs)
-    if (t.key == key) { m->d_node_tab = t.d; m->node_tab_key = key; m->node_slot_h = t.slot; m->node_log_h = t.lg; return 0; }
+  // table (a few dozen bytes); an object sees one or two shapes.  One that keeps meeting new ones holds at most MAX_TABS: beyond
+  // that the oldest goes, after the last enqueued finish of this object has completed (ev_done is recorded behind every one).
+  // The blocking copy below writes memory nothing on the device refers to yet.
+  constexpr size_t MAX_TABS = 8;
+  if (m->node_tabs.size() >= MAX_TABS) {
+    if (m->ev_done) HIPCHK(m, hipEventSynchronize(m->ev_done));
+    dev_free(m->node_tabs.front().d);
+    m->node_tabs.erase(m->node_tabs.begin());
+  }
   uint32_t* d = nullptr;
   int rc = dev_alloc(&m->err, &d, (size_t)nn * 8);
   if (rc) return rc;
@@ -483,9 +491,13 @@ int lcpc_commit_finish_device(lcpc_commit_t* m, uint8_t* gathered, uint64_t n_ro
   if (n_rows_total != m->n_rows) return LCPC_ERR_ARG;
   if (!m->shard_encoded) return LCPC_ERR_STATE;             // (read under the lock: the encode step may run on another host thread)
   HIPCHK(m, hipSetDevice(m->enc->prm.device));
-  int rc = shard_finish_cols(m, gathered, slots_per_rank, (hipStream_t)stream);
+  // the node table first: a slots_per_rank too small for this shape is an argument error that changes nothing -- the caller may
+  // call again with a corrected value
+  int rc = shard_node_table(m, slots_per_rank);
+  if (rc == LCPC_ERR_ARG) return rc;
+  if (!rc) rc = shard_finish_cols(m, gathered, slots_per_rank, (hipStream_t)stream);
   if (!rc) rc = shard_merkle_phase(m, (hipStream_t)stream, root);
-  if (rc) m->shard_encoded = false;                         // whatever failed, this commit cannot be finished any more
+  if (rc) m->shard_encoded = false;                         // a device step failed: this commit cannot be finished any more
   return rc;
   LCPC_CATCH(m)
 }

@@ -66,3 +66,21 @@ def commit_bincode(oc):
         out.append(struct.pack("<Q", 32) + bytes(h))
     return b"".join(out)
 
+
+
+def run_with_test_hooks(body, env=None, timeout=600):
+    """run `body` (python source) in a child process whose lcpc_amd loads lib/liblcpc_hip_testhooks.so -- the library built with
+    -DLCPC_TEST_HOOKS (lcpc_amd/csrc/Makefile), the only build that reads LCPC_TEST_FAIL.  The product library carries no such branch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hooks = os.path.join(root, "lcpc_amd", "lib", "liblcpc_hip_testhooks.so")
+    assert os.path.exists(hooks), "lcpc_amd/csrc/Makefile builds it beside the product"
+    pre = ("import os, sys\nsys.path[:0] = [%r, %r, %r]\nimport lcpc_amd._lib as _L\n_L.LIB_PATH = %r\n"
+           "import numpy as np\nimport oracle_lib as O\nfrom lcpc_amd import LcCommit, LigeroEncoding\n"
+           % (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), hooks))
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, "-c", pre + body], capture_output=True, text=True, env=e, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stdout

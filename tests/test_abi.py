@@ -251,3 +251,17 @@ def test_generated_sources_are_deterministic_and_current():
         assert a == b and len(a) > 1000, gen
         assert open(os.path.join(csrc, hdr), "rb").read() == a, "%s is stale: rebuild (make -C lcpc_amd/csrc)" % hdr
         assert hdr not in tracked, "%s must not be tracked" % hdr
+
+
+def test_product_library_has_no_test_hooks():
+    """the allocation-failure hooks of ctx.cpp (LCPC_TEST_FAIL) exist only in lib/liblcpc_hip_testhooks.so, the second build the
+    Makefile makes with -DLCPC_TEST_HOOKS for tests/common.py run_with_test_hooks; the product neither reads the variable nor
+    carries the branches.  Both export the same ABI."""
+    import subprocess
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    hooks = os.path.join(lib_dir, "liblcpc_hip_testhooks.so")
+    assert os.path.exists(hooks)
+    assert b"LCPC_TEST_FAIL" not in open(_lib.LIB_PATH, "rb").read()
+    assert b"LCPC_TEST_FAIL" in open(hooks, "rb").read()
+    syms = lambda p: sorted(l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", p], text=True).splitlines() if " T lcpc_" in l)
+    assert syms(hooks) == syms(_lib.LIB_PATH)

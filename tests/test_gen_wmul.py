@@ -8,8 +8,8 @@ import sys
 
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lcpc_amd", "csrc", "gen"))
-import gen_wmul_asm as G  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import wmul_sim as G  # noqa: E402
 
 
 def _limbs(v, N, W):

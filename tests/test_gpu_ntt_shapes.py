@@ -118,18 +118,22 @@ def test_commit_three_pass_shapes(oracle, log_n, rate):
 @pytest.mark.parametrize("fid", [3, 1])
 def test_three_pass_tables_do_not_fit(oracle, fid):
     """the three-pass plan's first pack is ~2.3 x one row; when the device cannot hold it the context falls back to the general
-    kernel's plan instead of failing (LCPC_TEST_FAIL=3pass simulates the failed allocation after the sub-sampled tables were
-    made, so the clean-up runs): same commitment, and the context made afterwards without the hook is unaffected."""
-    O = oracle
-    log_n = 21
-    n_cols, n_per_row = 1 << log_n, 1 << (log_n - 1)
-    coeffs = O.random_elems(fid, n_per_row + 1000, 9 + fid)
-    os.environ["LCPC_TEST_FAIL"] = "3pass"
-    try:
-        enc_f = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
-    finally:
-        del os.environ["LCPC_TEST_FAIL"]
-    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
-    a, b = LcCommit.commit(coeffs, enc_f), LcCommit.commit(coeffs, enc)
-    assert a.get_root() == b.get_root() and (a.comm() == b.comm()).all()
-    assert a.get_root() == O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=8).get_root()
+    kernel's plan instead of failing (LCPC_TEST_FAIL=3pass -- read only by the test-hooks build of the library,
+    common.run_with_test_hooks -- simulates the failed allocation after the sub-sampled tables were made, so the clean-up runs):
+    same commitment, and the context made afterwards without the hook is unaffected."""
+    from common import run_with_test_hooks
+    out = run_with_test_hooks("""
+fid = %d
+log_n = 21
+n_cols, n_per_row = 1 << log_n, 1 << (log_n - 1)
+coeffs = O.random_elems(fid, n_per_row + 1000, 9 + fid)
+os.environ["LCPC_TEST_FAIL"] = "3pass"
+enc_f = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+del os.environ["LCPC_TEST_FAIL"]
+enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+a, b = LcCommit.commit(coeffs, enc_f), LcCommit.commit(coeffs, enc)
+assert a.get_root() == b.get_root() and (a.comm() == b.comm()).all()
+assert a.get_root() == O.Commit.commit(coeffs, O.Encoding.ligero_from_dims(fid, n_per_row, n_cols), n_threads=8).get_root()
+print("fallback ok")
+""" % fid)
+    assert "fallback ok" in out
