@@ -606,3 +606,36 @@ def test_brakedown_limb_dot_product_small_fields(oracle, fid, n_per_row, n_rows)
     oc = O.Commit.commit(coeffs, oenc, n_threads=4)
     assert (c.comm() == oc.comm()).all()
     assert (c.hashes() == oc.hashes()).all() and c.get_root() == oc.get_root()
+
+
+@pytest.mark.parametrize("kind,fid,n_per_row,n_cols,n_rows", [
+    ("ligero", 0, 32768, 65536, 20), ("ligero", 1, 40000, 131072, 9), ("ligero", 2, 33000, 65536, 12), ("ligero", 3, 36864, 131072, 17),
+    ("sdig", 3, 0, 0, 0)])
+def test_prove_long_polynomial_two_ranges(oracle, kind, fid, n_per_row, n_cols, n_rows):
+    """LcCommit::prove (lcpc-2d/src/lib.rs:1004-1093) with n_per_row >= 32768: the prover fetches p_random in two column ranges (the
+    cut at n_per_row / 8 rounded up to 256: commit.cpp collapse_host_sliced) and absorbs the first while the second is computed.  Lengths
+    that are not powers of two, every field, a ragged last row, Brakedown's position-major commitment: the proof bytes are the oracle
+    prover's, two proofs in a row on one object (the second reuses the arena and the events)."""
+    O = oracle
+    from lcpc_amd import SdigEncoding
+    if kind == "sdig":
+        n = (1 << 22) - 77
+        enc = SdigEncoding.new(fid, n, 5)
+        _, n_per_row, n_cols = enc.get_dims(n)
+        oenc = O.Encoding.sdig_from_dims(fid, n_per_row, n_cols, 5, 3)
+    else:
+        n = n_rows * n_per_row - 1234
+        enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+        oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+    assert n_per_row >= 32768
+    coeffs = O.random_elems(fid, n, 77 + fid)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=8)
+    root = c.get_root()
+    assert root == oc.get_root()
+    nco = enc.get_n_col_opens()
+    for seed in (3, 4):
+        outer = O.random_elems(fid, c.n_rows, seed)
+        pf = c.prove(outer, enc, mk_transcript(Transcript, root, nco))
+        opf, _ = oc.prove(outer, oenc, mk_transcript(O.Transcript, root, nco))
+        assert pf.to_bytes() == opf
