@@ -14,6 +14,20 @@
 
 namespace lcpc {
 
+// Wave priority around the memory phases of the VALU-bound kernels (the row NTTs, the column hash): a wave that is about to issue its
+// few loads / LDS reads and then wait for them (tile load, the reads and twiddle loads at the top of a round, the store phase) takes
+// priority 1, a wave inside its multiplier / compression chains priority 0 -- so the memory instructions of one wave are not queued
+// behind hundreds of arithmetic instructions of its three neighbours on the SIMD and its latency starts to run at once.  Measured,
+// same box, interleaved: headline commit 9.57 -> 9.32 ms (levels 1, 2, 3 alike).  Placement only; results are unaffected.
+__device__ __forceinline__ void mem_phase(bool on) {
+#ifdef __HIP_DEVICE_COMPILE__
+  if (on) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#else
+  (void)on;
+#endif
+}
+
 typedef uint32_t u32;
 typedef uint64_t u64;
 

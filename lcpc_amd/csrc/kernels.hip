@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
   };
 
   const bool canon = a.roots29c != nullptr;
+  mem_phase(true);                                           // (field_dev.h: wave priority while a wave issues its memory instructions)
   for (u32 i = tid; i < 64 * 12; i += 256) qp[i] = a.qp29[i];
   const u32* src = a.src + row * a.src_stride * NL;
   for (u32 e = tid; e < T; e += 256) {
@@ -337,6 +338,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
       }
       const L9 x0 = lds9_get<LT>(lds, e0), x1 = lds9_get<LT>(lds, e0 + dq);
       const L9 x2 = lds9_get<LT>(lds, e0 + 2 * dq), x3 = lds9_get<LT>(lds, e0 + 3 * dq);   // I: normalised, |value| < 4p
+      mem_phase(false);
       const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);                                 // limbs [0, 2^30), |value| < 8p
       L9 c0 = l9::add(b0, b1);                                                             // limbs [0, 2^31), |value| < 16p
       l9::normalize(c0);
@@ -370,6 +372,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9_kernel(NttPassArgs a) {
         lds9_put<LT>(lds, e0 + 2 * dq, l9::mul(l9::add(e2, tI), w0.w));
         lds9_put<LT>(lds, e0 + 3 * dq, l9::mul(l9_neg_if(l9::sub(e2, tI), ng), w3.w));
       }
+      mem_phase(true);                                       // the next quad's reads, or the barrier and the next round's
     }
     __syncthreads();
   }

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     tile = blockIdx.x % tiles_per_row;
   }
   const u32 tid = threadIdx.x;
+  mem_phase(true);                                           // (field_dev.h: wave priority while a wave issues its memory instructions)
   const u32 lb = FIRST ? k - S : 0u;                         // index bits below the pass's stage field
   // element index of LDS slot e = (i << LBT) | lp.  First pass: (i << lb) | (tile << LTJ) | lp; last pass: tile * 2^S + i
   auto gindex = [&](u32 e) -> u32 {
@@ -207,6 +208,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
         const u32* wu = cls_pack + pi.u_off + ((r - RU) * 4 + wv) * (3 * U_SLOT);
         const L9 x0 = lds9_get<LT>(lds, SWZ(eu)), x1 = lds9_get<LT>(lds, SWZ(eu + dq));
         const L9 x2 = lds9_get<LT>(lds, SWZ(eu + 2 * dq)), x3 = lds9_get<LT>(lds, SWZ(eu + 3 * dq));
+        mem_phase(false);
         const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);
         L9 c0 = l9::add(b0, b1);
         l9::clamp_apply(c0, l9::clamp_row(nqp, l9::clamp_q(c0.v[8])));
@@ -220,6 +222,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
         l9::normalize(c2);
         lds9_put<LT>(lds, SWZ(eu + 2 * dq), c2);
         lds9_put<LT>(lds, SWZ(eu + 3 * dq), l9::mul_u(l9::sub(b2, b3), wu + 2 * U_SLOT));
+        mem_phase(true);
         __syncthreads();
         continue;
       }
@@ -229,6 +232,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       // is block 0, so with canonical output the three multiplies leaving it (w0, w3, and w2 for c1) take the converting set
       const u32 vb = canon ? 3u : 0u;
       const Fe29 w0 = pk_load<6>(blk, period, vb + 0, jl), w3 = pk_load<6>(blk, period, vb + 1, jl), w2 = pk_load<6>(blk, period, vb + 2, jl);
+      mem_phase(false);
       if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
         const L9 x0 = lds9_get<LT>(lds, SWZ(e0));
         lds9_put<LT>(lds, SWZ(e0 + dq), l9::mul(x0, w2));
@@ -244,11 +248,13 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
         lds9_put<LT>(lds, SWZ(e0 + 2 * dq), l9::mul(l9::add(x0, t), w0));                  // in: limbs (-2^29, 2^30), |value| < 3.7p
         lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(l9::sub(x0, t), w3));
       }
+      mem_phase(true);
       __syncthreads();
       continue;
     }
     const L9 x0 = lds9_get<LT>(lds, SWZ(e0)), x1 = lds9_get<LT>(lds, SWZ(e0 + dq));
     const L9 x2 = lds9_get<LT>(lds, SWZ(e0 + 2 * dq)), x3 = lds9_get<LT>(lds, SWZ(e0 + 3 * dq));     // I: normalised, |value| < 4p
+    mem_phase(false);
     const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);                                   // limbs [0, 2^30), |value| < 8p
     L9 c0 = l9::add(b0, b1);                                                               // limbs [0, 2^31), |value| < 16p
     if (last_two) {
@@ -295,6 +301,7 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       lds9_put<LT>(lds, SWZ(e0 + 2 * dq), l9::mul(l9::add(e2, t), w0));                    // in: limbs (-2^29, 2^30), |value| < 10.7p
       lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(l9::sub(e2, t), w3));
     }
+    mem_phase(true);                                         // the barrier, then the next round's reads and twiddle loads (or the store phase)
     __syncthreads();
   }
 

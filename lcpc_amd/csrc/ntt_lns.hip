@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
     tile = blockIdx.x % tiles_per_row;
   }
   const u32 tid = threadIdx.x;
+  mem_phase(true);                                           // (field_dev.h: wave priority while a wave issues its memory instructions)
   const u32 lb = FIRST ? k - S : 0u;                         // index bits below the pass's stage field
   // element index of LDS slot e = (i << LBT) | lp.  First pass: (i << lb) | (tile << LTJ) | lp; last pass: tile * 2^S + i
   auto gindex = [&](u32 e) -> u32 {
@@ -185,6 +186,7 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
       const u32 vb = canon ? 3u : 0u;
       const E w0 = planes_get<FT>(blk, 6 * period, (vb + 0) * period + jl), w2 = planes_get<FT>(blk, 6 * period, (vb + 2) * period + jl);
       const E w3 = planes_get<FT>(blk, 6 * period, (vb + 1) * period + jl);
+      mem_phase(false);
       if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
         const E x0 = planes_get<FT>(lds, T, e0);
         planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(x0, w2));
@@ -200,11 +202,13 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
         planes_put<FT>(lds, T, e0 + 2 * dq, ln::mul<FT>(ln::add(x0, t), w0));
         planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(ln::sub(x0, t), w3));
       }
+      mem_phase(true);
       __syncthreads();
       continue;
     }
     const E x0 = planes_get<FT>(lds, T, e0), x1 = planes_get<FT>(lds, T, e0 + dq);
     const E x2 = planes_get<FT>(lds, T, e0 + 2 * dq), x3 = planes_get<FT>(lds, T, e0 + 3 * dq);   // I: normalised, |value| < 4p
+    mem_phase(false);
     const E b0 = ln::add(x0, x2), b1 = ln::add(x1, x3);                                           // limbs [0, 2^(W+1)), |value| < 8p
     E c0 = ln::add(b0, b1);                                                                       // limbs [0, 2^(W+2)), |value| < 16p
     if (last_two) ln::normalize<FT>(c0);                                                          // (the store path clamps every slot)
@@ -235,6 +239,7 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
       planes_put<FT>(lds, T, e0 + 2 * dq, ln::mul<FT>(ln::add(e2, t), w0));                       // in: limbs (-2^W, 2^(W+1)), |value| < 10.5p
       planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(ln::sub(e2, t), w3));
     }
+    mem_phase(true);
     __syncthreads();
   }
 
