@@ -912,7 +912,11 @@ __global__ void __launch_bounds__(256) collapse29_kernel(CollapseArgs a) {
     Fe<8> c = fe_load<8>(a.coeffs + (rb * a.n_per_row + j) * 8);
     for (u64 r = rb; r < re; r++) {
       Fe<8> cn = c;
+      // (field_dev.h) one tensor: the next row's load goes out ahead of this row's 81 mads (0.425 -> 0.401 ms at the headline shape);
+      // with two tensors fused the same costs 10 % (0.66 -> 0.73): the longer arithmetic stretch already covers the load
+      if constexpr (NT == 1) mem_phase(true);
       if (r + 1 < re) cn = fe_load<8>(a.coeffs + ((r + 1) * a.n_per_row + j) * 8);     // next row in flight
+      if constexpr (NT == 1) mem_phase(false);
       const Fe29 x = fe_to29(c);
 #pragma unroll
       for (int t = 0; t < NT; t++) {
@@ -1315,12 +1319,14 @@ __device__ __forceinline__ Fe<NL> spmm_t_terms(const SpmmTArgs& a, const u32* xi
       for (int i = 0; i < 9; i++) v.v[i] = cv29[(size_t)kb * 12 + i];
       for (u32 k = kb; k < ke; k++) {
         Fe<NL> xn = x;
+        mem_phase(true);                            // (field_dev.h) the next term's gather goes out ahead of this term's 81 mads
         if (k + 1 < ke) xn = fe_load<NL>(xin + (size_t)cn * pstride);
         const u32 kn = k + 1 < ke ? k + 1 : k, kn2 = k + 2 < ke ? k + 2 : k;
         cn = cidx[kn2];
         Fe29 vn;
 #pragma unroll
         for (int i = 0; i < 9; i++) vn.v[i] = cv29[(size_t)kn * 12 + i];
+        mem_phase(false);
         lazy29_mac(acc, fe_to29(x), v);
         v = vn;
         if (++since == 6) { lazy29_normalize(acc); since = 0; }
@@ -1351,12 +1357,14 @@ __device__ __forceinline__ Fe<NL> spmm_t_terms(const SpmmTArgs& a, const u32* xi
           for (int i = 0; i < N; i++) v.v[i] = cvl[(size_t)kb * FT::STRIDE + i];
           for (u32 k = kb; k < ke; k++) {
             Fe<NL> xn = x;
+            mem_phase(true);
             if (k + 1 < ke) xn = fe_load<NL>(xin + (size_t)cn * pstride);
             const u32 kn = k + 1 < ke ? k + 1 : k, kn2 = k + 2 < ke ? k + 2 : k;
             cn = cidx[kn2];
             LN<N> vn;
 #pragma unroll
             for (int i = 0; i < N; i++) vn.v[i] = cvl[(size_t)kn * FT::STRIDE + i];
+            mem_phase(false);
             ln::lazy_mac<FT>(acc, ln::from_packed<FT>(x), v);
             v = vn;
             if (++since == 6) { ln::lazy_normalize<FT>(acc); since = 0; }
@@ -1449,7 +1457,9 @@ __global__ void __launch_bounds__(256) spmm_t_tail_kernel(SpmmTArgs a, u32 n_mai
     for (u32 i = ib; i < ie; i++) {
       Fe<NL> xn = x;
       Fe29 vn = v;
+      mem_phase(true);
       if (i + 1 < len) { xn = fe_load<NL>(xin + (size_t)a.colidx[k0 + i + 1] * pstride); vn = load_v(k0 + i + 1); }
+      mem_phase(false);
       if (i < len) lazy29_mac(acc, fe_to29(x), v);
       if (++since == 6) { lazy29_normalize(acc); since = 0; }
       x = xn; v = vn;
