@@ -255,7 +255,10 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.roots29 = sub ? c->d_rootsls : c->d_rootsl;
       a.roots29c = j.canon_out ? (sub ? c->d_rootslcs : c->d_rootslc) : nullptr;
       a.canon_row_mask = sub ? (1u << s0) - 1 : 0u;
-      a.mont_prefix = (j.canon_out && i == 2) ? 4u : 0u;
+      // (fields with a shifted-multiples multiply -- Ft127, Ft191 -- run uniform rounds in every 10-stage pass and convert block 0 before
+      // them: pass 1 leaves nothing in Montgomery form; Ft63 keeps the 4-element prefix of the last pass)
+      a.mont_prefix = (j.canon_out && i == 2 && c->NL == 2) ? 4u : 0u;
+      a.blk0_gone = (i == 2 && j.canon_out && c->NL != 2) ? 1u : 0u;
       a.src_stride = first ? j.src_stride : ((uint64_t)1 << 20);
       a.dst_stride = first ? c->n_cols : ((uint64_t)1 << 20);
       a.n_valid = first ? j.n_valid : ((uint64_t)1 << 20);
@@ -279,7 +282,10 @@ int encode_rows_device(const lcpc_ctx* c, EncodeWs* ws, const EncodeJob& j, hipS
       a.dst = j.dst;
       a.roots = c->d_roots; a.roots29 = c->d_rootsl; a.qp29 = c->d_qpl; a.wq_w = c->d_wq_w;
       a.roots29c = j.canon_out ? c->d_rootslc : nullptr;
-      a.mont_prefix = (j.canon_out && !first) ? 4u : 0u;       // the last pass ends with a radix-4 round (10 stages)
+      // the last pass ends with a radix-4 round (10 stages): Ft63 reduces its 4-element never-multiplied prefix at the store; Ft127 /
+      // Ft191 have a uniform round in that pass and convert block 0 before it (ntt_lns.hip), or already in a first pass of >= 8 stages
+      a.mont_prefix = (j.canon_out && !first && c->NL == 2) ? 4u : 0u;
+      a.blk0_gone = (!first && j.canon_out && c->NL != 2 && c->passes[0].s >= 8) ? 1u : 0u;
       a.src_stride = first ? j.src_stride : c->n_cols;
       a.dst_stride = c->n_cols;
       a.n_valid = first ? j.n_valid : c->n_cols;

@@ -81,7 +81,13 @@ template <int S, int LBT> struct Shape {
   static constexpr int NR4 = S / 2;
   static constexpr u32 period2 = 1u << (S - 1 + LBT);
   static constexpr u32 period4(int r) { return 1u << (S - U0 - 2 * r - 2 + LBT); }
+  // the uniform rounds of ntt_l9s.hip (Shape::RU there): from the radix-4 round whose twiddle period is 4 on, wave w takes the quads
+  // q = w mod 4 and all its lanes multiply by the same three twiddles -- scalar operands of ln::mul_u (fields that have one)
+  static constexpr int RU = NR4 >= 4 ? 3 : -1;
+  static constexpr int NRU = RU < 0 ? 0 : NR4 - RU;
 };
+// words per shifted-multiples table in the packs: N^2 = 25 / 49 used
+template <class FT> constexpr u32 U_SLOT = FT::N == 5 ? 32u : 64u;
 
 constexpr u32 TILE = 1024;
 
@@ -94,6 +100,9 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
   using SH = Shape<S, LBT>;
   using E = LN<N>;
   constexpr u32 T = TILE;
+  constexpr int RU = ln::has_mul_u<FT> ? SH::RU : -1;
+  // passes with a uniform round keep the tile XOR-swizzled, as K1s does (that round reads it with a lane stride of 16 elements)
+  auto SWZ = [](u32 e) -> u32 { if constexpr (RU >= 0) return e ^ ((e >> 4) & 15u); else return e; };
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   u32* nqp = lds + (size_t)T * N;                            // NEGATED q*p rows (ln::clamp_apply)
   const u32 k = a.log_n;
@@ -137,12 +146,14 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
     } else {
       v = fe_load<NL>(src + (size_t)g * NL);                 // < 2^(32 NL) (the first pass's store), not necessarily < p
     }
-    planes_put<FT>(lds, T, e, ln::from_packed<FT>(v));
+    planes_put<FT>(lds, T, SWZ(e), ln::from_packed<FT>(v));
   }
   __syncthreads();
   const u32* cls_pack = pack + (size_t)(FIRST ? tile : 0u) * pi.class_words;
   const bool canon = a.roots29c != nullptr && ((u32)row & a.canon_row_mask) == 0;     // (wave-uniform; three-pass plans: kernels.h)
-  const bool blk0_tile = FIRST || tile == 0;                 // tiles that hold elements of "block 0" (never multiplied so far)
+  // tiles that hold elements of "block 0" (never multiplied so far); a.blk0_gone: an earlier pass with a uniform round converted what
+  // was left of it (below)
+  const bool blk0_tile = (FIRST || tile == 0) && a.blk0_gone == 0;
   const bool zero_hi = FIRST && a.n_valid <= (1ull << (k - 1));
 
   if constexpr (SH::U0 == 1) {
@@ -153,15 +164,15 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
     for (u32 pp = 0; pp < 2; pp++) {
       const u32 e1 = tid + 256u * pp;                        // slots with the top stage bit clear are [0, half)
       const E w = planes_get<FT>(blk, 2 * SH::period2, (canon ? SH::period2 : 0u) + e1);   // stage 0 is all block 0
-      const E x = planes_get<FT>(lds, T, e1);
+      const E x = planes_get<FT>(lds, T, SWZ(e1));
       if (zero_hi) {
-        planes_put<FT>(lds, T, e1 + half, ln::mul<FT>(x, w));         // (x, 0) -> (x, x w)
+        planes_put<FT>(lds, T, SWZ(e1 + half), ln::mul<FT>(x, w));         // (x, 0) -> (x, x w)
       } else {
-        const E y = planes_get<FT>(lds, T, e1 + half);
+        const E y = planes_get<FT>(lds, T, SWZ(e1 + half));
         E sum = ln::add(x, y);                               // [0, 2p + 128 B)
         ln::normalize<FT>(sum);
-        planes_put<FT>(lds, T, e1, sum);
-        planes_put<FT>(lds, T, e1 + half, ln::mul<FT>(ln::sub(x, y), w));
+        planes_put<FT>(lds, T, SWZ(e1), sum);
+        planes_put<FT>(lds, T, SWZ(e1 + half), ln::mul<FT>(ln::sub(x, y), w));
       }
     }
     __syncthreads();
@@ -180,6 +191,37 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
     const u32 period = one << (hb - 1 + LBT);                // quads q and q + period share their twiddles
     const u32 jl = q & (period - 1);
     const u32* blk = cls_pack + pi.round_off[SH::U0 + r];
+    if constexpr (RU >= 0) {
+      if (r >= RU && !last_two) {
+        // ---- a uniform round (ntt_l9s.hip): wave w takes the quads q = w mod 4; its three twiddles are scalar operands.  Block 0 is
+        //      gone (converted in round RU - 1), so every lane multiplies by the same plain constants
+        const u32 wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const u32 qu = ((tid & 63u) << 2) | wv;
+        const u32 lpu = qu & ((1u << LBT) - 1), ju = qu >> LBT;
+        const u32 iu = ((ju >> (hb - 1)) << (hb + 1)) | (ju & ((1u << (hb - 1)) - 1));
+        const u32 eu = (iu << LBT) | lpu;
+        const u32* wu = cls_pack + pi.u_off + ((r - RU) * 4 + wv) * (3 * U_SLOT<FT>);
+        const E x0 = planes_get<FT>(lds, T, SWZ(eu)), x1 = planes_get<FT>(lds, T, SWZ(eu + dq));
+        const E x2 = planes_get<FT>(lds, T, SWZ(eu + 2 * dq)), x3 = planes_get<FT>(lds, T, SWZ(eu + 3 * dq));
+        mem_phase(false);
+        const E b0 = ln::add(x0, x2), b1 = ln::add(x1, x3);
+        E c0 = ln::add(b0, b1);
+        ln::clamp_apply<FT>(c0, ln::clamp_row<FT>(nqp, ln::clamp_q<FT>(c0.v[N - 1])));
+        planes_put<FT>(lds, T, SWZ(eu), c0);
+        E d1 = ln::sub(b0, b1);
+        ln::normalize<FT>(d1);                                                                      // mul_u wants sum |limb| < N 2^W
+        planes_put<FT>(lds, T, SWZ(eu + dq), ln::mul_u<FT>(d1, wu + 2 * U_SLOT<FT>));
+        const E b2 = ln::mul_u<FT>(ln::sub(x0, x2), wu);
+        const E b3 = ln::mul_u<FT>(ln::sub(x1, x3), wu + U_SLOT<FT>);                               // (-2.5p, 1.6p)
+        E c2 = ln::add(b2, b3);
+        ln::normalize<FT>(c2);
+        planes_put<FT>(lds, T, SWZ(eu + 2 * dq), c2);
+        planes_put<FT>(lds, T, SWZ(eu + 3 * dq), ln::mul_u<FT>(ln::sub(b2, b3), wu + 2 * U_SLOT<FT>));
+        mem_phase(true);
+        __syncthreads();
+        continue;
+      }
+    }
     if (u == 0 && zero_hi) {
       // zero-padded first round (rate <= 1/2): x2 = x3 = 0, the stage-0 butterflies are (x, x w); inputs < 4p; everything
       // is block 0, so with canonical output the three multiplies leaving it (w0, w3, and w2 for c1) take the converting set
@@ -188,32 +230,32 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
       const E w3 = planes_get<FT>(blk, 6 * period, (vb + 1) * period + jl);
       mem_phase(false);
       if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
-        const E x0 = planes_get<FT>(lds, T, e0);
-        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(x0, w2));
-        planes_put<FT>(lds, T, e0 + 2 * dq, ln::mul<FT>(x0, w0));
-        planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(x0, w3));
+        const E x0 = planes_get<FT>(lds, T, SWZ(e0));
+        planes_put<FT>(lds, T, SWZ(e0 + dq), ln::mul<FT>(x0, w2));
+        planes_put<FT>(lds, T, SWZ(e0 + 2 * dq), ln::mul<FT>(x0, w0));
+        planes_put<FT>(lds, T, SWZ(e0 + 3 * dq), ln::mul<FT>(x0, w3));
       } else {
-        const E x0 = planes_get<FT>(lds, T, e0), x1 = planes_get<FT>(lds, T, e0 + dq);
+        const E x0 = planes_get<FT>(lds, T, SWZ(e0)), x1 = planes_get<FT>(lds, T, SWZ(e0 + dq));
         E c0 = ln::add(x0, x1);
         ln::normalize<FT>(c0);
-        planes_put<FT>(lds, T, e0, c0);
-        planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(x0, x1), w2));
+        planes_put<FT>(lds, T, SWZ(e0), c0);
+        planes_put<FT>(lds, T, SWZ(e0 + dq), ln::mul<FT>(ln::sub(x0, x1), w2));
         const E t = mul_i<FT>(x1, a);                                                        // x1 I: keeps x1's form; normalised, (-2.5p, 1.6p)
-        planes_put<FT>(lds, T, e0 + 2 * dq, ln::mul<FT>(ln::add(x0, t), w0));
-        planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(ln::sub(x0, t), w3));
+        planes_put<FT>(lds, T, SWZ(e0 + 2 * dq), ln::mul<FT>(ln::add(x0, t), w0));
+        planes_put<FT>(lds, T, SWZ(e0 + 3 * dq), ln::mul<FT>(ln::sub(x0, t), w3));
       }
       mem_phase(true);
       __syncthreads();
       continue;
     }
-    const E x0 = planes_get<FT>(lds, T, e0), x1 = planes_get<FT>(lds, T, e0 + dq);
-    const E x2 = planes_get<FT>(lds, T, e0 + 2 * dq), x3 = planes_get<FT>(lds, T, e0 + 3 * dq);   // I: normalised, |value| < 4p
+    const E x0 = planes_get<FT>(lds, T, SWZ(e0)), x1 = planes_get<FT>(lds, T, SWZ(e0 + dq));
+    const E x2 = planes_get<FT>(lds, T, SWZ(e0 + 2 * dq)), x3 = planes_get<FT>(lds, T, SWZ(e0 + 3 * dq));   // I: normalised, |value| < 4p
     mem_phase(false);
     const E b0 = ln::add(x0, x2), b1 = ln::add(x1, x3);                                           // limbs [0, 2^(W+1)), |value| < 8p
     E c0 = ln::add(b0, b1);                                                                       // limbs [0, 2^(W+2)), |value| < 16p
     if (last_two) ln::normalize<FT>(c0);                                                          // (the store path clamps every slot)
     else ln::clamp_apply<FT>(c0, ln::clamp_row<FT>(nqp, ln::clamp_q<FT>(c0.v[N - 1])));           // [0, p + 64 B)
-    planes_put<FT>(lds, T, e0, c0);
+    planes_put<FT>(lds, T, SWZ(e0), c0);
     if (last_two) {
       // outputs go straight to the store path (normalised, |value| < 16p)
       E c1 = ln::sub(b0, b1);
@@ -222,22 +264,32 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
       E c2 = ln::add(b2, b3);
       E c3 = ln::sub(b2, b3);
       ln::normalize<FT>(c1); ln::normalize<FT>(c2); ln::normalize<FT>(c3);
-      planes_put<FT>(lds, T, e0 + dq, c1);
-      planes_put<FT>(lds, T, e0 + 2 * dq, c2);
-      planes_put<FT>(lds, T, e0 + 3 * dq, c3);
+      planes_put<FT>(lds, T, SWZ(e0 + dq), c1);
+      planes_put<FT>(lds, T, SWZ(e0 + 2 * dq), c2);
+      planes_put<FT>(lds, T, SWZ(e0 + 3 * dq), c3);
     } else {
       // block 0 of stages (u, u + 1) = the quads whose elements all lie below n / 2^(t + 2): exactly q < period in the tiles
       // that hold block 0.  Their three multiplies that leave block 0 (c1, c2, c3) take the converting set; c0 stays a pure sum;
       // t = (x1 - x3) I is by a plain constant and stays in the form of its inputs
-      const bool blk0c = canon && blk0_tile && q < period;
+      const bool blk0c = canon && blk0_tile && q < period && (RU < 0 || r < RU);
+      if constexpr (RU >= 1) {
+        if (r == RU - 1 && blk0c) {
+          // the last round before the uniform one: c0, the pure sum that would carry block 0 on, is converted as well -- a multiply by
+          // R' R^-1 = 2^(N W - 32 NL) (16 lanes of one wave per block-0 tile) -- so that the uniform round sees canonical values only
+          E kc;
+#pragma unroll
+          for (int i = 0; i < N; i++) kc.v[i] = i == 0 ? (1u << (N * FT::W - 32 * NL)) : 0u;
+          planes_put<FT>(lds, T, SWZ(e0), ln::mul<FT>(c0, kc));
+        }
+      }
       const u32 vb = blk0c ? 3u : 0u;
       const E w2 = planes_get<FT>(blk, 6 * period, (vb + 2) * period + jl);
-      planes_put<FT>(lds, T, e0 + dq, ln::mul<FT>(ln::sub(b0, b1), w2));                          // in: |value| < 16p
+      planes_put<FT>(lds, T, SWZ(e0 + dq), ln::mul<FT>(ln::sub(b0, b1), w2));                          // in: |value| < 16p
       const E t = mul_i<FT>(ln::sub(x1, x3), a);                                                  // normalised, (-2.5p, 1.6p)
       const E e2 = ln::sub(x0, x2);                                                               // limbs (-2^W, 2^W), |value| < 8p
       const E w0 = planes_get<FT>(blk, 6 * period, (vb + 0) * period + jl), w3 = planes_get<FT>(blk, 6 * period, (vb + 1) * period + jl);
-      planes_put<FT>(lds, T, e0 + 2 * dq, ln::mul<FT>(ln::add(e2, t), w0));                       // in: limbs (-2^W, 2^(W+1)), |value| < 10.5p
-      planes_put<FT>(lds, T, e0 + 3 * dq, ln::mul<FT>(ln::sub(e2, t), w3));
+      planes_put<FT>(lds, T, SWZ(e0 + 2 * dq), ln::mul<FT>(ln::add(e2, t), w0));                       // in: limbs (-2^W, 2^(W+1)), |value| < 10.5p
+      planes_put<FT>(lds, T, SWZ(e0 + 3 * dq), ln::mul<FT>(ln::sub(e2, t), w3));
     }
     mem_phase(true);
     __syncthreads();
@@ -247,7 +299,7 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
 #pragma unroll
   for (u32 e = tid; e < T; e += 256) {
     const u32 g = gindex(e);
-    E x = planes_get<FT>(lds, T, e);                                            // normalised, |value| < 16p
+    E x = planes_get<FT>(lds, T, SWZ(e));                                            // normalised, |value| < 16p
     ln::clamp_apply<FT>(x, ln::clamp_row<FT>(nqp, ln::clamp_q<FT>(x.v[N - 1])));  // [0, p + 64 B) < 2^(32 NL)
     u32 w[NL];
     ln::to_packed<FT>(w, x.v);
@@ -317,6 +369,57 @@ __global__ void __launch_bounds__(256) ntt_lns_pack_kernel(NttPassArgs a, NttPac
   }
 }
 
+// the uniform rounds' constants (ntt_l9s.hip ntt_upack_kernel for N limbs of W bits): per class, for jl = 0..3 and the round's three
+// twiddles w0, w1 = I w0, w2 (plain: block 0 is gone by then), the N shifted multiples W_j = balanced(w 2^(W j) mod p) as N^2 words
+// t = N k + j (limb k of W_j; ln::mul_u / field_wmul_gen.h).  The table entry is w R' mod p: ln::mul(2^(W j), entry) = w 2^(W j),
+// lazily reduced in (-p - eps, eps]; + p where that lies below -(p - 1) / 2.
+template <class FT, int S, int LBT>
+__global__ void __launch_bounds__(64) ntt_lns_upack_kernel(NttPassArgs a, NttPackInfo pi, u32 n_classes, bool first, u32* pack) {
+  using SH = Shape<S, LBT>;
+  constexpr int N = FT::N, W = FT::W;
+  constexpr u32 M = (1u << W) - 1;
+  const u32 k = a.log_n, t0 = a.t0;
+  const u32 lb = first ? k - S : 0u;
+  const u32 id = blockIdx.x * 64 + threadIdx.x;
+  if (id >= n_classes * SH::NRU * 12) return;
+  const u32 cls = id / (SH::NRU * 12), ru = (id / 12) % SH::NRU, jl0 = (id % 12) / 3, v = id % 3;
+  const u32 r = SH::RU + ru;
+  const u32 u = SH::U0 + 2 * r, hb = S - u - 1;
+  const u32 t = t0 + u;
+  if (t + 2 == k) return;                                    // (a last pass's final round: w^(n/4), not packed)
+  const u32 jl = jl0 & (SH::period4(r) - 1);                 // periods 2 and 1: the four slots repeat
+  const u32 lo = first ? (cls << LBT) : 0u;
+  const u32 gm0 = (1u << (k - t - 1)) - 1, gm1 = gm0 >> 1;
+  const u32 lp = jl & ((1u << LBT) - 1), j = jl >> LBT;
+  const u32 i0 = ((j >> (hb - 1)) << (hb + 1)) | (j & ((1u << (hb - 1)) - 1));
+  const u32 g0 = (i0 << lb) | lo | lp;
+  const u32 g1 = g0 + (1u << (hb - 1 + lb));
+  const u32 idx = v == 0 ? (g0 & gm0) << t : (v == 1 ? (g1 & gm0) << t : (g0 & gm1) << (t + 1));
+  const LN<N> w = tab_entry<FT>(a.roots29, idx);
+  u32* out = pack + (size_t)cls * pi.class_words + pi.u_off + ((ru * 4 + jl0) * 3 + v) * U_SLOT<FT>;
+  for (u32 jj = 0; jj < (u32)N; jj++) {
+    LN<N> sh;
+#pragma unroll
+    for (int z = 0; z < N; z++) sh.v[z] = (u32)z == jj ? 1u : 0u;
+    LN<N> x = ln::mul<FT>(sh, w);                            // w 2^(W jj) mod p, in (-p - eps, eps], normalised
+    LN<N> tt;                                                // x + (p - 1) / 2 < 0  <=>  x below the balanced range
+#pragma unroll
+    for (int z = 0; z < N; z++) {
+      const u32 hz = z + 1 < N ? ((FT::limb(z) >> 1) | ((FT::limb(z + 1) & 1u) << (W - 1))) : (FT::limb(z) >> 1);
+      tt.v[z] = x.v[z] + hz;
+    }
+    ln::normalize<FT>(tt);
+    if ((int32_t)tt.v[N - 1] < 0) {
+#pragma unroll
+      for (int z = 0; z < N; z++) x.v[z] += FT::limb(z);
+      ln::normalize<FT>(x);
+    }
+#pragma unroll
+    for (int kk = 0; kk < N; kk++) out[N * kk + jj] = kk + 1 < N ? (x.v[kk] & M) : x.v[kk];
+  }
+  for (u32 z = N * N; z < U_SLOT<FT>; z++) out[z] = 0;
+}
+
 template <class FT, int S, int LBT> NttPackInfo pack_info_t() {
   using SH = Shape<S, LBT>;
   NttPackInfo pi{};
@@ -324,6 +427,7 @@ template <class FT, int S, int LBT> NttPackInfo pack_info_t() {
   // radix-2 slot: variants (plain, converting); radix-4 slots: w0, w3 = w0 w2, w2 plain, then the same from the converting table
   if (SH::U0) { pi.round_off[slot++] = off; off += 2 * SH::period2 * FT::N; off = (off + 3) & ~3u; }
   for (int r = 0; r < SH::NR4; r++) { pi.round_off[slot++] = off; off += 6 * SH::period4(r) * FT::N; off = (off + 3) & ~3u; }
+  if (ln::has_mul_u<FT> && SH::RU >= 0) { off = (off + 15) & ~15u; pi.u_off = off; off += SH::NRU * 4 * 3 * U_SLOT<FT>; }
   pi.class_words = off;
   return pi;
 }
@@ -360,8 +464,10 @@ template <class FT> NttPackInfo pack_info_f(uint32_t s, bool first) {
   return NttPackInfo{};
 }
 template <class FT> hipError_t launch_pack_f(const NttPassArgs& a, bool first, const NttPackInfo& pi, uint32_t n_classes, uint32_t* pack, hipStream_t st) {
+  const unsigned ugrid = (n_classes * 2 * 12 + 63) / 64;      // (<= 2 uniform rounds per pass)
   if (!first) {
     hipLaunchKernelGGL((ntt_lns_pack_kernel<FT, 10, 0>), dim3(64), dim3(256), 0, st, a, pi, n_classes, false, pack);
+    if constexpr (ln::has_mul_u<FT>) hipLaunchKernelGGL((ntt_lns_upack_kernel<FT, 10, 0>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, false, pack);
     return hipGetLastError();
   }
   switch (a.s) {
@@ -369,6 +475,11 @@ template <class FT> hipError_t launch_pack_f(const NttPassArgs& a, bool first, c
     LNS_FIRST_CASES(X)
 #undef X
     default: return hipErrorInvalidValue;
+  }
+  if constexpr (ln::has_mul_u<FT>) {
+    if (a.s == 8) hipLaunchKernelGGL((ntt_lns_upack_kernel<FT, 8, 2>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, true, pack);
+    if (a.s == 9) hipLaunchKernelGGL((ntt_lns_upack_kernel<FT, 9, 1>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, true, pack);
+    if (a.s == 10) hipLaunchKernelGGL((ntt_lns_upack_kernel<FT, 10, 0>), dim3(ugrid), dim3(64), 0, st, a, pi, n_classes, true, pack);
   }
   return hipGetLastError();
 }
