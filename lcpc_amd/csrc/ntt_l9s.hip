@@ -121,6 +121,8 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
   const bool canon = a.roots29c != nullptr && ((u32)row & a.canon_row_mask) == 0;     // (wave-uniform)
   for (u32 i = tid; i < 64 * 12; i += 256) nqp[i] = 0u - a.qp29[i];
   const u32* src = a.src + row * a.src_stride * NL;
+  constexpr bool DIRECT = !(LAST && MID);                    // the first round takes its inputs from the loads (below)
+  L9 xin[4];
   if constexpr (LAST && MID) {
     // the tile as the first pass left it: [limbs 0-3][limbs 4-7][limb 8] planes, the LDS layout itself
     const uint4* t4 = reinterpret_cast<const uint4*>(a.mid + (row << k) * 9 + (size_t)tile * (9 * T));
@@ -140,8 +142,11 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     for (u32 i = tid; i < 9 * T / 4; i += 256) l4[i] = t4[i];
     }
   } else {
+    // The four elements a thread loads, e = tid + 256 it, ARE the quad (the two pairs) of its first round: dq = 256 there whatever the
+    // pass shape.  They go to that round in registers -- no LDS round trip and, where that round needs no clamp table, no barrier
 #pragma unroll
-  for (u32 e = tid; e < T; e += 256) {
+  for (u32 it = 0; it < 4; it++) {
+    const u32 e = tid + 256u * it;
     const u32 g = gindex(e);
     Fe<NL> v;
     if constexpr (FIRST) {        // zero padding, the ragged tail of the caller's vector and the coeffs copy exist here only
@@ -150,15 +155,18 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     } else {
       v = fe_load<NL>(src + (size_t)g * NL);                 // < 2^256 (the first pass's store), not necessarily < p
     }
-    lds9_put<LT>(lds, SWZ(e), l9::from_packed(v));
+    xin[it] = l9::from_packed(v);
   }
+  __builtin_amdgcn_sched_barrier(0);                         // (the first round's twiddle loads stay behind the conversions: registers)
   }
-  __syncthreads();
   const u32* cls_pack = pack + (size_t)(FIRST ? tile : 0u) * pi.class_words;
   // tiles that hold elements of "block 0" (never multiplied so far).  a.blk0_gone: an earlier pass had a uniform round and
   // converted what was left of block 0 before it (below): nothing is in Montgomery form any more
   const bool blk0_tile = (FIRST || tile == 0) && a.blk0_gone == 0;
   const bool zero_hi = FIRST && a.n_valid <= (1ull << (k - 1));
+  // the limb intermediate's tile sits in LDS; otherwise only the q*p table does, which no first round reads (their pure sums are
+  // sums of loads: normalised, not clamped): the barrier at the end of that round serves
+  if constexpr (!DIRECT) __syncthreads();
 
   if constexpr (SH::U0 == 1) {
     // ---- radix-2 round at stage 0 (odd S): pairs (e1, e1 + half), twiddle w^(index of e1).  Inputs straight from the
@@ -169,17 +177,20 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     for (u32 pp = 0; pp < 2; pp++) {
       const u32 e1 = tid + 256u * pp;                        // slots with the top stage bit clear are [0, half)
       const Fe29 w = pk_load<2>(blk, SH::period2, canon ? 1u : 0u, e1);
-      const L9 x = lds9_get<LT>(lds, SWZ(e1));
+      const L9 x = DIRECT ? xin[pp] : lds9_get<LT>(lds, SWZ(e1));
+      if (pp == 0) mem_phase(false);
       if (zero_hi) {
+        if constexpr (DIRECT) lds9_put<LT>(lds, SWZ(e1), x);
         lds9_put<LT>(lds, SWZ(e1 + half), l9::mul(x, w));         // (x, 0) -> (x, x w)
       } else {
-        const L9 y = lds9_get<LT>(lds, SWZ(e1 + half));
+        const L9 y = DIRECT ? xin[pp + 2] : lds9_get<LT>(lds, SWZ(e1 + half));
         L9 sum = l9::add(x, y);                              // [0, 2p)
         l9::normalize(sum);
         lds9_put<LT>(lds, SWZ(e1), sum);
         lds9_put<LT>(lds, SWZ(e1 + half), l9::mul(l9::sub(x, y), w));
       }
     }
+    mem_phase(true);
     __syncthreads();
   }
 
@@ -234,12 +245,13 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       const Fe29 w0 = pk_load<6>(blk, period, vb + 0, jl), w3 = pk_load<6>(blk, period, vb + 1, jl), w2 = pk_load<6>(blk, period, vb + 2, jl);
       mem_phase(false);
       if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
-        const L9 x0 = lds9_get<LT>(lds, SWZ(e0));
+        const L9 x0 = DIRECT ? xin[0] : lds9_get<LT>(lds, SWZ(e0));
+        if constexpr (DIRECT) lds9_put<LT>(lds, SWZ(e0), x0);
         lds9_put<LT>(lds, SWZ(e0 + dq), l9::mul(x0, w2));
         lds9_put<LT>(lds, SWZ(e0 + 2 * dq), l9::mul(x0, w0));
         lds9_put<LT>(lds, SWZ(e0 + 3 * dq), l9::mul(x0, w3));
       } else {
-        const L9 x0 = lds9_get<LT>(lds, SWZ(e0)), x1 = lds9_get<LT>(lds, SWZ(e0 + dq));
+        const L9 x0 = DIRECT ? xin[0] : lds9_get<LT>(lds, SWZ(e0)), x1 = DIRECT ? xin[1] : lds9_get<LT>(lds, SWZ(e0 + dq));
         L9 c0 = l9::add(x0, x1);                                                           // [0, 2p)
         l9::normalize(c0);
         lds9_put<LT>(lds, SWZ(e0), c0);
@@ -252,8 +264,9 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       __syncthreads();
       continue;
     }
-    const L9 x0 = lds9_get<LT>(lds, SWZ(e0)), x1 = lds9_get<LT>(lds, SWZ(e0 + dq));
-    const L9 x2 = lds9_get<LT>(lds, SWZ(e0 + 2 * dq)), x3 = lds9_get<LT>(lds, SWZ(e0 + 3 * dq));     // I: normalised, |value| < 4p
+    const bool from_regs = DIRECT && SH::U0 == 0 && r == 0;   // (e0 == tid, dq == 256: the thread's own loads)
+    const L9 x0 = from_regs ? xin[0] : lds9_get<LT>(lds, SWZ(e0)), x1 = from_regs ? xin[1] : lds9_get<LT>(lds, SWZ(e0 + dq));
+    const L9 x2 = from_regs ? xin[2] : lds9_get<LT>(lds, SWZ(e0 + 2 * dq)), x3 = from_regs ? xin[3] : lds9_get<LT>(lds, SWZ(e0 + 3 * dq));     // I: normalised, |value| < 4p
     mem_phase(false);
     const L9 b0 = l9::add(x0, x2), b1 = l9::add(x1, x3);                                   // limbs [0, 2^30), |value| < 8p
     L9 c0 = l9::add(b0, b1);                                                               // limbs [0, 2^31), |value| < 16p
@@ -274,7 +287,9 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     } else {
       // clamp the pure sum at once: c0 leaves the registers before the multiplier chains start (holding it and its
       // q*p row across them spills at 128 VGPRs: +1 GB of scratch writes per pass, profiles/r02b)
-      l9::clamp_apply(c0, l9::clamp_row(nqp, l9::clamp_q(c0.v[8])));                       // [0, p + 2^239)
+      // (a first round fed by the loads: four values < p + 2^239, their sum < 4.001 p needs the carries only -- and no q*p table yet)
+      if (from_regs) l9::normalize(c0);
+      else l9::clamp_apply(c0, l9::clamp_row(nqp, l9::clamp_q(c0.v[8])));                  // [0, p + 2^239)
       lds9_put<LT>(lds, SWZ(e0), c0);
       // block 0 of stages (u, u + 1) = the quads whose elements all lie below n / 2^(t + 2): here exactly q < period in the
       // tiles that hold block 0.  Their three multiplies that leave block 0 (c1, c2, c3) take the converting set; c0 stays a
