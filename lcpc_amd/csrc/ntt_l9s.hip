@@ -280,10 +280,25 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
       L9 c2 = l9::add(b2, b3);
       L9 c3 = l9::sub(b2, b3);
       l9::normalize(c1); l9::normalize(c2); l9::normalize(c3);
-      lds9_put<LT>(lds, SWZ(e0), c0);
-      lds9_put<LT>(lds, SWZ(e0 + dq), c1);
-      lds9_put<LT>(lds, SWZ(e0 + 2 * dq), c2);
-      lds9_put<LT>(lds, SWZ(e0 + 3 * dq), c3);
+      // dq == 1 here: the quad is four CONSECUTIVE elements of the row, 128 bytes -- reduced and stored from the registers (no LDS round
+      // trip, no barrier; -0.2 ... -0.8 % by shape).  -> [0, p): after the clamp, value >= p needs the top limb to reach floor(p / 2^232)
+      // -- about one element in 2^17; the conditional subtract runs only in the waves that hold such an element
+      mem_phase(true);
+      u32* dstq = a.dst + row * a.dst_stride * NL + (size_t)((tile << S) | e0) * NL;
+      L9 cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        L9 x = cc[c];                                                     // normalised, |value| < 16p
+        l9::clamp_apply(x, l9::clamp_row(nqp, l9::clamp_q(x.v[8])));      // [0, p + 2^239) < 2^256
+        u32 w[8];
+        fe_from29(w, x.v);
+        Fe<NL> v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v.v[i] = w[i];
+        if (__any((int)(x.v[8] >= (u32)P29::limb(8)))) v = fe_reduce_once8(w);
+        fe_store<NL>(dstq + (size_t)c * NL, v);
+      }
+      return;
     } else {
       // clamp the pure sum at once: c0 leaves the registers before the multiplier chains start (holding it and its
       // q*p row across them spills at 128 VGPRs: +1 GB of scratch writes per pass, profiles/r02b)
@@ -336,24 +351,20 @@ __global__ void __launch_bounds__(256, 4) ntt_pass_l9s_kernel(NttPassArgs a, con
     }
     return;
   }
+  if constexpr (FIRST) {           // (a last pass has stored from its final round and returned)
   u32* dst = a.dst + row * a.dst_stride * NL;
 #pragma unroll
   for (u32 e = tid; e < T; e += 256) {
     const u32 g = gindex(e);
     L9 x = lds9_get<LT>(lds, SWZ(e));                                        // normalised, |value| < 16p
-    l9::clamp_apply(x, l9::clamp_row(nqp, l9::clamp_q(x.v[8])));        // [0, p + 2^239) < 2^256
+    l9::clamp_apply(x, l9::clamp_row(nqp, l9::clamp_q(x.v[8])));        // [0, p + 2^239) < 2^256: what the successor reads as limbs anyway
     u32 w[8];
     fe_from29(w, x.v);
     Fe<NL> v;
 #pragma unroll
     for (int i = 0; i < 8; i++) v.v[i] = w[i];
-    if constexpr (LAST) {
-      // -> [0, p): after the clamp, value >= p needs the top limb to reach floor(p / 2^232) -- about one element in 2^17;
-      // the conditional subtract runs only in the waves that hold such an element
-      if (__any((int)(x.v[8] >= (u32)P29::limb(8)))) v = fe_reduce_once8(w);
-      if (canon && tile == 0 && g < a.mont_prefix) v = fe_canon_r29(v); // canonical output: the never-multiplied prefix
-    }
     fe_store<NL>(dst + (size_t)g * NL, v);
+  }
   }
 }
 
@@ -555,6 +566,8 @@ hipError_t launch_ntt_l9s_pack(const NttPassArgs& a, bool first, const NttPackIn
 hipError_t launch_ntt_pass_l9s(const NttPassArgs& a, bool first, const uint32_t* pack, const NttPackInfo& pi, hipStream_t st) {
   if (!first) {
     if (a.s != 10 || a.log_tj != 0 || a.t0 + a.s != a.log_n) return hipErrorInvalidValue;
+    // (the last pass has a uniform round and converts block 0 before it: no Montgomery-form prefix is left for the store to reduce)
+    if (a.mont_prefix) return hipErrorInvalidValue;
     return launch_t<10, 0, false>(a, pack, pi, st);
   }
   // two-pass plans: s + 10 stages in all; three-pass plans: s + 20 (the first pass works at element stride 2^20)
