@@ -136,8 +136,16 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
   };
   for (u32 i = tid; i < 64 * FT::STRIDE; i += 256) nqp[i] = 0u - a.qp29[i];
   const u32* src = a.src + row * a.src_stride * NL;
+  // The four elements a thread loads, e = tid + 256 it, ARE the quad (the two pairs) of its first round (dq = 256 there whatever the
+  // pass shape): they go to that round in registers -- no LDS round trip, and no barrier, since that round's pure sum is a sum of
+  // loads and is normalised, not clamped (the q*p table is first read a round later).  As in K1s (ntt_l9s.hip)
+  // DOUT: a last pass stores from its final round's registers (below) -- Ft63 / Ft127; Ft191's 24-byte elements make those stores a 16 + 8
+  // byte pair at a lane stride of 96 bytes, which costs more than the LDS round trip saves (2^24: 1.648 -> 1.680 ms, 2^20 +5 %)
+  constexpr bool DOUT = N <= 5;
+  E xin[4];
 #pragma unroll
-  for (u32 e = tid; e < T; e += 256) {
+  for (u32 it = 0; it < 4; it++) {
+    const u32 e = tid + 256u * it;
     const u32 g = gindex(e);
     Fe<NL> v;
     if constexpr (FIRST) {        // zero padding, the ragged tail of the caller's vector and the coeffs copy exist here only
@@ -146,9 +154,8 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
     } else {
       v = fe_load<NL>(src + (size_t)g * NL);                 // < 2^(32 NL) (the first pass's store), not necessarily < p
     }
-    planes_put<FT>(lds, T, SWZ(e), ln::from_packed<FT>(v));
+    xin[it] = ln::from_packed<FT>(v);
   }
-  __syncthreads();
   const u32* cls_pack = pack + (size_t)(FIRST ? tile : 0u) * pi.class_words;
   const bool canon = a.roots29c != nullptr && ((u32)row & a.canon_row_mask) == 0;     // (wave-uniform; three-pass plans: kernels.h)
   // tiles that hold elements of "block 0" (never multiplied so far); a.blk0_gone: an earlier pass with a uniform round converted what
@@ -164,17 +171,20 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
     for (u32 pp = 0; pp < 2; pp++) {
       const u32 e1 = tid + 256u * pp;                        // slots with the top stage bit clear are [0, half)
       const E w = planes_get<FT>(blk, 2 * SH::period2, (canon ? SH::period2 : 0u) + e1);   // stage 0 is all block 0
-      const E x = planes_get<FT>(lds, T, SWZ(e1));
+      const E x = xin[pp];
+      if (pp == 0) mem_phase(false);
       if (zero_hi) {
+        planes_put<FT>(lds, T, SWZ(e1), x);
         planes_put<FT>(lds, T, SWZ(e1 + half), ln::mul<FT>(x, w));         // (x, 0) -> (x, x w)
       } else {
-        const E y = planes_get<FT>(lds, T, SWZ(e1 + half));
+        const E y = xin[pp + 2];
         E sum = ln::add(x, y);                               // [0, 2p + 128 B)
         ln::normalize<FT>(sum);
         planes_put<FT>(lds, T, SWZ(e1), sum);
         planes_put<FT>(lds, T, SWZ(e1 + half), ln::mul<FT>(ln::sub(x, y), w));
       }
     }
+    mem_phase(true);
     __syncthreads();
   }
 
@@ -230,12 +240,13 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
       const E w3 = planes_get<FT>(blk, 6 * period, (vb + 1) * period + jl);
       mem_phase(false);
       if (a.n_valid <= (1ull << (k - 2))) {                  // rate <= 1/4: x1 is zero too
-        const E x0 = planes_get<FT>(lds, T, SWZ(e0));
+        const E x0 = xin[0];
+        planes_put<FT>(lds, T, SWZ(e0), x0);
         planes_put<FT>(lds, T, SWZ(e0 + dq), ln::mul<FT>(x0, w2));
         planes_put<FT>(lds, T, SWZ(e0 + 2 * dq), ln::mul<FT>(x0, w0));
         planes_put<FT>(lds, T, SWZ(e0 + 3 * dq), ln::mul<FT>(x0, w3));
       } else {
-        const E x0 = planes_get<FT>(lds, T, SWZ(e0)), x1 = planes_get<FT>(lds, T, SWZ(e0 + dq));
+        const E x0 = xin[0], x1 = xin[1];
         E c0 = ln::add(x0, x1);
         ln::normalize<FT>(c0);
         planes_put<FT>(lds, T, SWZ(e0), c0);
@@ -248,25 +259,50 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
       __syncthreads();
       continue;
     }
-    const E x0 = planes_get<FT>(lds, T, SWZ(e0)), x1 = planes_get<FT>(lds, T, SWZ(e0 + dq));
-    const E x2 = planes_get<FT>(lds, T, SWZ(e0 + 2 * dq)), x3 = planes_get<FT>(lds, T, SWZ(e0 + 3 * dq));   // I: normalised, |value| < 4p
+    const bool from_regs = SH::U0 == 0 && r == 0;             // (e0 == tid, dq == 256: the thread's own loads)
+    const E x0 = from_regs ? xin[0] : planes_get<FT>(lds, T, SWZ(e0)), x1 = from_regs ? xin[1] : planes_get<FT>(lds, T, SWZ(e0 + dq));
+    const E x2 = from_regs ? xin[2] : planes_get<FT>(lds, T, SWZ(e0 + 2 * dq)), x3 = from_regs ? xin[3] : planes_get<FT>(lds, T, SWZ(e0 + 3 * dq));   // I: normalised, |value| < 4p
     mem_phase(false);
     const E b0 = ln::add(x0, x2), b1 = ln::add(x1, x3);                                           // limbs [0, 2^(W+1)), |value| < 8p
     E c0 = ln::add(b0, b1);                                                                       // limbs [0, 2^(W+2)), |value| < 16p
-    if (last_two) ln::normalize<FT>(c0);                                                          // (the store path clamps every slot)
+    if (last_two || from_regs) ln::normalize<FT>(c0);                                             // (the store path clamps every slot; sums of loads < 4.01 p)
     else ln::clamp_apply<FT>(c0, ln::clamp_row<FT>(nqp, ln::clamp_q<FT>(c0.v[N - 1])));           // [0, p + 64 B)
-    planes_put<FT>(lds, T, SWZ(e0), c0);
+    if (!(last_two && DOUT)) planes_put<FT>(lds, T, SWZ(e0), c0);
     if (last_two) {
-      // outputs go straight to the store path (normalised, |value| < 16p)
+      // outputs go straight to the store (normalised, |value| < 16p)
       E c1 = ln::sub(b0, b1);
       const E b2 = ln::sub(x0, x2);
       const E b3 = mul_i<FT>(ln::sub(x1, x3), a);                                                 // w^(n/4): the one twiddle every lane shares
       E c2 = ln::add(b2, b3);
       E c3 = ln::sub(b2, b3);
       ln::normalize<FT>(c1); ln::normalize<FT>(c2); ln::normalize<FT>(c3);
-      planes_put<FT>(lds, T, SWZ(e0 + dq), c1);
-      planes_put<FT>(lds, T, SWZ(e0 + 2 * dq), c2);
-      planes_put<FT>(lds, T, SWZ(e0 + 3 * dq), c3);
+      // dq == 1 here: the quad is four CONSECUTIVE elements of the row -- reduced and stored from the registers (no LDS round trip, no
+      // barrier; ntt_l9s.hip).  -> [0, p): after the clamp, value >= p needs the top limb to reach floor(p / B)
+      if constexpr (!DOUT) {
+        planes_put<FT>(lds, T, SWZ(e0 + dq), c1);
+        planes_put<FT>(lds, T, SWZ(e0 + 2 * dq), c2);
+        planes_put<FT>(lds, T, SWZ(e0 + 3 * dq), c3);
+      } else {
+      mem_phase(true);
+      u32* dstq = a.dst + row * a.dst_stride * NL + (size_t)((tile << S) | e0) * NL;
+      E cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        E x = cc[c];
+        ln::clamp_apply<FT>(x, ln::clamp_row<FT>(nqp, ln::clamp_q<FT>(x.v[N - 1])));  // [0, p + 64 B) < 2^(32 NL)
+        u32 w[NL];
+        ln::to_packed<FT>(w, x.v);
+        Fe<NL> v;
+        if (__any((int)(x.v[N - 1] >= FT::limb(N - 1)))) v = fe_reduce_once<NL>(w, 0u);
+        else {
+#pragma unroll
+          for (int i = 0; i < NL; i++) v.v[i] = w[i];
+        }
+        if (canon && tile == 0 && e0 + (u32)c < a.mont_prefix) v = fe_canon<NL>(v);     // canonical output: the never-multiplied prefix (Ft63)
+        fe_store<NL>(dstq + (size_t)c * NL, v);
+      }
+      return;
+      }
     } else {
       // block 0 of stages (u, u + 1) = the quads whose elements all lie below n / 2^(t + 2): exactly q < period in the tiles
       // that hold block 0.  Their three multiplies that leave block 0 (c1, c2, c3) take the converting set; c0 stays a pure sum;
@@ -295,28 +331,25 @@ __global__ void __launch_bounds__(256, FT::WAVES) ntt_pass_lns_kernel(NttPassArg
     __syncthreads();
   }
 
+  if constexpr (FIRST || N > 5) {           // (a last pass with DOUT has stored from its final round and returned)
   u32* dst = a.dst + row * a.dst_stride * NL;
 #pragma unroll
   for (u32 e = tid; e < T; e += 256) {
     const u32 g = gindex(e);
     E x = planes_get<FT>(lds, T, SWZ(e));                                            // normalised, |value| < 16p
-    ln::clamp_apply<FT>(x, ln::clamp_row<FT>(nqp, ln::clamp_q<FT>(x.v[N - 1])));  // [0, p + 64 B) < 2^(32 NL)
+    ln::clamp_apply<FT>(x, ln::clamp_row<FT>(nqp, ln::clamp_q<FT>(x.v[N - 1])));  // [0, p + 64 B) < 2^(32 NL): the successor reads limbs anyway
     u32 w[NL];
     ln::to_packed<FT>(w, x.v);
     Fe<NL> v;
+#pragma unroll
+    for (int i = 0; i < NL; i++) v.v[i] = w[i];
     if constexpr (LAST) {
       // -> [0, p): after the clamp, value >= p needs the top limb to reach floor(p / B)
       if (__any((int)(x.v[N - 1] >= FT::limb(N - 1)))) v = fe_reduce_once<NL>(w, 0u);
-      else {
-#pragma unroll
-        for (int i = 0; i < NL; i++) v.v[i] = w[i];
-      }
       if (canon && tile == 0 && g < a.mont_prefix) v = fe_canon<NL>(v); // canonical output: the never-multiplied prefix
-    } else {
-#pragma unroll
-      for (int i = 0; i < NL; i++) v.v[i] = w[i];
     }
     fe_store<NL>(dst + (size_t)g * NL, v);
+  }
   }
 }
 
