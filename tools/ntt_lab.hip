@@ -654,8 +654,12 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&pa, (size_t)n_cls_A * qa.class_words * 4)); CHECK(hipMalloc(&pb, (size_t)qb.class_words * 4));
     CHECK(launch_ntt_l9s_pack(B.pa, true, qa, n_cls_A, pa, nullptr)); CHECK(launch_ntt_l9s_pack(B.pb, false, qb, 1, pb, nullptr));
     CHECK(hipDeviceSynchronize());
-    time_variant("library ntt_pass_l9s_kernel", B, [&](const NttPassArgs& x) { CHECK(launch_ntt_pass_l9s(x, true, pa, qa, nullptr)); },
-                 [&](const NttPassArgs& x) { CHECK(launch_ntt_pass_l9s(x, false, pb, qb, nullptr)); });
+    // (since round 6 the library's passes convert block 0 before their uniform rounds: no Montgomery prefix reaches the last store, the first
+    // pass of 8 stages has left none -- blk0_gone -- and both take the shifted multiples of w^(n/4), which this lab does not build:
+    // run it from a context's tables, or expect this variant to be skipped)
+    time_variant("library ntt_pass_l9s_kernel", B, [&](const NttPassArgs& x) { if (x.wq_w) CHECK(launch_ntt_pass_l9s(x, true, pa, qa, nullptr)); },
+                 [&](const NttPassArgs& x) { NttPassArgs y = x; y.mont_prefix = 0; y.blk0_gone = y.roots29c ? 1u : 0u;
+                                            if (y.wq_w) CHECK(launch_ntt_pass_l9s(y, false, pb, qb, nullptr)); });
     check("library l9s");
   }
   time_variant("general kernel again", B, prod, prod);
