@@ -17,6 +17,10 @@
 //     final conditional subtract; the last pass does that subtract only for the rare waves that need it;
 //   * an odd stage count is peeled as a radix-2 round at stage 0, where a zero-padded row (rate <= 1/2) needs no
 //     additions at all: (x, 0) -> (x, x w).
+//   * (round 6) a tile makes no LDS round trip it does not need: the four elements a thread loads are its first round's quad, which
+//     therefore runs from the registers with no barrier before it; the last pass's final round owns four consecutive elements and
+//     reduces and stores them itself;
+//   * (round 6) a wave holds priority 1 while it issues memory instructions and 0 inside the multiplier chains (field_dev.h mem_phase).
 // Exact modular arithmetic: any stage grouping gives the same fully-reduced bits as the reference's radix-2 loop.
 #include "kernels.h"
 #include "ntt_l9_dev.h"

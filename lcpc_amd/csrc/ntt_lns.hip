@@ -17,8 +17,12 @@
 // root of unity, so t = (x1 - x3) I, c2 = ((x0 - x2) + t) w0, c3 = ((x0 - x2) - t) w^(3e): three lane-varying multiplies and one by a
 // constant every lane shares -- the shifted-multiples multiply with scalar operands for Ft127 / Ft191 (ln::mul_u), the ordinary
 // one on a broadcast table entry for Ft63, whose 3-limb Montgomery multiply is the shorter of the two.
+// Round 6 also brought over from K1s: the uniform rounds (Ft127 / Ft191: Shape::RU, the swizzled tile, block 0 converted one round
+// earlier, so that for these two fields nothing is left in Montgomery form at the store -- only Ft63 still has the 4-element prefix),
+// the wave priorities (field_dev.h mem_phase), the first round run from the thread's own loads, and -- Ft63 / Ft127 -- the final
+// round of a last pass storing its four consecutive elements itself.
 // Exact modular arithmetic: any stage grouping gives the same fully-reduced bits as the reference's radix-2 loop.
-// The general kernel (kernels.hip ntt_pass_kernel) remains for one-pass rows, three-pass plans and as the A/B reference
+// The general kernel (kernels.hip ntt_pass_kernel) remains for one-pass rows, plans whose tables do not fit and as the A/B reference
 // (LCPC_NTT_GENERAL=1; tests/test_gpu_ntt_shapes.py).
 #include "kernels.h"
 #include "field_ln.h"
