@@ -600,6 +600,10 @@ int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uin
   if (padded > n_coeffs)
     HIPCHK(m, hipMemsetAsync(reinterpret_cast<uint8_t*>(m->d_coeffs) + total_bytes, 0, (size_t)(padded - n_coeffs) * eb, m->s_copy));
   const uint64_t rows_per = (n_rows + NB - 1) / NB;
+  const uint64_t n_chunks = leaf_chunks(c, n_rows);
+  uint64_t chunks_hashed = 0;
+  m->comm_t = false;                                        // (Ligero: row-major comm; leaf_args reads it)
+  if (n_chunks > 1 && (rc = ensure_cvs(m, n_chunks))) return rc;
   for (int b = 0; b < NB; b++) {
     const uint64_t r0 = (uint64_t)b * rows_per;
     if (r0 >= n_rows) break;
@@ -613,9 +617,29 @@ int lcpc_commit(lcpc_commit_t* m, const uint64_t* coeffs, uint64_t n_coeffs, uin
     j.src = m->d_coeffs + (size_t)r0 * c->n_per_row * c->NL; j.src_stride = c->n_per_row; j.n_valid = c->n_per_row;
     j.dst = m->d_comm + (size_t)r0 * c->n_cols * c->NL; j.n_rows = r1 - r0; j.canon_out = c->comm_canon;
     if ((rc = encode_rows_device(c, &m->ws, j, m->s_comp, &m->err, &m->launches[0]))) return rc;
+    // the column hash chunk by chunk behind the rows it needs (a 1 KiB chunk of the leaf message 0^32 || repr(col[0]) || ... spans
+    // 1024 / F rows, lib.rs:719-735): the chunks the encoded rows complete are hashed now, under the upload of the next batches, and
+    // only the last batch's chunks, the fold and the tree remain behind the bus -- the reference hashes after its encode loop
+    // (lib.rs:648-671), same digests
+    if (n_chunks > 1) {
+      const uint64_t done = r1 == n_rows ? n_chunks : std::min<uint64_t>(n_chunks, (32 + (uint64_t)eb * r1) / 1024);
+      if (done > chunks_hashed) {
+        LeafArgs la = leaf_args(m);
+        la.row_base = 0; la.n_chunks_total = (uint32_t)n_chunks;
+        la.chunk_begin = (uint32_t)chunks_hashed; la.n_chunks_local = (uint32_t)(done - chunks_hashed);
+        la.out = m->d_cvs + chunks_hashed * c->n_cols * 8;
+        HIPCHK(m, launch_leaf_chunks(c->NL, la, m->s_comp));
+        m->launches[1]++;
+        chunks_hashed = done;
+      }
+    }
   }
   m->coeffs_view = m->d_coeffs;
-  if ((rc = merkleize_device(m, m->s_comp))) return rc;
+  if (n_chunks > 1) {
+    HIPCHK(m, launch_leaf_finish(m->d_cvs, (uint32_t)n_chunks, c->n_cols, m->d_hashes, m->s_comp));
+    m->launches[1]++;
+    if ((rc = merkle_top(m, m->s_comp))) return rc;
+  } else if ((rc = merkleize_device(m, m->s_comp))) return rc;
   if (root) HIPCHK(m, hipMemcpyAsync(root, m->d_hashes + (2 * c->np2 - 2) * 8, 32, hipMemcpyDeviceToHost, m->s_comp));
   HIPCHK(m, hipStreamSynchronize(m->s_comp));              // later calls use the null stream / caller streams
   HIPCHK(m, hipStreamSynchronize(m->s_copy));              // (the tail memset when no batch followed it)
