@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/profile_round.sh TAG -- everything profiles/ holds for one state of the code, as text, under gpurun_out/prof_TAG/:
-#   bench_line.json           python bench.py (un-profiled, with the CPU baseline)
+#   bench_line.json           python bench.py (un-profiled, with the CPU baseline and the configs; run AFTER the counter passes, which it quotes)
 #   bench_kernel_stats.txt    rocprofv3 --kernel-trace --stats of the same command (no CPU baseline)
 #   bench_pmc_{fetch,write,sq}.txt + pmc.json     separate --pmc passes (never combined with traces)
 #   clock_power.txt           rocm-smi sclk / socket power sampled while the bench loops
@@ -13,7 +13,6 @@ O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 5 --warmup 1 --lean"
-python $R/bench.py > $O/bench_line.json 2> $O/bench_stderr.log
 db() { find $1 -name '*.db' | head -1; }
 rocprofv3 --kernel-trace --stats -d $O/kt -o bench -- $BENCH > $O/kt.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/kt) > $O/bench_kernel_stats.txt
@@ -25,6 +24,11 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BA
   -d $O/sq -o bench -- python $R/bench.py --steps 2 --warmup 1 --lean > $O/sq.log 2>&1
 python $R/tools/rocpd_summary.py $(db $O/sq) --pmc > $O/bench_pmc_sq.txt
 python $R/tools/pmc_to_json.py $(db $O/fetch) $(db $O/write) $O/pmc.json $(db $O/sq) > /dev/null      # -> copy to profiles/pmc_latest.json
+# the bench line LAST among the bench.py runs, with this call's counters and instruction mix in place (on this box's copy of the
+# repo), so that roofline.traffic / valu_issue of bench_line.json speak about the very sources being run
+cp $O/pmc.json $R/profiles/pmc_latest.json
+python $R/tools/isa_mix.py $R/profiles/valu_mix_latest.json > /dev/null 2> $O/isa_mix.log && cp $R/profiles/valu_mix_latest.json $O/valu_mix.json
+python $R/bench.py > $O/bench_line.json 2> $O/bench_stderr.log
 # clocks / power while the bench loops
 python $R/bench.py --steps 1200 --warmup 2 --no-cpu-baseline > $O/clk_bench.log 2>&1 &
 BP=$!
