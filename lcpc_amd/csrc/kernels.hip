@@ -537,19 +537,26 @@ __device__ __forceinline__ void leaf_chunk_cv(const LeafArgs& a, u64 col, u32 ch
   };
   if constexpr (NL != 6) {
     // every block starts on an element boundary (PH == 0): software-pipeline the loads one block ahead
+    // (two blocks per trip, their operands in two register sets that swap roles: no copy of the block fetched ahead)
     int ph;
-    LeafRaw<NL, 0> cur, nxt;
-    leaf_load_raw<NL, 0>(cur, a, col, block_row0(0, ph));
-    for (u32 b = 0; b < nblocks; b++) {
-      if (b + 1 < nblocks) leaf_load_raw<NL, 0>(nxt, a, col, block_row0(b + 1, ph));
+    LeafRaw<NL, 0> ra, rb;
+    auto one = [&](const LeafRaw<NL, 0>& r, u32 b) {
       u32 m[16];
-      leaf_build_block<NL, 0, CANON>(m, cur);
+      leaf_build_block<NL, 0, CANON>(m, r);
       const u32 rem = chunk_len - 64 * b;
       const u32 blen = rem < 64 ? rem : 64;
       u32 flags = (b == 0 ? B3_CHUNK_START : 0u);
       if (b == nblocks - 1) flags |= B3_CHUNK_END | (a.n_chunks_total == 1 ? B3_ROOT : 0u);
       compress(m, blen, flags);
-      cur = nxt;
+    };
+    leaf_load_raw<NL, 0>(ra, a, col, block_row0(0, ph));
+    for (u32 b = 0; b < nblocks; b += 2) {
+      if (b + 1 < nblocks) leaf_load_raw<NL, 0>(rb, a, col, block_row0(b + 1, ph));
+      one(ra, b);
+      if (b + 1 < nblocks) {
+        if (b + 2 < nblocks) leaf_load_raw<NL, 0>(ra, a, col, block_row0(b + 2, ph));
+        one(rb, b + 1);
+      }
     }
   } else {
     for (u32 b = 0; b < nblocks; b++) {
