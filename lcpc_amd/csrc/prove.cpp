@@ -382,8 +382,10 @@ int lcpc_verify(lcpc_ctx* c, const uint8_t root[32], const uint64_t* outer, uint
   std::vector<uint8_t> leaf(n_columns * 32);
   uint64_t eval_acc[MAXL] = {0, 0, 0, 0};
   // to_repr of the polynomials is published in chunks: the transcript starts absorbing a polynomial as soon as its first
-  // chunk is there instead of waiting for all of it (0.3 ms per polynomial at 2^26)
-  constexpr uint64_t CANON_CHUNK = 8192;
+  // chunk is there instead of waiting for all of it.  1024 elements per chunk (50 us of conversion on one pool thread): with 8192 a
+  // polynomial of <= 8192 coefficients was ONE chunk converted by one thread (0.4 ms) in front of its absorb -- verify at 2^19
+  // 2.75 -> 1.05 ms, at 2^23 4.6 -> 3.7, at 2^26 14.2 -> 13.8 (the absorbs alone: 13.5)
+  constexpr uint64_t CANON_CHUNK = 1024;
   const uint64_t n_cchunks = (n_per_row + CANON_CHUNK - 1) / CANON_CHUNK;
   std::unique_ptr<std::atomic<uint8_t>[]> canon_done(new std::atomic<uint8_t>[(n_deg + 1) * n_cchunks + 1]);
   for (uint64_t i = 0; i < (n_deg + 1) * n_cchunks; i++) canon_done[i].store(0, std::memory_order_relaxed);
