@@ -7,7 +7,12 @@ import torch, bench
 from lcpc_amd import LcCommit, LigeroEncoding, Transcript
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 19
 n = 1 << lg
-enc = LigeroEncoding.new(3, n)
+kind = sys.argv[2] if len(sys.argv) > 2 else "ligero"
+if kind == "sdig":
+    from lcpc_amd import SdigEncoding
+    enc = SdigEncoding.new(3, n, 0)
+else:
+    enc = LigeroEncoding.new(3, n)
 dev = enc.random_coeffs_device(n, seed=0)
 st = torch.cuda.current_stream().cuda_stream
 c = LcCommit.commit_device(dev.data_ptr(), n, enc, st)
