@@ -185,6 +185,8 @@ struct lcpc_commit_s {
   bool shard_encoded = false;      // split phases: the encode step of a sharded commit has been enqueued, hash / finish / merkle may follow
   hipStream_t s_copy = nullptr, s_comp = nullptr;   // lcpc_commit (host pointer): H2D of row batch b+1 overlaps the NTTs of batch b
   hipEvent_t ev_batch[16] = {nullptr};
+  std::mutex prove_mu;             // held for a whole prove on this commitment: the pinned arena, the slice events and the scratch layout are
+                                   // per object (LcCommit::prove takes &self: concurrent proves on ONE commitment queue up, on different ones run side by side)
   hipEvent_t ev_slice[2] = {nullptr, nullptr};   // prove: arrival of the two column ranges of p_random on the host (collapse_host_sliced)
   lcpc_timings last{};
   uint32_t launches[3] = {0, 0, 0};

@@ -77,6 +77,7 @@ void proof_buf_free(void* p) {
 int prove_impl(lcpc_commit_t* m, const uint64_t* outer, uint64_t n_outer, lcpc_transcript* trw, uint8_t** proof, uint64_t* proof_len,
                uint64_t* cols_opened, const ShardXchg* xchg) {
   if (!m || !outer || !trw || !proof || !proof_len) return LCPC_ERR_ARG;
+  std::lock_guard<std::mutex> prove_lock(m->prove_mu);
   if (!m->committed) return LCPC_ERR_STATE;
   lcpc_ctx* c = m->enc;
   if (c->prm.shard_count > 1 && !xchg) return LCPC_ERR_STATE;   // sharded commitments prove through lcpc_prove_sharded*

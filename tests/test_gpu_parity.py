@@ -639,3 +639,37 @@ def test_prove_long_polynomial_two_ranges(oracle, kind, fid, n_per_row, n_cols, 
         pf = c.prove(outer, enc, mk_transcript(Transcript, root, nco))
         opf, _ = oc.prove(outer, oenc, mk_transcript(O.Transcript, root, nco))
         assert pf.to_bytes() == opf
+
+
+def test_concurrent_proves_on_one_commitment(oracle):
+    """LcCommit::prove takes &self (lcpc-2d/src/lib.rs:304-311): two host threads may prove the same commitment at once.  The pinned arena and the
+    slice events belong to the object, so such calls queue up inside the library -- every proof must still be the oracle prover's."""
+    import threading
+    O, fid = oracle, 3
+    n_per_row, n_cols, n_rows = 32768, 65536, 24
+    enc = LigeroEncoding.new_from_dims(fid, n_per_row, n_cols)
+    oenc = O.Encoding.ligero_from_dims(fid, n_per_row, n_cols)
+    coeffs = O.random_elems(fid, n_rows * n_per_row - 7, 91)
+    c = LcCommit.commit(coeffs, enc)
+    oc = O.Commit.commit(coeffs, oenc, n_threads=8)
+    root = c.get_root()
+    assert root == oc.get_root()
+    nco = enc.get_n_col_opens()
+    outers = [O.random_elems(fid, c.n_rows, 200 + k) for k in range(4)]
+    want = [oc.prove(t, oenc, mk_transcript(O.Transcript, root, nco))[0] for t in outers]
+    got, errs = [None] * 4, []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                got[k] = c.prove(outers[k], enc, mk_transcript(Transcript, root, nco)).to_bytes()
+        except Exception as ex:      # pragma: no cover
+            errs.append(ex)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs
+    assert got == want
